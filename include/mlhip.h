@@ -1,0 +1,144 @@
+/* mlhip.h -- C ABI of the MI355X (gfx950) Gaussian-mixture EM / K-means hot path.
+ *
+ * Drop-in boundary. The reference (romanwerpachowski/ML, "ML++") has no FFI of its own for this
+ * path: the hot loops are private C++ member functions. Each entry point below is the device-side
+ * replacement of one of them and cites the reference function it stands in for (paths relative to
+ * the reference checkout). The C++ facade in include/ML/ (ml::EM, ml::Clustering::KMeans -- same
+ * names and semantics as ML/EM.hpp, ML/KMeans.hpp) and the Python surface ml_amd.cppyml.clustering
+ * (same names as cppyml/clustering.cpp) are built on these calls only.
+ *
+ * Conventions
+ *  - plain C types only; every function returns 0 on success, <0 on error (MLHIP_E_*);
+ *    mlhip_last_error() gives the thread-local message of the last failure;
+ *  - matrices are column-major, one sample per column (d x N), exactly the memory of the reference's
+ *    `Eigen::Ref<const Eigen::MatrixXd> data` (ML/Clustering.hpp:28-33) == a C-contiguous N x d numpy
+ *    array (cppyml/clustering.cpp:27-30). `ld` = distance in doubles between consecutive samples;
+ *  - all pointers are HOST pointers owned by the caller unless a name ends in `_dev`;
+ *  - one context drives one GPU (one process per GPU); a context is not thread-safe;
+ *  - there is no CPU fallback: without a usable HIP device every compute entry point fails with
+ *    MLHIP_E_NO_DEVICE.
+ */
+#ifndef MLHIP_H
+#define MLHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLHIP_OK 0
+#define MLHIP_E_INVALID_ARGUMENT (-1) /* maps to std::invalid_argument in the facade */
+#define MLHIP_E_DOMAIN (-2)           /* maps to std::domain_error */
+#define MLHIP_E_RUNTIME (-3)          /* HIP / collective failure: std::runtime_error */
+#define MLHIP_E_NO_DEVICE (-4)        /* no usable GPU: std::runtime_error */
+#define MLHIP_E_UNSUPPORTED (-5)      /* shape outside what the kernels are built for */
+
+typedef struct mlhip_ctx mlhip_ctx;   /* one GPU + stream + scratch */
+typedef struct mlhip_data mlhip_data; /* a d x N sample block resident in HBM (row shard of this rank) */
+
+const char* mlhip_last_error(void);
+const char* mlhip_version(void);
+
+/* ---- context ------------------------------------------------------------------------------------ */
+int mlhip_device_count(int* count);
+/* device_id < 0: take MLHIP_DEVICE, else LOCAL_RANK, else 0. */
+int mlhip_ctx_create(int device_id, mlhip_ctx** out);
+int mlhip_ctx_destroy(mlhip_ctx* ctx);
+int mlhip_ctx_synchronize(mlhip_ctx* ctx);
+int mlhip_ctx_device(const mlhip_ctx* ctx, int* device_id);
+/* The HIP stream (hipStream_t) every kernel of this context is launched on. */
+int mlhip_ctx_stream(const mlhip_ctx* ctx, void** stream);
+
+/* Row-sharded multi-GPU: the N samples are split across `world_size` ranks; the only
+ * exchange is one sum all-reduce per iteration of the sufficient statistics. The library calls `fn` on the
+ * buffer to be summed in place across ranks; with on_device != 0 `buf` is a device pointer valid on the
+ * context's stream (hand it to RCCL / torch.distributed "nccl"), else a host pointer (gloo, MPI).
+ * The hook must return only when `buf` holds the global sum and is safe to read from the context's stream.
+ * fn == NULL restores single-rank behaviour. */
+typedef int (*mlhip_allreduce_fn)(void* user, double* buf, size_t count, int on_device, void* stream);
+int mlhip_ctx_set_allreduce(mlhip_ctx* ctx, mlhip_allreduce_fn fn, void* user, int on_device,
+                            int world_size, int rank);
+
+/* ---- resident data ------------------------------------------------------------------------------ */
+/* Copies this rank's d x n block to HBM (stored dimension-major for coalesced per-sample access) and
+ * computes the statistics shift (global column mean; all-reduced when a hook is set). The host block is
+ * only read during the call (the reference borrows `data` for the duration of fit, ML/EM.cpp:91). */
+int mlhip_data_upload(mlhip_ctx* ctx, const double* x, uint32_t d, uint64_t n, int64_t ld, mlhip_data** out);
+/* Same, from a sample-major block already in device memory (e.g. a torch tensor's data_ptr()). */
+int mlhip_data_upload_dev(mlhip_ctx* ctx, const double* x_dev, uint32_t d, uint64_t n, int64_t ld, mlhip_data** out);
+int mlhip_data_free(mlhip_data* data);
+int mlhip_data_shape(const mlhip_data* data, uint32_t* d, uint64_t* n_local, uint64_t* n_global);
+/* Global column means used as the numerical shift of the second-moment accumulation (d doubles). */
+int mlhip_data_shift(const mlhip_data* data, double* shift);
+
+/* ---- Gaussian-mixture EM -------------------------------------------------------------------------- */
+/* One EM iteration == EM::expectation_step + EM::maximisation_step (ML/EM.cpp:190-263, incl.
+ * process_covariances :274-287) on the resident shard, statistics all-reduced across ranks.
+ *   in : mixing[K], means[d*K] (column k = mean k), covariances[K*d*d] (symmetric, column-major each)
+ *   out: *log_likelihood  = mean_i log sum_k pi_k N(x_i|mu_k,Sigma_k)  under the INPUT parameters (:211)
+ *        mixing_out/means_out/covariances_out = the M-step result (:229-257, ridge 1e-15 included)
+ * Output arrays may alias the input arrays. The unnormalised log-responsibilities of this E-step stay on
+ * the device for mlhip_em_responsibilities / mlhip_em_labels. */
+int mlhip_em_step(mlhip_ctx* ctx, mlhip_data* data, uint32_t K,
+                  const double* mixing, const double* means, const double* covariances,
+                  double* log_likelihood, double* mixing_out, double* means_out, double* covariances_out);
+
+/* E-step only (ML/EM.cpp:190-219): leaves log-responsibilities on the device, returns the log-likelihood. */
+int mlhip_em_expectation(mlhip_ctx* ctx, mlhip_data* data, uint32_t K,
+                         const double* mixing, const double* means, const double* covariances,
+                         double* log_likelihood);
+/* M-step only (ML/EM.cpp:221-263) from the responsibilities left by the last E-step. */
+int mlhip_em_maximisation(mlhip_ctx* ctx, mlhip_data* data, uint32_t K,
+                          double* mixing_out, double* means_out, double* covariances_out);
+/* M-step from caller-given responsibilities (n_local x K column-major, ldr >= n_local): the
+ * `maximise_first` start (ML/EM.cpp:120-125). */
+int mlhip_em_maximisation_from(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* resp, int64_t ldr,
+                               double* mixing_out, double* means_out, double* covariances_out);
+/* M-step from hard labels (one-hot responsibilities, what ClosestCentroid::init produces,
+ * ML/Clustering.cpp:72-89) without materialising N x K on the host. */
+int mlhip_em_maximisation_from_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const uint32_t* labels,
+                                      double* mixing_out, double* means_out, double* covariances_out);
+
+/* Normalised responsibilities of the last E-step, this rank's n_local x K block, column-major
+ * (EM::responsibilities(), ML/EM.hpp:132-135; rows /= row sum, ML/EM.cpp:214-218). */
+int mlhip_em_responsibilities(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, double* resp, int64_t ldr);
+/* argmax_k of those responsibilities, first maximum wins (EM::calculate_labels, ML/EM.cpp:289-304). */
+int mlhip_em_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, uint32_t* labels);
+
+/* (X - mean)(X - mean)^T / (N - 1) over ALL ranks' samples (EM::calculate_sample_covariance,
+ * ML/EM.cpp:265-272). mean may be NULL. */
+int mlhip_sample_covariance(mlhip_ctx* ctx, mlhip_data* data, double* mean, double* covariance);
+
+/* Host helper, no GPU needed: covariance -> what EM::process_covariances (ML/EM.cpp:274-287) derives:
+ * inverse (d*d), sqrt(det). Used by the facade for point queries (EM::assign_responsibilities). */
+int mlhip_process_covariance(uint32_t d, const double* covariance, double* inverse, double* sqrt_det);
+
+/* ---- K-means -------------------------------------------------------------------------------------- */
+/* One Lloyd step == KMeans::assignment_step + the sums KMeans::update_step needs (ML/KMeans.cpp:167-192),
+ * all-reduced across ranks.
+ *   in : centroids[d*K]
+ *   out: *inertia = sum_i min_k |x_i - c_k|^2 ; *n_changed = #labels differing from the previous call on
+ *        this data (first call: n_global); counts[K]; centroids_out[d*K] = per-cluster means, an EMPTY cluster's
+ *        centroid is the origin (:184). Labels stay on the device for mlhip_kmeans_labels. */
+int mlhip_kmeans_step(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* centroids,
+                      double* inertia, uint64_t* n_changed, double* counts, double* centroids_out);
+/* Assignment only (KMeans::assignment_step, :167-178): labels + inertia, no update. */
+int mlhip_kmeans_assign(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* centroids,
+                        double* inertia, uint64_t* n_changed);
+int mlhip_kmeans_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t* labels);
+/* min_k |x_i - c_k|^2 per sample of this rank's shard (the weights of KPP::init, ML/Clustering.cpp:44-51). */
+int mlhip_min_squared_distances(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* centroids, double* dist2);
+
+/* ---- timing (for bench.py / profiling) -------------------------------------------------------------- */
+/* Average device time in ms of the named kernel family over its launches since the last reset, measured with
+ * HIP events on the context's stream. name: "em_estep", "em_mstats", "kmeans_assign". Returns count in *launches. */
+int mlhip_timing_enable(mlhip_ctx* ctx, int on);
+int mlhip_timing_reset(mlhip_ctx* ctx);
+int mlhip_timing_get(mlhip_ctx* ctx, const char* name, double* avg_ms, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLHIP_H */

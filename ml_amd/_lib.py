@@ -1,0 +1,258 @@
+"""ctypes binding of the C ABI (include/mlhip.h). Loads ml_amd/libmlhip.so; never falls back to anything else."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmlhip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(or `make -C ml_amd/csrc`). ml_amd has no CPU fallback.")
+
+lib = C.CDLL(LIB_PATH)
+
+OK, E_INVALID_ARGUMENT, E_DOMAIN, E_RUNTIME, E_NO_DEVICE, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+
+c_dp = C.POINTER(C.c_double)
+c_u32p = C.POINTER(C.c_uint32)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+
+lib.mlhip_last_error.restype = C.c_char_p
+lib.mlhip_version.restype = C.c_char_p
+
+
+class MlhipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+class NoDeviceError(MlhipError):
+    pass
+
+
+def check(rc):
+    if rc == OK:
+        return
+    msg = lib.mlhip_last_error().decode()
+    if rc in (E_INVALID_ARGUMENT, E_DOMAIN):
+        raise ValueError(msg)          # pybind11 maps invalid_argument / domain_error to ValueError
+    if rc == E_NO_DEVICE:
+        raise NoDeviceError(rc, msg)
+    raise MlhipError(rc, msg)
+
+
+def dptr(a):
+    return a.ctypes.data_as(c_dp)
+
+
+def u32ptr(a):
+    return a.ctypes.data_as(c_u32p)
+
+
+def device_count():
+    n = C.c_int()
+    check(lib.mlhip_device_count(C.byref(n)))
+    return n.value
+
+
+class Context:
+    """One GPU + stream (mlhip_ctx)."""
+
+    def __init__(self, device_id=-1):
+        self._h = C.c_void_p()
+        check(lib.mlhip_ctx_create(int(device_id), C.byref(self._h)))
+        self._hook = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.mlhip_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def device(self):
+        d = C.c_int()
+        check(lib.mlhip_ctx_device(self._h, C.byref(d)))
+        return d.value
+
+    @property
+    def stream(self):
+        s = C.c_void_p()
+        check(lib.mlhip_ctx_stream(self._h, C.byref(s)))
+        return s.value or 0
+
+    def synchronize(self):
+        check(lib.mlhip_ctx_synchronize(self._h))
+
+    def set_allreduce(self, fn, on_device, world_size, rank):
+        """fn(ptr:int, count:int, on_device:bool, stream:int) -> None sums the buffer in place across ranks."""
+        if fn is None:
+            self._hook = None
+            check(lib.mlhip_ctx_set_allreduce(self._h, C.cast(None, ALLREDUCE_FN), None, 0, 1, 0))
+            return
+
+        def trampoline(_user, buf, count, on_dev, stream):
+            try:
+                fn(buf or 0, count, bool(on_dev), stream or 0)
+                return 0
+            except Exception:  # surfaced as MLHIP_E_RUNTIME by the library
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._hook = ALLREDUCE_FN(trampoline)
+        check(lib.mlhip_ctx_set_allreduce(self._h, self._hook, None, int(on_device), int(world_size), int(rank)))
+
+    def timing_enable(self, on=True):
+        check(lib.mlhip_timing_enable(self._h, int(on)))
+
+    def timing_reset(self):
+        check(lib.mlhip_timing_reset(self._h))
+
+    def timing_get(self, name):
+        ms, cnt = C.c_double(), C.c_uint64()
+        check(lib.mlhip_timing_get(self._h, name.encode(), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+
+class Data:
+    """A d x N sample block resident in HBM (mlhip_data). `x` is N x d float64 C-contiguous."""
+
+    def __init__(self, ctx, x=None, device_ptr=None, shape=None):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        if x is not None:
+            if not (isinstance(x, np.ndarray) and x.dtype == np.float64 and x.ndim == 2 and x.flags.c_contiguous):
+                raise TypeError("data must be a C-contiguous float64 N x d numpy array")
+            n, d = x.shape
+            check(lib.mlhip_data_upload(ctx.handle, dptr(x), d, C.c_uint64(n), C.c_int64(d), C.byref(self._h)))
+        else:
+            n, d = shape
+            check(lib.mlhip_data_upload_dev(ctx.handle, C.cast(C.c_void_p(device_ptr), c_dp), d, C.c_uint64(n),
+                                            C.c_int64(d), C.byref(self._h)))
+        self.n, self.d = n, d
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.mlhip_data_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def n_global(self):
+        ng = C.c_uint64()
+        check(lib.mlhip_data_shape(self._h, None, None, C.byref(ng)))
+        return ng.value
+
+    @property
+    def shift(self):
+        out = np.empty(self.d)
+        check(lib.mlhip_data_shift(self._h, dptr(out)))
+        return out
+
+    # ---- EM -----------------------------------------------------------------------------------------------
+    # Parameter conventions (Python side): means K x d, covariances K x d x d, mixing K.
+    def em_step(self, mixing, means, covs):
+        K = len(mixing)
+        mixing = np.ascontiguousarray(mixing, dtype=np.float64)
+        means = np.ascontiguousarray(means, dtype=np.float64)
+        covs = np.ascontiguousarray(covs, dtype=np.float64)
+        ll = C.c_double()
+        pi1, mu1, S1 = np.empty(K), np.empty((K, self.d)), np.empty((K, self.d, self.d))
+        check(lib.mlhip_em_step(self.ctx.handle, self._h, K, dptr(mixing), dptr(means), dptr(covs), C.byref(ll),
+                                dptr(pi1), dptr(mu1), dptr(S1)))
+        return ll.value, pi1, mu1, S1
+
+    def em_expectation(self, mixing, means, covs):
+        K = len(mixing)
+        mixing = np.ascontiguousarray(mixing, dtype=np.float64)
+        means = np.ascontiguousarray(means, dtype=np.float64)
+        covs = np.ascontiguousarray(covs, dtype=np.float64)
+        ll = C.c_double()
+        check(lib.mlhip_em_expectation(self.ctx.handle, self._h, K, dptr(mixing), dptr(means), dptr(covs), C.byref(ll)))
+        return ll.value
+
+    def em_maximisation(self, K):
+        pi1, mu1, S1 = np.empty(K), np.empty((K, self.d)), np.empty((K, self.d, self.d))
+        check(lib.mlhip_em_maximisation(self.ctx.handle, self._h, K, dptr(pi1), dptr(mu1), dptr(S1)))
+        return pi1, mu1, S1
+
+    def em_maximisation_from(self, resp):
+        resp = np.asfortranarray(resp, dtype=np.float64)
+        n, K = resp.shape
+        pi1, mu1, S1 = np.empty(K), np.empty((K, self.d)), np.empty((K, self.d, self.d))
+        check(lib.mlhip_em_maximisation_from(self.ctx.handle, self._h, K, dptr(resp), C.c_int64(n), dptr(pi1), dptr(mu1), dptr(S1)))
+        return pi1, mu1, S1
+
+    def em_maximisation_from_labels(self, labels, K):
+        labels = np.ascontiguousarray(labels, dtype=np.uint32)
+        pi1, mu1, S1 = np.empty(K), np.empty((K, self.d)), np.empty((K, self.d, self.d))
+        check(lib.mlhip_em_maximisation_from_labels(self.ctx.handle, self._h, K, u32ptr(labels), dptr(pi1), dptr(mu1), dptr(S1)))
+        return pi1, mu1, S1
+
+    def em_responsibilities(self, K):
+        out = np.empty((self.n, K), order="F")
+        check(lib.mlhip_em_responsibilities(self.ctx.handle, self._h, K, dptr(out), C.c_int64(self.n)))
+        return out
+
+    def em_labels(self, K):
+        out = np.empty(self.n, dtype=np.uint32)
+        check(lib.mlhip_em_labels(self.ctx.handle, self._h, K, u32ptr(out)))
+        return out
+
+    def sample_covariance(self):
+        mean, cov = np.empty(self.d), np.empty((self.d, self.d))
+        check(lib.mlhip_sample_covariance(self.ctx.handle, self._h, dptr(mean), dptr(cov)))
+        return mean, cov
+
+    # ---- K-means --------------------------------------------------------------------------------------------
+    def kmeans_step(self, centroids):
+        centroids = np.ascontiguousarray(centroids, dtype=np.float64)
+        K = centroids.shape[0]
+        inertia, changed = C.c_double(), C.c_uint64()
+        counts, cout = np.empty(K), np.empty((K, self.d))
+        check(lib.mlhip_kmeans_step(self.ctx.handle, self._h, K, dptr(centroids), C.byref(inertia), C.byref(changed),
+                                    dptr(counts), dptr(cout)))
+        return inertia.value, changed.value, counts, cout
+
+    def kmeans_assign(self, centroids):
+        centroids = np.ascontiguousarray(centroids, dtype=np.float64)
+        K = centroids.shape[0]
+        inertia, changed = C.c_double(), C.c_uint64()
+        check(lib.mlhip_kmeans_assign(self.ctx.handle, self._h, K, dptr(centroids), C.byref(inertia), C.byref(changed)))
+        return inertia.value, changed.value
+
+    def kmeans_labels(self):
+        out = np.empty(self.n, dtype=np.uint32)
+        check(lib.mlhip_kmeans_labels(self.ctx.handle, self._h, u32ptr(out)))
+        return out
+
+    def min_squared_distances(self, centroids):
+        centroids = np.ascontiguousarray(centroids, dtype=np.float64)
+        out = np.empty(self.n)
+        check(lib.mlhip_min_squared_distances(self.ctx.handle, self._h, centroids.shape[0], dptr(centroids), dptr(out)))
+        return out
+
+
+def process_covariance(cov):
+    cov = np.ascontiguousarray(cov, dtype=np.float64)
+    d = cov.shape[0]
+    inv, sd = np.empty((d, d)), C.c_double()
+    check(lib.mlhip_process_covariance(d, dptr(cov), dptr(inv), C.byref(sd)))
+    return inv, sd.value

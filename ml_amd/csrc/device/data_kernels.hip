@@ -1,0 +1,83 @@
+// Data-movement kernels: sample-major (the caller's d x N column-major block, reference
+// ML/Clustering.hpp:28-33) -> dimension-major HBM layout, and deterministic column sums.
+#include "device.hpp"
+
+namespace mlhip {
+namespace {
+
+// Tile of 64 samples x d dims through LDS so that both the global read (consecutive doubles of a sample
+// row) and the global write (consecutive samples of one dimension) are coalesced.
+__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ src, int64_t lds_, int d, uint64_t n,
+                                                         double* __restrict__ dst, size_t ldd, uint64_t i0)
+{
+    extern __shared__ double tile[];   // [64][d+1]
+    const int DS = d + 1;
+    const uint64_t base = (uint64_t)blockIdx.x * 64;
+    for (int e = threadIdx.x; e < 64 * d; e += 256) {
+        const int s = e / d, j = e - s * d;
+        const uint64_t i = base + s;
+        tile[s * DS + j] = i < n ? src[(int64_t)i * lds_ + j] : 0.0;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * d; e += 256) {
+        const int s = e & 63, j = e >> 6;
+        const uint64_t i = base + s;
+        if (i < n) dst[(size_t)j * ldd + i0 + i] = tile[s * DS + j];
+    }
+}
+
+// Stage 1: block b of row j sums a contiguous chunk; stage 2: one block per row sums the 1024 partials.
+__global__ __launch_bounds__(256) void colsum_stage1(const double* __restrict__ xt, size_t ldx, uint64_t n,
+                                                      double* __restrict__ scratch)
+{
+    __shared__ double red[256];
+    const int j = blockIdx.y;
+    const uint64_t chunk = (n + gridDim.x - 1) / gridDim.x;
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk;
+    uint64_t hi = lo + chunk;
+    if (hi > n) hi = n;
+    double s = 0.0;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) s += xt[(size_t)j * ldx + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) scratch[(size_t)j * gridDim.x + blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void colsum_stage2(const double* __restrict__ scratch, int parts, double* __restrict__ sums)
+{
+    __shared__ double red[256];
+    const int j = blockIdx.x;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < parts; b += 256) s += scratch[(size_t)j * parts + b];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[j] = red[0];
+}
+
+}  // namespace
+
+void launch_transpose_to_dim_major(const double* src, int64_t lds, int d, uint64_t n, double* dst, size_t ldd,
+                                   uint64_t i0, hipStream_t stream)
+{
+    if (n == 0) return;
+    const unsigned blocks = (unsigned)((n + 63) / 64);
+    hipLaunchKernelGGL(transpose_kernel, dim3(blocks), dim3(256), sizeof(double) * 64 * (d + 1), stream, src, lds, d, n, dst,
+                       ldd, i0);
+}
+
+void launch_column_sums(const double* xt, size_t ldx, int d, uint64_t n, double* scratch, double* sums, hipStream_t stream)
+{
+    const int parts = 1024;
+    hipLaunchKernelGGL(colsum_stage1, dim3(parts, d), dim3(256), 0, stream, xt, ldx, n, scratch);
+    hipLaunchKernelGGL(colsum_stage2, dim3(d), dim3(256), 0, stream, scratch, parts, sums);
+}
+
+}  // namespace mlhip

@@ -1,0 +1,76 @@
+// Internal interface between the runtime (runtime.cpp) and the gfx950 kernels (*.hip).
+// Everything here is launched on the caller's hipStream_t; no function synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "layout.hpp"
+
+namespace mlhip {
+
+// ---- data movement --------------------------------------------------------------------------------
+/// dst[j*ldd + i0 + i] = src[i*lds + j] for i < n, j < d (sample-major -> dimension-major).
+void launch_transpose_to_dim_major(const double* src, int64_t lds, int d, uint64_t n, double* dst, size_t ldd,
+                                   uint64_t i0, hipStream_t stream);
+/// sums[j] = sum_i xt[j*ldx + i] (deterministic two-stage reduction); scratch >= d * 1024 doubles.
+void launch_column_sums(const double* xt, size_t ldx, int d, uint64_t n, double* scratch, double* sums, hipStream_t stream);
+
+// ---- EM ----------------------------------------------------------------------------------------------
+struct EstepArgs {
+    const double* xt; size_t ldx; uint32_t n; int D;      // D = padded dimension
+    const double* params; int K;                            // K records of estep_param_stride(D)
+    double* lw; size_t ldr;                                 // out: unnormalised log-responsibilities [K][ldr]
+    double* lse;                                            // out: log sum_k exp(lw) per sample
+    double* ll_partials; int n_ll_partials;                 // out: per-block sums of lse (grid size)
+};
+/// Returns the grid size used (= number of ll partials written), or <0 if D is not instantiated.
+int launch_em_estep(const EstepArgs& a, hipStream_t stream);
+
+enum MstatsMode : int {
+    kFromLogResp = 0,   // r = exp(lw - lse)          (after an E-step)
+    kFromResp = 1,      // r = lw                     (caller-given responsibilities)
+    kFromLabels = 2,    // r = (labels[i] == k)
+    kOnes = 3           // r = 1 (K = 1)              (sample covariance)
+};
+struct MstatsArgs {
+    const double* xt; size_t ldx; uint32_t n; int d;        // d = true dimension
+    const double* shift;                                     // device, d doubles
+    const double* lw; size_t ldr; const double* lse; const uint32_t* labels; int K; int mode;
+    double* partials; size_t partials_capacity;              // scratch (doubles)
+    const double* ll_partials; int n_ll_partials;            // summed into stats[K*F] (may be null/0)
+    double* stats;                                           // out: device, K*F + 1 doubles
+};
+/// Doubles of scratch the statistics kernel needs for (d, K).
+size_t em_mstats_scratch_doubles(int d, int K, int num_cus);
+/// Main statistics kernel; returns the number of per-workgroup partials written (>0) or <0 on error.
+int launch_em_mstats(const MstatsArgs& a, int num_cus, hipStream_t stream);
+/// Fixed-order combination of those partials (and of the log-likelihood partials) into a.stats.
+void launch_em_reduce(const MstatsArgs& a, int num_cus, int n_partials, hipStream_t stream);
+/// out[0] = sum of n_ll log-likelihood partials (fixed order).
+void launch_ll_reduce(const double* ll_partials, int n_ll, double* out, hipStream_t stream);
+
+struct RespArgs {
+    const double* lw; size_t ldr; const double* lse; uint32_t n; int K;
+    double* resp; size_t ldo;       // out (may be null): resp[k*ldo + i]
+    uint32_t* labels;               // out (may be null)
+};
+void launch_em_responsibilities(const RespArgs& a, hipStream_t stream);
+
+// ---- K-means -----------------------------------------------------------------------------------------
+struct KmeansArgs {
+    const double* xt; size_t ldx; uint32_t n; int D; int d;
+    const double* centroids; int K;            // device, [K][D] (padded coordinates zero)
+    uint32_t* labels; const uint32_t* old_labels; int have_old;
+    double* min_dist;                          // out (may be null): per-sample min squared distance
+    int accumulate;                            // also accumulate per-cluster sums / counts
+    double* partials; size_t partials_capacity;
+    double* out;                               // device: [inertia, n_changed, counts(K), sums(K*d)]
+};
+size_t kmeans_scratch_doubles(int d, int K, int num_cus);
+/// Assignment kernel; returns the number of per-workgroup partials (>0) or <0 on error.
+int launch_kmeans_assign(const KmeansArgs& a, int num_cus, hipStream_t stream);
+void launch_kmeans_reduce(const KmeansArgs& a, int n_partials, hipStream_t stream);
+
+}  // namespace mlhip

@@ -1,0 +1,253 @@
+// M-step sufficient statistics of Gaussian-mixture EM on the gfx950 fp64 matrix cores -- replaces the
+// accumulation loops of EM::maximisation_step (reference ML/EM.cpp:229, 238, 245-248: means = X*R,
+// sum of weights, N*K rank-1 updates through LinearAlgebra::add_a_xxT, ML/LinearAlgebra.cpp:54-73) and of
+// EM::calculate_sample_covariance (ML/EM.cpp:265-272).
+//
+// Formulation. With xt_i = [x_i - shift ; 1] (length d+1) every statistic the M-step needs is an entry of
+//     S_k = sum_i r_ik xt_i xt_i^T        (S0 = S_k[d][d], S1' = S_k[d][0..d), M2' = S_k[0..d)[0..d))
+// and S_k is symmetric, so only its F = (d+1)(d+2)/2 lower-triangular entries are formed. Stacking them,
+//     stats[K x F] = R^T[K x N] * Phi[N x F],   Phi_i = vech(xt_i xt_i^T)
+// is ONE dense GEMM whose B operand is generated in registers from the LDS-resident sample tile
+// (one multiply per element, shared by all components): v_mfma_f64_16x16x4_f64 with
+//     A[i = component][k = sample] = r_ik,  B[k = sample][j = feature] = xt_i[a(j)] * xt_i[b(j)].
+// That is 2*K*F flop per sample (561 features at d = 32) instead of the 2*K*d^2 of per-component
+// 16x16-tiled covariance blocks, and one pass over X and over the N x K log-responsibilities.
+//
+// Work split: grid.x persistent workgroups stride over 64-sample tiles; grid.y splits the (row-block,
+// column-block) tile space when it does not fit one workgroup's registers. A wave holds RBW x CBW
+// 16x16 accumulators (8 VGPRs each). Per-workgroup partial sums go to scratch and are combined in a
+// fixed order by em_reduce_kernel (no atomics: bitwise reproducible).
+#include "device.hpp"
+
+namespace mlhip {
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int TS = 64;   // samples per LDS tile
+
+__device__ __forceinline__ void feature_pair(int col, int F, int da, int& a, int& b)
+{
+    if (col >= F) { a = b = da; return; }   // padding column -> zero slot
+    int r = (int)((__builtin_sqrt(8.0 * col + 1.0) - 1.0) * 0.5);
+    while ((r + 1) * (r + 2) / 2 <= col) ++r;
+    while (r * (r + 1) / 2 > col) --r;
+    a = r;
+    b = col - r * (r + 1) / 2;
+}
+
+template <int RBW, int CBW>
+__global__ __launch_bounds__(256, 2) void em_mstats_kernel(
+    const double* __restrict__ xt, size_t ldx, uint32_t n, int d, const double* __restrict__ shift,
+    const double* __restrict__ lw, size_t ldr, const double* __restrict__ lse, const uint32_t* __restrict__ labels,
+    int K, int mode, int n_rbg, int CB_total, double* __restrict__ partials, int KP, int FP)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int da = d + 1;          // augmented length; slot `da` of every row holds 0 for padding columns
+    const int XS = (da + 1) | 1;   // odd row stride (doubles)
+    constexpr int RS = RBW * 16 + 1;
+    double* Xs = smem;             // [TS][XS]
+    double* Rs = smem + TS * XS;   // [TS][RS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rbg = blockIdx.y % n_rbg, cbg = blockIdx.y / n_rbg;
+    const int rb0 = rbg * RBW;                       // first 16-component row block of this workgroup
+    const int cb0 = (cbg * 4 + wave) * CBW;          // first 16-feature column block of this wave
+    const int F = da * (da + 1) / 2;
+
+    int offa[CBW], offb[CBW];
+#pragma unroll
+    for (int c = 0; c < CBW; ++c) {
+        int a, b;
+        feature_pair((cb0 + c) * 16 + (lane & 15), (cb0 + c) < CB_total ? F : 0, da, a, b);
+        offa[c] = a;
+        offb[c] = b;
+    }
+
+    d4 acc[RBW][CBW];
+#pragma unroll
+    for (int r = 0; r < RBW; ++r)
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) acc[r][c] = d4{0.0, 0.0, 0.0, 0.0};
+
+    const uint32_t n_tiles = (n + TS - 1) / TS;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t i0 = tile * TS;
+        __syncthreads();   // previous tile fully consumed
+        // ---- stage xt tile: Xs[s][j] = x[j][i0+s] - shift[j]; Xs[s][d] = 1; Xs[s][da] = 0
+        for (int e = tid; e < TS * d; e += 256) {
+            const int s = e & (TS - 1), j = e / TS;
+            Xs[s * XS + j] = xt[(size_t)j * ldx + i0 + s] - shift[j];
+        }
+        if (tid < TS) {
+            Xs[tid * XS + d] = 1.0;
+            Xs[tid * XS + da] = 0.0;
+        }
+        // ---- stage responsibilities: Rs[s][kk] for the RBW*16 components of this row-block group
+        for (int e = tid; e < TS * RBW * 16; e += 256) {
+            const int s = e & (TS - 1), kk = e / TS;
+            const int k = rb0 * 16 + kk;
+            const uint32_t i = i0 + s;
+            double r = 0.0;
+            if (k < K && i < n) {
+                if (mode == kFromLogResp) r = exp(lw[(size_t)k * ldr + i] - lse[i]);
+                else if (mode == kFromResp) r = lw[(size_t)k * ldr + i];
+                else if (mode == kFromLabels) r = (labels[i] == (uint32_t)k) ? 1.0 : 0.0;
+                else r = 1.0;
+            }
+            Rs[s * RS + kk] = r;
+        }
+        __syncthreads();
+        // ---- contraction: 16 groups of 4 samples
+#pragma unroll 2
+        for (int sg = 0; sg < TS / 4; ++sg) {
+            const int s = sg * 4 + (lane >> 4);
+            const double* xr = Xs + s * XS;
+            const double* rr = Rs + s * RS + (lane & 15);
+            double av[RBW];
+#pragma unroll
+            for (int r = 0; r < RBW; ++r) av[r] = rr[r * 16];
+#pragma unroll
+            for (int c = 0; c < CBW; ++c) {
+                const double bv = xr[offa[c]] * xr[offb[c]];
+#pragma unroll
+                for (int r = 0; r < RBW; ++r)
+                    acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], bv, acc[r][c], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: partials[blockIdx.x][k][f]; C/D layout of v_mfma_f64_16x16x4: col = lane&15, row = (lane>>4) + 4*reg
+    double* out = partials + (size_t)blockIdx.x * KP * FP;
+#pragma unroll
+    for (int r = 0; r < RBW; ++r)
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) {
+            const int cb = cb0 + c;
+            if (cb < CB_total && (rb0 + r) * 16 < KP) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int k = (rb0 + r) * 16 + (lane >> 4) + 4 * g;
+                    out[(size_t)k * FP + cb * 16 + (lane & 15)] = acc[r][c][g];
+                }
+            }
+        }
+}
+
+/// stats[k*F + f] = sum_b partials[b][k][f]  (b ascending: deterministic), stats[K*F] = sum of ll partials.
+__global__ __launch_bounds__(256) void em_reduce_kernel(const double* __restrict__ partials, int n_blocks, int KP, int FP,
+                                                         int K, int F, const double* __restrict__ ll_partials,
+                                                         int n_ll, double* __restrict__ stats)
+{
+    const int total = K * F;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 < total) {
+        if (e < total) {
+            const int k = e / F, f = e - k * F;
+            const double* p = partials + (size_t)k * FP + f;
+            double s = 0.0;
+            for (int b = 0; b < n_blocks; ++b) s += p[(size_t)b * KP * FP];
+            stats[e] = s;
+        }
+    } else {
+        // one extra block: log-likelihood partials (fixed-order tree)
+        __shared__ double red[256];
+        double s = 0.0;
+        for (int b = threadIdx.x; b < n_ll; b += 256) s += ll_partials[b];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) stats[total] = red[0];
+    }
+}
+
+struct Plan {
+    int RBW, CBW;       // per-wave register blocking
+    int RB, CB;         // total 16-blocks
+    int n_rbg, n_cbg;   // grid.y decomposition
+    int grid_x;
+};
+
+Plan make_plan(int d, int K, int num_cus)
+{
+    Plan p;
+    const int F = stats_count(d);
+    p.RB = (K + 15) / 16;
+    p.CB = (F + 15) / 16;
+    const int cb_per_wave = (p.CB + 3) / 4;
+    // Prefer covering all column blocks in one group (no re-staging of X), then as many row blocks as fit.
+    p.RBW = p.RB >= 4 && cb_per_wave <= 3 ? 4 : (p.RB >= 2 ? 2 : 1);
+    // accumulators per wave limited to 18 tiles (144 registers) so that two workgroups share a CU
+    int cbw_max = 18 / p.RBW;
+    if (cbw_max > 9) cbw_max = 9;
+    static const int choices[] = {1, 2, 3, 5, 9};
+    p.CBW = 9;
+    for (int c : choices)
+        if (c >= cb_per_wave || c == 9) { p.CBW = c; break; }
+    if (p.CBW > cbw_max) p.CBW = cbw_max >= 9 ? 9 : (cbw_max >= 5 ? 5 : (cbw_max >= 3 ? 3 : (cbw_max >= 2 ? 2 : 1)));
+    p.n_rbg = (p.RB + p.RBW - 1) / p.RBW;
+    p.n_cbg = (p.CB + 4 * p.CBW - 1) / (4 * p.CBW);
+    int gx = 2 * num_cus / (p.n_rbg * p.n_cbg);   // two workgroups per CU
+    if (gx < 1) gx = 1;
+    p.grid_x = gx;
+    return p;
+}
+
+template <int RBW, int CBW>
+void launch_t(const MstatsArgs& a, const Plan& p, int grid_x, int KP, int FP, hipStream_t stream)
+{
+    const int da = a.d + 1;
+    const int XS = (da + 1) | 1;
+    const size_t smem = sizeof(double) * ((size_t)TS * XS + (size_t)TS * (RBW * 16 + 1));
+    hipLaunchKernelGGL((em_mstats_kernel<RBW, CBW>), dim3(grid_x, p.n_rbg * p.n_cbg), dim3(256), smem, stream, a.xt, a.ldx,
+                       a.n, a.d, a.shift, a.lw, a.ldr, a.lse, a.labels, a.K, a.mode, p.n_rbg, p.CB, a.partials, KP, FP);
+}
+
+}  // namespace
+
+size_t em_mstats_scratch_doubles(int d, int K, int num_cus)
+{
+    const Plan p = make_plan(d, K, num_cus);
+    const size_t KP = (size_t)p.n_rbg * p.RBW * 16, FP = (size_t)p.n_cbg * 4 * p.CBW * 16;
+    return (size_t)p.grid_x * KP * FP;
+}
+
+int launch_em_mstats(const MstatsArgs& a, int num_cus, hipStream_t stream)
+{
+    const Plan p = make_plan(a.d, a.K, num_cus);
+    const int KP = p.n_rbg * p.RBW * 16, FP = p.n_cbg * 4 * p.CBW * 16;
+    const uint32_t n_tiles = (a.n + TS - 1) / TS;
+    int grid_x = p.grid_x;
+    if ((uint32_t)grid_x > n_tiles) grid_x = (int)(n_tiles ? n_tiles : 1);
+    if ((size_t)grid_x * KP * FP > a.partials_capacity) return -2;
+
+#define MLHIP_CASE(R, C) \
+    if (p.RBW == R && p.CBW == C) { launch_t<R, C>(a, p, grid_x, KP, FP, stream); } else
+    MLHIP_CASE(1, 1) MLHIP_CASE(1, 2) MLHIP_CASE(1, 3) MLHIP_CASE(1, 5) MLHIP_CASE(1, 9)
+    MLHIP_CASE(2, 1) MLHIP_CASE(2, 2) MLHIP_CASE(2, 3) MLHIP_CASE(2, 5) MLHIP_CASE(2, 9)
+    MLHIP_CASE(4, 1) MLHIP_CASE(4, 2) MLHIP_CASE(4, 3)
+    { return -1; }
+#undef MLHIP_CASE
+    return grid_x;
+}
+
+void launch_em_reduce(const MstatsArgs& a, int num_cus, int grid_x, hipStream_t stream)
+{
+    const Plan p = make_plan(a.d, a.K, num_cus);
+    const int KP = p.n_rbg * p.RBW * 16, FP = p.n_cbg * 4 * p.CBW * 16;
+    const int F = stats_count(a.d);
+    const int total = a.K * F;
+    const int red_blocks = (total + 255) / 256 + 1;
+    hipLaunchKernelGGL(em_reduce_kernel, dim3(red_blocks), dim3(256), 0, stream, a.partials, grid_x, KP, FP, a.K, F,
+                       a.ll_partials, a.n_ll_partials, a.stats);
+}
+
+void launch_ll_reduce(const double* ll_partials, int n_ll, double* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(em_reduce_kernel, dim3(1), dim3(256), 0, stream, nullptr, 0, 0, 0, 0, 0, ll_partials, n_ll, out);
+}
+
+}  // namespace mlhip

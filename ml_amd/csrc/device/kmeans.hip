@@ -1,0 +1,168 @@
+// K-means assignment + update statistics for gfx950 -- replaces KMeans::assignment_step / assign_label
+// (reference ML/KMeans.cpp:153-178), the sums KMeans::update_step needs (:180-192) and the identical
+// nearest-centroid loops of the initialisers (ML/Clustering.cpp:44-51, 77-88).
+//
+// One lane owns one sample (coordinates in VGPRs, X dimension-major in HBM -> coalesced loads); the
+// centroid of the current cluster is wave-uniform and arrives through scalar loads. Distances are the
+// direct form sum_j (x_j - c_j)^2 accumulated in ascending j with separately rounded multiply and add
+// (no FMA contraction), i.e. exactly the IEEE operations the host-side assign_label performs, so the
+// per-sample distance and the argmin (strict '<', scan from k = 0, first minimum wins, label 0 default)
+// are bit-identical to the host point query. The expanded |x|^2 - 2x.c + |c|^2 form is deliberately not
+// used: its cancellation can flip labels of nearly equidistant samples.
+//
+// Update statistics: per-workgroup LDS-privatised sums/counts (ds_add_f64), written out per workgroup
+// and combined in a fixed order by kmeans_reduce_kernel.
+#include "device.hpp"
+
+namespace mlhip {
+namespace {
+
+template <int D, bool USE_LDS>
+__global__ __launch_bounds__(256) void kmeans_assign_kernel(
+    const double* __restrict__ xt, size_t ldx, uint32_t n, int d, const double* __restrict__ cent, int K,
+    uint32_t* __restrict__ labels, const uint32_t* __restrict__ old_labels, int have_old,
+    double* __restrict__ min_dist, int accumulate, double* __restrict__ partials, size_t pstride)
+{
+    extern __shared__ double acc_lds[];   // [K][d+1] when use_lds
+    __shared__ double red[8];
+    const int tid = threadIdx.x;
+    const int W = d + 1;
+    double* my_part = partials + (size_t)blockIdx.x * pstride;   // [inertia, changed, K*(d+1) ...]
+    if (accumulate) {
+        if (USE_LDS) {
+            for (int e = tid; e < K * W; e += 256) acc_lds[e] = 0.0;
+        } else {
+            for (int e = tid; e < K * W; e += 256) my_part[2 + e] = 0.0;
+        }
+        __syncthreads();
+    }
+
+    double inertia = 0.0, changed = 0.0;
+    for (uint32_t i = blockIdx.x * 256u + tid; i < n; i += gridDim.x * 256u) {
+        double x[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) x[j] = xt[(size_t)j * ldx + i];
+        double best = __builtin_inf();
+        uint32_t arg = 0;
+        for (int k = 0; k < K; ++k) {
+            const double* __restrict__ c = cent + (size_t)k * D;   // wave-uniform -> scalar loads
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double t = __dsub_rn(x[j], c[j]);
+                s = __dadd_rn(s, __dmul_rn(t, t));
+            }
+            if (s < best) { best = s; arg = (uint32_t)k; }
+        }
+        labels[i] = arg;
+        if (min_dist) min_dist[i] = best;
+        inertia += best;
+        changed += (!have_old || old_labels[i] != arg) ? 1.0 : 0.0;
+        if (accumulate) {
+            if (USE_LDS) {
+                double* row = acc_lds + (size_t)arg * W;
+#pragma unroll
+                for (int j = 0; j < D; ++j)
+                    if (j < d) unsafeAtomicAdd(row + j, x[j]);
+                unsafeAtomicAdd(row + d, 1.0);
+            } else {
+                double* row = my_part + 2 + (size_t)arg * W;
+#pragma unroll
+                for (int j = 0; j < D; ++j)
+                    if (j < d) unsafeAtomicAdd(row + j, x[j]);
+                unsafeAtomicAdd(row + d, 1.0);
+            }
+        }
+    }
+    // block sums of inertia / changed (fixed order)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        inertia += __shfl_down(inertia, off, 64);
+        changed += __shfl_down(changed, off, 64);
+    }
+    if ((tid & 63) == 0) {
+        red[tid >> 6] = inertia;
+        red[4 + (tid >> 6)] = changed;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        my_part[0] = red[0] + red[1] + red[2] + red[3];
+        my_part[1] = red[4] + red[5] + red[6] + red[7];
+    }
+    if (accumulate && USE_LDS) {
+        for (int e = tid; e < K * W; e += 256) my_part[2 + e] = acc_lds[e];
+    }
+}
+
+/// out = [inertia, n_changed, counts(K), sums(K*d)] = fixed-order sum of the per-workgroup partials.
+__global__ __launch_bounds__(256) void kmeans_reduce_kernel(const double* __restrict__ partials, int n_blocks, size_t pstride,
+                                                             int K, int d, int accumulate, double* __restrict__ out)
+{
+    const int W = d + 1;
+    const int total = 2 + (accumulate ? K * W : 0);
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    double s = 0.0;
+    for (int b = 0; b < n_blocks; ++b) s += partials[(size_t)b * pstride + e];
+    if (e < 2) { out[e] = s; return; }
+    const int k = (e - 2) / W, j = (e - 2) - k * W;
+    if (j == d) out[2 + k] = s;                       // count
+    else out[2 + K + (size_t)k * d + j] = s;          // coordinate sum
+}
+
+template <int D>
+void launch_t(const KmeansArgs& a, int grid, int use_lds, size_t pstride, hipStream_t stream)
+{
+    const size_t smem = use_lds ? sizeof(double) * (size_t)a.K * (a.d + 1) : 0;
+    if (use_lds)
+        hipLaunchKernelGGL((kmeans_assign_kernel<D, true>), dim3(grid), dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d,
+                           a.centroids, a.K, a.labels, a.old_labels, a.have_old, a.min_dist, a.accumulate, a.partials, pstride);
+    else
+        hipLaunchKernelGGL((kmeans_assign_kernel<D, false>), dim3(grid), dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d,
+                           a.centroids, a.K, a.labels, a.old_labels, a.have_old, a.min_dist, a.accumulate, a.partials, pstride);
+}
+
+inline int kmeans_grid(int num_cus) { return num_cus * 4; }
+
+}  // namespace
+
+size_t kmeans_scratch_doubles(int d, int K, int num_cus)
+{
+    return (size_t)kmeans_grid(num_cus) * (2 + (size_t)K * (d + 1));
+}
+
+int launch_kmeans_assign(const KmeansArgs& a, int num_cus, hipStream_t stream)
+{
+    const size_t pstride = 2 + (size_t)a.K * (a.d + 1);
+    int grid = kmeans_grid(num_cus);
+    const uint32_t blocks_needed = (a.n + 255) / 256;
+    if ((uint32_t)grid > blocks_needed) grid = (int)(blocks_needed ? blocks_needed : 1);
+    if ((size_t)grid * pstride > a.partials_capacity) return -2;
+    const int use_lds = (size_t)a.K * (a.d + 1) * sizeof(double) <= 64 * 1024;
+    switch (a.D) {
+    case 1: launch_t<1>(a, grid, use_lds, pstride, stream); break;
+    case 2: launch_t<2>(a, grid, use_lds, pstride, stream); break;
+    case 3: launch_t<3>(a, grid, use_lds, pstride, stream); break;
+    case 4: launch_t<4>(a, grid, use_lds, pstride, stream); break;
+    case 6: launch_t<6>(a, grid, use_lds, pstride, stream); break;
+    case 8: launch_t<8>(a, grid, use_lds, pstride, stream); break;
+    case 12: launch_t<12>(a, grid, use_lds, pstride, stream); break;
+    case 16: launch_t<16>(a, grid, use_lds, pstride, stream); break;
+    case 20: launch_t<20>(a, grid, use_lds, pstride, stream); break;
+    case 24: launch_t<24>(a, grid, use_lds, pstride, stream); break;
+    case 28: launch_t<28>(a, grid, use_lds, pstride, stream); break;
+    case 32: launch_t<32>(a, grid, use_lds, pstride, stream); break;
+    default: return -1;
+    }
+    return grid;
+}
+
+void launch_kmeans_reduce(const KmeansArgs& a, int n_partials, hipStream_t stream)
+{
+    const size_t pstride = 2 + (size_t)a.K * (a.d + 1);
+    const int total = 2 + (a.accumulate ? a.K * (a.d + 1) : 0);
+    hipLaunchKernelGGL(kmeans_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, a.partials, n_partials, pstride,
+                       a.K, a.d, a.accumulate, a.out);
+}
+
+}  // namespace mlhip

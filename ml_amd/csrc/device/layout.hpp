@@ -1,0 +1,34 @@
+// HBM / parameter / statistics layouts shared by the host code and the gfx950 kernels. No HIP types here.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace mlhip {
+
+// ---- layout constants shared by host and device code -------------------------------------------
+constexpr int kSampleTile = 256;  // N is padded to a multiple of this in HBM
+
+/// Largest dimension the register-resident kernels are instantiated for.
+constexpr int kMaxDim = 32;
+
+/// Dimension the kernels are instantiated for: d is padded with zero coordinates up to this.
+inline int padded_dim(int d)
+{
+    static const int sizes[] = {1, 2, 3, 4, 6, 8, 12, 16, 20, 24, 28, 32};
+    for (int s : sizes)
+        if (d <= s) return s;
+    return -1;
+}
+
+/// E-step parameter record of one component, PS(D) doubles:
+///   [ mean(D) | W = L^{-1}, lower triangle packed row by row (row j holds j+1 entries) | coef ]
+/// with Sigma = L L^T and coef = log(pi) - sum_j log L_jj.
+inline int estep_param_stride(int D) { return D + D * (D + 1) / 2 + 1; }
+
+/// Sufficient statistics of one component: packed lower triangle (row-major) of sum_i r_i xt_i xt_i^T,
+/// xt = [x - shift ; 1] (length d+1). Entry (a,b), a >= b, sits at a(a+1)/2 + b; so
+///   S0 = (d,d), S1'_b = (d,b), M2'_ab = (a,b).
+inline int stats_count(int d) { return (d + 1) * (d + 2) / 2; }
+inline int stats_index(int a, int b) { return a * (a + 1) / 2 + b; }
+
+}  // namespace mlhip

@@ -1,0 +1,102 @@
+#include "em_math.hpp"
+
+#include <cmath>
+#include <vector>
+
+#include "../device/layout.hpp"
+
+namespace mlhip {
+namespace host {
+
+void cholesky_lower(int d, const double* A, double* L)
+{
+    for (int i = 0; i < d * d; ++i) L[i] = 0.0;
+    for (int j = 0; j < d; ++j) {
+        double s = A[j * d + j];
+        for (int l = 0; l < j; ++l) s -= L[l * d + j] * L[l * d + j];
+        const double ljj = std::sqrt(s);
+        L[j * d + j] = ljj;
+        for (int i = j + 1; i < d; ++i) {
+            double t = A[j * d + i];
+            for (int l = 0; l < j; ++l) t -= L[l * d + i] * L[l * d + j];
+            L[j * d + i] = t / ljj;
+        }
+    }
+}
+
+void process_covariance(int d, const double* cov, double* inverse, double* sqrt_det)
+{
+    std::vector<double> L((size_t)d * d), y(d);
+    cholesky_lower(d, cov, L.data());
+    for (int c = 0; c < d; ++c) {
+        for (int i = 0; i < d; ++i) {
+            double t = (i == c) ? 1.0 : 0.0;
+            for (int l = 0; l < i; ++l) t -= L[l * d + i] * y[l];
+            y[i] = t / L[i * d + i];
+        }
+        for (int i = d - 1; i >= 0; --i) {
+            double t = y[i];
+            for (int l = i + 1; l < d; ++l) t -= L[i * d + l] * inverse[c * d + l];
+            inverse[c * d + i] = t / L[i * d + i];
+        }
+    }
+    double sd = 1.0;
+    for (int i = 0; i < d; ++i) sd *= L[i * d + i];
+    *sqrt_det = sd;
+}
+
+void build_estep_params(int d, int D, int K, const double* mixing, const double* means, const double* covariances,
+                        double* records)
+{
+    const int PS = estep_param_stride(D);
+    std::vector<double> L((size_t)d * d), W((size_t)d * d);
+    for (int k = 0; k < K; ++k) {
+        double* rec = records + (size_t)k * PS;
+        for (int i = 0; i < PS; ++i) rec[i] = 0.0;
+        for (int j = 0; j < d; ++j) rec[j] = means[(size_t)k * d + j];
+        cholesky_lower(d, covariances + (size_t)k * d * d, L.data());
+        // W = L^-1 by forward substitution, column by column (W is lower triangular).
+        for (int c = 0; c < d; ++c) {
+            for (int i = 0; i < d; ++i) {
+                if (i < c) { W[c * d + i] = 0.0; continue; }
+                double t = (i == c) ? 1.0 : 0.0;
+                for (int l = c; l < i; ++l) t -= L[l * d + i] * W[c * d + l];
+                W[c * d + i] = t / L[i * d + i];
+            }
+        }
+        double* w = rec + D;
+        for (int j = 0; j < d; ++j)
+            for (int l = 0; l <= j; ++l) w[j * (j + 1) / 2 + l] = W[l * d + j];
+        double log_det_half = 0.0;
+        for (int j = 0; j < d; ++j) log_det_half += std::log(L[j * d + j]);
+        rec[PS - 1] = std::log(mixing[k]) - log_det_half;
+    }
+}
+
+void finalize_mstep(int d, int K, const double* stats, const double* shift, double n_global, double* mixing,
+                    double* means, double* covariances)
+{
+    const int F = stats_count(d);
+    std::vector<double> m(d);
+    for (int k = 0; k < K; ++k) {
+        const double* s = stats + (size_t)k * F;
+        const double s0 = s[stats_index(d, d)];
+        for (int a = 0; a < d; ++a) {
+            m[a] = s[stats_index(d, a)] / s0;
+            means[(size_t)k * d + a] = shift[a] + m[a];
+        }
+        double* cov = covariances + (size_t)k * d * d;
+        for (int a = 0; a < d; ++a)
+            for (int b = 0; b <= a; ++b) {
+                const double v = (s[stats_index(a, b)] - s[stats_index(d, a)] * m[b]) / s0;
+                cov[b * d + a] = v;
+                cov[a * d + b] = v;
+            }
+        static constexpr double epsilon = 1e-15;   // ML/EM.cpp:252
+        for (int a = 0; a < d; ++a) cov[a * d + a] += epsilon;
+        mixing[k] = s0 / n_global;                 // ML/EM.cpp:257
+    }
+}
+
+}  // namespace host
+}  // namespace mlhip

@@ -1,0 +1,31 @@
+// Host-side dense helpers of the EM path (tiny d x d work that stays on the CPU):
+// what EM::process_covariances (reference ML/EM.cpp:274-287) and the closing lines of
+// EM::maximisation_step (ML/EM.cpp:242, 250-257) do, expressed on raw column-major buffers.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace mlhip {
+namespace host {
+
+/// Lower Cholesky factor of the symmetric d x d matrix A (column-major); what Eigen::LLT computes at
+/// ML/EM.cpp:279. A non-positive-definite A yields NaNs, silently, like the reference (no info() check).
+void cholesky_lower(int d, const double* A, double* L);
+
+/// inverse = A^-1 via L y = e_c, L^T x = y (the llt.solve(Identity) of ML/EM.cpp:280);
+/// sqrt_det = prod L_ii (ML/EM.cpp:281-285).
+void process_covariance(int d, const double* cov, double* inverse, double* sqrt_det);
+
+/// One E-step record per component for the device kernel (layout: device/device.hpp estep_param_stride):
+/// [mean(D) | W = L^-1 packed lower, row-major | log(pi) - sum log L_jj], coordinates >= d zero-padded.
+void build_estep_params(int d, int D, int K, const double* mixing, const double* means, const double* covariances,
+                        double* records);
+
+/// M-step closing arithmetic from the all-reduced shifted statistics (device/device.hpp stats_count):
+///   mean_k = shift + S1'/S0 ; cov_k = (M2' - S1' (S1'/S0)^T) / S0 + 1e-15 I ; pi_k = S0 / N.
+/// Algebraically the reference's  sum_i r_ik (x_i - mean_k)(x_i - mean_k)^T / S0  (ML/EM.cpp:245-257).
+void finalize_mstep(int d, int K, const double* stats, const double* shift, double n_global, double* mixing,
+                    double* means, double* covariances);
+
+}  // namespace host
+}  // namespace mlhip

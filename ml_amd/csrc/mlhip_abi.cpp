@@ -1,0 +1,740 @@
+// Runtime + C ABI (include/mlhip.h): device context, HBM-resident data, and the per-iteration
+// orchestration of the gfx950 kernels. Host-side work here is only the tiny per-component d x d algebra
+// (Cholesky / inverse / M-step closing arithmetic) that the reference also keeps out of its hot loops.
+// There is no CPU fallback: every compute entry point needs a HIP device.
+#include "mlhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "device/device.hpp"
+#include "host/em_math.hpp"
+
+namespace {
+
+thread_local std::string g_error;
+
+struct InvalidArgument : std::runtime_error { using std::runtime_error::runtime_error; };
+struct NoDevice : std::runtime_error { using std::runtime_error::runtime_error; };
+struct Unsupported : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#define HIP_CHECK(expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr);  \
+    } while (0)
+
+template <class F> int guarded(F&& f)
+{
+    try { f(); return MLHIP_OK; }
+    catch (const InvalidArgument& e) { g_error = e.what(); return MLHIP_E_INVALID_ARGUMENT; }
+    catch (const NoDevice& e) { g_error = e.what(); return MLHIP_E_NO_DEVICE; }
+    catch (const Unsupported& e) { g_error = e.what(); return MLHIP_E_UNSUPPORTED; }
+    catch (const std::exception& e) { g_error = e.what(); return MLHIP_E_RUNTIME; }
+}
+
+/// Growable device buffer.
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    void reserve(size_t b)
+    {
+        if (b <= bytes) return;
+        if (p) HIP_CHECK(hipFree(p));
+        p = nullptr; bytes = 0;
+        HIP_CHECK(hipMalloc(&p, b));
+        bytes = b;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+struct PinnedBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    void reserve(size_t b)
+    {
+        if (b <= bytes) return;
+        if (p) HIP_CHECK(hipHostFree(p));
+        p = nullptr; bytes = 0;
+        HIP_CHECK(hipHostMalloc(&p, b, hipHostMallocDefault));
+        bytes = b;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct Timer {
+    double total_ms = 0;
+    uint64_t launches = 0;
+};
+
+}  // namespace
+
+struct mlhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    // all-reduce hook
+    mlhip_allreduce_fn reduce_fn = nullptr;
+    void* reduce_user = nullptr;
+    int reduce_on_device = 0, world_size = 1, rank = 0;
+    // scratch
+    DevBuf small_dev;        // for all-reducing short host vectors through a device hook
+    PinnedBuf small_host;
+    // timing
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::map<std::string, Timer> timers;
+
+    void use() const { HIP_CHECK(hipSetDevice(device)); }
+    void sync() const { HIP_CHECK(hipStreamSynchronize(stream)); }
+
+    template <class F> void timed(const char* name, F&& launch)
+    {
+        if (!timing) { launch(); return; }
+        HIP_CHECK(hipEventRecord(ev0, stream));
+        launch();
+        HIP_CHECK(hipEventRecord(ev1, stream));
+        HIP_CHECK(hipEventSynchronize(ev1));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
+        Timer& t = timers[name];
+        t.total_ms += ms;
+        t.launches += 1;
+    }
+
+    /// Sum `count` host doubles across ranks (no-op single rank).
+    void allreduce_host(double* v, size_t count)
+    {
+        if (!reduce_fn) return;
+        if (reduce_on_device) {
+            small_dev.reserve(count * sizeof(double));
+            HIP_CHECK(hipMemcpyAsync(small_dev.p, v, count * sizeof(double), hipMemcpyHostToDevice, stream));
+            if (reduce_fn(reduce_user, small_dev.as<double>(), count, 1, stream) != 0)
+                throw std::runtime_error("all-reduce hook failed");
+            HIP_CHECK(hipMemcpyAsync(v, small_dev.p, count * sizeof(double), hipMemcpyDeviceToHost, stream));
+            sync();
+        } else {
+            if (reduce_fn(reduce_user, v, count, 0, stream) != 0) throw std::runtime_error("all-reduce hook failed");
+        }
+    }
+};
+
+struct mlhip_data {
+    mlhip_ctx* ctx = nullptr;
+    int d = 0, D = 0;
+    uint32_t n = 0, n_pad = 0;
+    uint64_t n_global = 0;
+    size_t ldx = 0;
+    DevBuf xt;                    // [D][ldx]
+    DevBuf shift_dev;             // d doubles
+    std::vector<double> shift;    // host copy
+    // EM workspace (sized for em_K)
+    int em_K = 0;
+    size_t ldr = 0;
+    DevBuf lw, lse, ll_partials, params_dev, partials, stats_dev, resp_dev, labels_dev;
+    PinnedBuf params_host, stats_host;
+    int n_ll = 0;
+    bool have_estep = false;
+    // K-means workspace
+    DevBuf km_labels[2], km_cent, km_partials, km_out, km_mind;
+    PinnedBuf km_host;
+    int km_cur = 0;
+    bool km_have_old = false;
+
+    ~mlhip_data()
+    {
+        for (DevBuf* b : {&xt, &shift_dev, &lw, &lse, &ll_partials, &params_dev, &partials, &stats_dev, &resp_dev,
+                          &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_partials, &km_out, &km_mind})
+            b->release();
+        params_host.release(); stats_host.release(); km_host.release();
+    }
+};
+
+namespace {
+
+using namespace mlhip;
+
+constexpr int kMaxLlPartials = 2048;
+
+void require(bool ok, const char* msg) { if (!ok) throw InvalidArgument(msg); }
+
+int env_int(const char* name, int fallback)
+{
+    const char* v = std::getenv(name);
+    return (v && *v) ? std::atoi(v) : fallback;
+}
+
+void finish_upload(mlhip_data* dt)
+{
+    mlhip_ctx* ctx = dt->ctx;
+    // shift = global column mean (all-reduced sums and counts).
+    DevBuf scratch, sums;
+    scratch.reserve(sizeof(double) * 1024 * dt->d);
+    sums.reserve(sizeof(double) * dt->d);
+    launch_column_sums(dt->xt.as<double>(), dt->ldx, dt->d, dt->n, scratch.as<double>(), sums.as<double>(), ctx->stream);
+    std::vector<double> v(dt->d + 1);
+    HIP_CHECK(hipMemcpyAsync(v.data(), sums.p, sizeof(double) * dt->d, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+    scratch.release(); sums.release();
+    v[dt->d] = (double)dt->n;
+    ctx->allreduce_host(v.data(), v.size());
+    dt->n_global = (uint64_t)std::llround(v[dt->d]);
+    dt->shift.resize(dt->d);
+    for (int j = 0; j < dt->d; ++j) dt->shift[j] = v[j] / v[dt->d];
+    dt->shift_dev.reserve(sizeof(double) * dt->d);
+    HIP_CHECK(hipMemcpyAsync(dt->shift_dev.p, dt->shift.data(), sizeof(double) * dt->d, hipMemcpyHostToDevice, ctx->stream));
+    ctx->sync();
+}
+
+mlhip_data* upload_common(mlhip_ctx* ctx, const double* x, bool on_device, uint32_t d, uint64_t n, int64_t ld)
+{
+    require(ctx != nullptr, "null context");
+    require(x != nullptr || n == 0, "null data");
+    require(d >= 1, "At least one dimension required");
+    require(ld >= (int64_t)d, "ld must be >= d");
+    require(n < 0xffffff00ull, "shard too large (n must fit 32 bits, like the reference's unsigned int)");
+    const int D = padded_dim((int)d);
+    if (D < 0) throw Unsupported("dimension d > 32 is not supported by the register-resident kernels yet");
+    ctx->use();
+    auto* dt = new mlhip_data;
+    try {
+        dt->ctx = ctx;
+        dt->d = (int)d;
+        dt->D = D;
+        dt->n = (uint32_t)n;
+        dt->n_pad = (uint32_t)((n + kSampleTile - 1) / kSampleTile * kSampleTile);
+        if (dt->n_pad == 0) dt->n_pad = kSampleTile;
+        dt->ldx = dt->n_pad;
+        dt->xt.reserve(sizeof(double) * dt->ldx * D);
+        HIP_CHECK(hipMemsetAsync(dt->xt.p, 0, sizeof(double) * dt->ldx * D, ctx->stream));
+        if (on_device) {
+            launch_transpose_to_dim_major(x, ld, dt->d, n, dt->xt.as<double>(), dt->ldx, 0, ctx->stream);
+        } else {
+            const uint64_t chunk = 1u << 20;
+            DevBuf stage;
+            stage.reserve(sizeof(double) * d * (n < chunk ? (n ? n : 1) : chunk));
+            for (uint64_t i0 = 0; i0 < n; i0 += chunk) {
+                const uint64_t c = (n - i0 < chunk) ? n - i0 : chunk;
+                HIP_CHECK(hipMemcpy2DAsync(stage.p, sizeof(double) * d, x + (int64_t)i0 * ld, sizeof(double) * ld,
+                                           sizeof(double) * d, c, hipMemcpyHostToDevice, ctx->stream));
+                launch_transpose_to_dim_major(stage.as<double>(), d, dt->d, c, dt->xt.as<double>(), dt->ldx, i0, ctx->stream);
+                ctx->sync();   // the staging buffer is reused
+            }
+            stage.release();
+        }
+        finish_upload(dt);
+    } catch (...) {
+        delete dt;
+        throw;
+    }
+    return dt;
+}
+
+void ensure_em_workspace(mlhip_data* dt, int K)
+{
+    mlhip_ctx* ctx = dt->ctx;
+    if (dt->em_K == K) return;
+    dt->have_estep = false;
+    dt->ldr = dt->n_pad;
+    dt->lw.reserve(sizeof(double) * dt->ldr * K);
+    dt->lse.reserve(sizeof(double) * dt->n_pad);
+    dt->ll_partials.reserve(sizeof(double) * kMaxLlPartials);
+    const size_t ps = (size_t)estep_param_stride(dt->D) * K * sizeof(double);
+    dt->params_dev.reserve(ps);
+    dt->params_host.reserve(ps);
+    dt->partials.reserve(sizeof(double) * em_mstats_scratch_doubles(dt->d, K, ctx->num_cus));
+    const size_t sb = sizeof(double) * ((size_t)K * stats_count(dt->d) + 1);
+    dt->stats_dev.reserve(sb);
+    dt->stats_host.reserve(sb);
+    dt->em_K = K;
+}
+
+void run_estep(mlhip_data* dt, int K, const double* mixing, const double* means, const double* covs)
+{
+    mlhip_ctx* ctx = dt->ctx;
+    ensure_em_workspace(dt, K);
+    host::build_estep_params(dt->d, dt->D, K, mixing, means, covs, dt->params_host.as<double>());
+    HIP_CHECK(hipMemcpyAsync(dt->params_dev.p, dt->params_host.p, sizeof(double) * estep_param_stride(dt->D) * K,
+                             hipMemcpyHostToDevice, ctx->stream));
+    EstepArgs a{};
+    a.xt = dt->xt.as<double>(); a.ldx = dt->ldx; a.n = dt->n; a.D = dt->D;
+    a.params = dt->params_dev.as<double>(); a.K = K;
+    a.lw = dt->lw.as<double>(); a.ldr = dt->ldr; a.lse = dt->lse.as<double>();
+    a.ll_partials = dt->ll_partials.as<double>(); a.n_ll_partials = kMaxLlPartials;
+    int grid = 0;
+    ctx->timed("em_estep", [&] { grid = launch_em_estep(a, ctx->stream); });
+    if (grid < 0) throw Unsupported("E-step kernel not instantiated for this dimension");
+    HIP_CHECK(hipGetLastError());
+    dt->n_ll = grid;
+    dt->have_estep = true;
+}
+
+/// Runs the statistics kernel in `mode`, all-reduces, leaves [K*F stats, ll_sum] in stats_host.
+void run_mstats(mlhip_data* dt, int K, int mode, const double* resp_dev, size_t ld_resp, const uint32_t* labels_dev,
+                bool with_ll)
+{
+    mlhip_ctx* ctx = dt->ctx;
+    ensure_em_workspace(dt, K);
+    MstatsArgs a{};
+    a.xt = dt->xt.as<double>(); a.ldx = dt->ldx; a.n = dt->n; a.d = dt->d;
+    a.shift = dt->shift_dev.as<double>();
+    a.lw = (mode == kFromResp) ? resp_dev : dt->lw.as<double>();
+    a.ldr = (mode == kFromResp) ? ld_resp : dt->ldr;
+    a.lse = dt->lse.as<double>();
+    a.labels = labels_dev;
+    a.K = K; a.mode = mode;
+    a.partials = dt->partials.as<double>(); a.partials_capacity = dt->partials.bytes / sizeof(double);
+    a.ll_partials = with_ll ? dt->ll_partials.as<double>() : nullptr;
+    a.n_ll_partials = with_ll ? dt->n_ll : 0;
+    a.stats = dt->stats_dev.as<double>();
+    int rc = 0;
+    ctx->timed("em_mstats", [&] { rc = launch_em_mstats(a, ctx->num_cus, ctx->stream); });
+    if (rc <= 0) throw std::runtime_error("statistics kernel launch failed (plan/scratch)");
+    launch_em_reduce(a, ctx->num_cus, rc, ctx->stream);
+    HIP_CHECK(hipGetLastError());
+    const size_t count = (size_t)K * stats_count(dt->d) + 1;
+    if (ctx->reduce_fn && ctx->reduce_on_device) {
+        if (ctx->reduce_fn(ctx->reduce_user, dt->stats_dev.as<double>(), count, 1, ctx->stream) != 0)
+            throw std::runtime_error("all-reduce hook failed");
+    }
+    HIP_CHECK(hipMemcpyAsync(dt->stats_host.p, dt->stats_dev.p, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+    if (ctx->reduce_fn && !ctx->reduce_on_device) {
+        if (ctx->reduce_fn(ctx->reduce_user, dt->stats_host.as<double>(), count, 0, ctx->stream) != 0)
+            throw std::runtime_error("all-reduce hook failed");
+    }
+}
+
+double ll_from_stats(const mlhip_data* dt, int K)
+{
+    static const double log_2_pi = std::log(2. * 3.14159265358979323846);   // ML/EM.cpp:197
+    const double sum = dt->stats_host.as<double>()[(size_t)K * stats_count(dt->d)];
+    return sum / (double)dt->n_global - (double)dt->d * log_2_pi / 2;
+}
+
+void check_em_args(mlhip_ctx* ctx, mlhip_data* dt, uint32_t K)
+{
+    require(ctx && dt, "null context or data");
+    require(dt->ctx == ctx, "data belongs to another context");
+    require(K >= 1, "At least one component required");
+    ctx->use();
+}
+
+void finalize_out(mlhip_data* dt, int K, double* mixing_out, double* means_out, double* cov_out)
+{
+    host::finalize_mstep(dt->d, K, dt->stats_host.as<double>(), dt->shift.data(), (double)dt->n_global, mixing_out,
+                         means_out, cov_out);
+}
+
+void ensure_km_workspace(mlhip_data* dt, int K)
+{
+    mlhip_ctx* ctx = dt->ctx;
+    for (int b = 0; b < 2; ++b) dt->km_labels[b].reserve(sizeof(uint32_t) * dt->n_pad);
+    dt->km_cent.reserve(sizeof(double) * (size_t)K * dt->D);
+    dt->km_partials.reserve(sizeof(double) * kmeans_scratch_doubles(dt->d, K, ctx->num_cus));
+    const size_t ob = sizeof(double) * (2 + (size_t)K * (dt->d + 1));
+    dt->km_out.reserve(ob);
+    const size_t hb = ob > sizeof(double) * (size_t)K * dt->D ? ob : sizeof(double) * (size_t)K * dt->D;
+    dt->km_host.reserve(hb);
+}
+
+/// Assignment (+ optional accumulation); leaves all-reduced [inertia, changed, counts, sums] in km_host.
+void run_kmeans(mlhip_data* dt, int K, const double* centroids, bool accumulate, double* min_dist_dev)
+{
+    mlhip_ctx* ctx = dt->ctx;
+    ensure_km_workspace(dt, K);
+    double* ch = dt->km_host.as<double>();
+    for (int k = 0; k < K; ++k)
+        for (int j = 0; j < dt->D; ++j) ch[(size_t)k * dt->D + j] = j < dt->d ? centroids[(size_t)k * dt->d + j] : 0.0;
+    HIP_CHECK(hipMemcpyAsync(dt->km_cent.p, ch, sizeof(double) * (size_t)K * dt->D, hipMemcpyHostToDevice, ctx->stream));
+    ctx->sync();   // km_host is reused for the results below
+    const int nxt = dt->km_cur ^ 1;
+    KmeansArgs a{};
+    a.xt = dt->xt.as<double>(); a.ldx = dt->ldx; a.n = dt->n; a.D = dt->D; a.d = dt->d;
+    a.centroids = dt->km_cent.as<double>(); a.K = K;
+    a.labels = dt->km_labels[nxt].as<uint32_t>();
+    a.old_labels = dt->km_labels[dt->km_cur].as<uint32_t>();
+    a.have_old = dt->km_have_old ? 1 : 0;
+    a.min_dist = min_dist_dev;
+    a.accumulate = accumulate ? 1 : 0;
+    a.partials = dt->km_partials.as<double>(); a.partials_capacity = dt->km_partials.bytes / sizeof(double);
+    a.out = dt->km_out.as<double>();
+    int rc = 0;
+    ctx->timed("kmeans_assign", [&] { rc = launch_kmeans_assign(a, ctx->num_cus, ctx->stream); });
+    if (rc == -1) throw Unsupported("K-means kernel not instantiated for this dimension");
+    if (rc <= 0) throw std::runtime_error("K-means kernel launch failed");
+    launch_kmeans_reduce(a, rc, ctx->stream);
+    HIP_CHECK(hipGetLastError());
+    dt->km_cur = nxt;
+    dt->km_have_old = true;
+    const size_t count = 2 + (accumulate ? (size_t)K * (dt->d + 1) : 0);
+    if (ctx->reduce_fn && ctx->reduce_on_device) {
+        if (ctx->reduce_fn(ctx->reduce_user, dt->km_out.as<double>(), count, 1, ctx->stream) != 0)
+            throw std::runtime_error("all-reduce hook failed");
+    }
+    HIP_CHECK(hipMemcpyAsync(ch, dt->km_out.p, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+    if (ctx->reduce_fn && !ctx->reduce_on_device) {
+        if (ctx->reduce_fn(ctx->reduce_user, ch, count, 0, ctx->stream) != 0) throw std::runtime_error("all-reduce hook failed");
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mlhip_last_error(void) { return g_error.c_str(); }
+const char* mlhip_version(void) { return "0.1.0 (gfx950)"; }
+
+int mlhip_device_count(int* count)
+{
+    return guarded([&] {
+        require(count != nullptr, "null count");
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+        *count = n;
+    });
+}
+
+int mlhip_ctx_create(int device_id, mlhip_ctx** out)
+{
+    return guarded([&] {
+        require(out != nullptr, "null out");
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+            throw NoDevice("no HIP device available: this library has no CPU fallback (needs an AMD GPU, built for gfx950)");
+        if (device_id < 0) device_id = env_int("MLHIP_DEVICE", env_int("LOCAL_RANK", 0));
+        if (device_id >= n) device_id = device_id % n;
+        auto* ctx = new mlhip_ctx;
+        try {
+            ctx->device = device_id;
+            ctx->use();
+            hipDeviceProp_t prop;
+            HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+            ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreate(&ctx->ev0));
+            HIP_CHECK(hipEventCreate(&ctx->ev1));
+        } catch (...) {
+            delete ctx;
+            throw;
+        }
+        *out = ctx;
+    });
+}
+
+int mlhip_ctx_destroy(mlhip_ctx* ctx)
+{
+    return guarded([&] {
+        if (!ctx) return;
+        (void)hipSetDevice(ctx->device);
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        ctx->small_dev.release();
+        ctx->small_host.release();
+        if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+        if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+    });
+}
+
+int mlhip_ctx_synchronize(mlhip_ctx* ctx)
+{
+    return guarded([&] { require(ctx, "null context"); ctx->use(); ctx->sync(); });
+}
+int mlhip_ctx_device(const mlhip_ctx* ctx, int* device_id)
+{
+    return guarded([&] { require(ctx && device_id, "null argument"); *device_id = ctx->device; });
+}
+int mlhip_ctx_stream(const mlhip_ctx* ctx, void** stream)
+{
+    return guarded([&] { require(ctx && stream, "null argument"); *stream = (void*)ctx->stream; });
+}
+
+int mlhip_ctx_set_allreduce(mlhip_ctx* ctx, mlhip_allreduce_fn fn, void* user, int on_device, int world_size, int rank)
+{
+    return guarded([&] {
+        require(ctx, "null context");
+        require(world_size >= 1 && rank >= 0 && rank < world_size, "bad world_size / rank");
+        ctx->reduce_fn = fn;
+        ctx->reduce_user = user;
+        ctx->reduce_on_device = on_device;
+        ctx->world_size = fn ? world_size : 1;
+        ctx->rank = fn ? rank : 0;
+    });
+}
+
+int mlhip_data_upload(mlhip_ctx* ctx, const double* x, uint32_t d, uint64_t n, int64_t ld, mlhip_data** out)
+{
+    return guarded([&] { require(out, "null out"); *out = upload_common(ctx, x, false, d, n, ld); });
+}
+int mlhip_data_upload_dev(mlhip_ctx* ctx, const double* x_dev, uint32_t d, uint64_t n, int64_t ld, mlhip_data** out)
+{
+    return guarded([&] { require(out, "null out"); *out = upload_common(ctx, x_dev, true, d, n, ld); });
+}
+int mlhip_data_free(mlhip_data* data)
+{
+    return guarded([&] {
+        if (!data) return;
+        (void)hipSetDevice(data->ctx->device);
+        (void)hipStreamSynchronize(data->ctx->stream);
+        delete data;
+    });
+}
+int mlhip_data_shape(const mlhip_data* data, uint32_t* d, uint64_t* n_local, uint64_t* n_global)
+{
+    return guarded([&] {
+        require(data, "null data");
+        if (d) *d = (uint32_t)data->d;
+        if (n_local) *n_local = data->n;
+        if (n_global) *n_global = data->n_global;
+    });
+}
+int mlhip_data_shift(const mlhip_data* data, double* shift)
+{
+    return guarded([&] {
+        require(data && shift, "null argument");
+        std::memcpy(shift, data->shift.data(), sizeof(double) * data->d);
+    });
+}
+
+int mlhip_em_expectation(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* mixing, const double* means,
+                         const double* covariances, double* log_likelihood)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, K);
+        require(mixing && means && covariances && log_likelihood, "null argument");
+        run_estep(data, (int)K, mixing, means, covariances);
+        double* slot = data->stats_dev.as<double>() + (size_t)K * stats_count(data->d);
+        launch_ll_reduce(data->ll_partials.as<double>(), data->n_ll, slot, ctx->stream);
+        HIP_CHECK(hipGetLastError());
+        double* host_slot = data->stats_host.as<double>() + (size_t)K * stats_count(data->d);
+        HIP_CHECK(hipMemcpyAsync(host_slot, slot, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        ctx->sync();
+        ctx->allreduce_host(host_slot, 1);
+        *log_likelihood = ll_from_stats(data, (int)K);
+    });
+}
+
+int mlhip_em_maximisation(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, double* mixing_out, double* means_out,
+                          double* covariances_out)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, K);
+        require(mixing_out && means_out && covariances_out, "null argument");
+        require(data->have_estep && data->em_K == (int)K, "no E-step results on the device for this K");
+        run_mstats(data, (int)K, kFromLogResp, nullptr, 0, nullptr, true);
+        finalize_out(data, (int)K, mixing_out, means_out, covariances_out);
+    });
+}
+
+int mlhip_em_step(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* mixing, const double* means,
+                  const double* covariances, double* log_likelihood, double* mixing_out, double* means_out,
+                  double* covariances_out)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, K);
+        require(mixing && means && covariances && log_likelihood && mixing_out && means_out && covariances_out, "null argument");
+        run_estep(data, (int)K, mixing, means, covariances);
+        run_mstats(data, (int)K, kFromLogResp, nullptr, 0, nullptr, true);
+        *log_likelihood = ll_from_stats(data, (int)K);
+        finalize_out(data, (int)K, mixing_out, means_out, covariances_out);
+    });
+}
+
+int mlhip_em_maximisation_from(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* resp, int64_t ldr,
+                               double* mixing_out, double* means_out, double* covariances_out)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, K);
+        require(resp && mixing_out && means_out && covariances_out, "null argument");
+        require(ldr >= (int64_t)data->n, "ldr must be >= n_local");
+        ensure_em_workspace(data, (int)K);
+        data->resp_dev.reserve(sizeof(double) * data->ldr * K);
+        HIP_CHECK(hipMemsetAsync(data->resp_dev.p, 0, sizeof(double) * data->ldr * K, ctx->stream));
+        if (data->n)
+            HIP_CHECK(hipMemcpy2DAsync(data->resp_dev.p, sizeof(double) * data->ldr, resp, sizeof(double) * ldr,
+                                       sizeof(double) * data->n, K, hipMemcpyHostToDevice, ctx->stream));
+        run_mstats(data, (int)K, kFromResp, data->resp_dev.as<double>(), data->ldr, nullptr, false);
+        finalize_out(data, (int)K, mixing_out, means_out, covariances_out);
+    });
+}
+
+int mlhip_em_maximisation_from_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const uint32_t* labels,
+                                      double* mixing_out, double* means_out, double* covariances_out)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, K);
+        require(labels && mixing_out && means_out && covariances_out, "null argument");
+        ensure_em_workspace(data, (int)K);
+        data->labels_dev.reserve(sizeof(uint32_t) * data->n_pad);
+        HIP_CHECK(hipMemcpyAsync(data->labels_dev.p, labels, sizeof(uint32_t) * data->n, hipMemcpyHostToDevice, ctx->stream));
+        run_mstats(data, (int)K, kFromLabels, nullptr, 0, data->labels_dev.as<uint32_t>(), false);
+        finalize_out(data, (int)K, mixing_out, means_out, covariances_out);
+    });
+}
+
+int mlhip_em_responsibilities(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, double* resp, int64_t ldr)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, K);
+        require(resp, "null argument");
+        require(ldr >= (int64_t)data->n, "ldr must be >= n_local");
+        require(data->have_estep && data->em_K == (int)K, "no E-step results on the device for this K");
+        data->resp_dev.reserve(sizeof(double) * data->ldr * K);
+        RespArgs a{data->lw.as<double>(), data->ldr, data->lse.as<double>(), data->n, (int)K,
+                   data->resp_dev.as<double>(), data->ldr, nullptr};
+        launch_em_responsibilities(a, ctx->stream);
+        HIP_CHECK(hipGetLastError());
+        if (data->n)
+            HIP_CHECK(hipMemcpy2DAsync(resp, sizeof(double) * ldr, data->resp_dev.p, sizeof(double) * data->ldr,
+                                       sizeof(double) * data->n, K, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->sync();
+    });
+}
+
+int mlhip_em_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, uint32_t* labels)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, K);
+        require(labels, "null argument");
+        require(data->have_estep && data->em_K == (int)K, "no E-step results on the device for this K");
+        data->labels_dev.reserve(sizeof(uint32_t) * data->n_pad);
+        RespArgs a{data->lw.as<double>(), data->ldr, data->lse.as<double>(), data->n, (int)K, nullptr, 0,
+                   data->labels_dev.as<uint32_t>()};
+        launch_em_responsibilities(a, ctx->stream);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(labels, data->labels_dev.p, sizeof(uint32_t) * data->n, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->sync();
+    });
+}
+
+int mlhip_sample_covariance(mlhip_ctx* ctx, mlhip_data* data, double* mean, double* covariance)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, 1);
+        require(covariance, "null argument");
+        const int saved_K = data->em_K;
+        (void)saved_K;
+        // K = 1, r = 1: S_0 = sum_i xt_i xt_i^T about the global mean. The E-step workspace for another K is
+        // left untouched only if K == 1; otherwise it is rebuilt on the next E-step.
+        ensure_em_workspace(data, 1);
+        run_mstats(data, 1, kOnes, nullptr, 0, nullptr, false);
+        const double* s = data->stats_host.as<double>();
+        const int d = data->d;
+        const double n = (double)data->n_global;
+        // shift == global mean, so S1' is rounding noise; subtract its (tiny) contribution anyway.
+        for (int a = 0; a < d; ++a) {
+            const double ma = s[stats_index(d, a)] / n;
+            if (mean) mean[a] = data->shift[a] + ma;
+            for (int b = 0; b <= a; ++b) {
+                const double v = (s[stats_index(a, b)] - s[stats_index(d, a)] * (s[stats_index(d, b)] / n)) / (n - 1.0);
+                covariance[(size_t)b * d + a] = v;
+                covariance[(size_t)a * d + b] = v;
+            }
+        }
+    });
+}
+
+int mlhip_process_covariance(uint32_t d, const double* covariance, double* inverse, double* sqrt_det)
+{
+    return guarded([&] {
+        require(d >= 1 && covariance && inverse && sqrt_det, "bad argument");
+        host::process_covariance((int)d, covariance, inverse, sqrt_det);
+    });
+}
+
+int mlhip_kmeans_step(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* centroids, double* inertia,
+                      uint64_t* n_changed, double* counts, double* centroids_out)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, K);
+        require(centroids && inertia && n_changed && counts && centroids_out, "null argument");
+        run_kmeans(data, (int)K, centroids, true, nullptr);
+        const double* r = data->km_host.as<double>();
+        const int d = data->d;
+        *inertia = r[0];
+        *n_changed = (uint64_t)std::llround(r[1]);
+        for (uint32_t k = 0; k < K; ++k) {
+            const double c = r[2 + k];
+            counts[k] = c;
+            for (int j = 0; j < d; ++j)
+                centroids_out[(size_t)k * d + j] = c > 0 ? r[2 + K + (size_t)k * d + j] / c : 0.0;   // empty -> origin (:184)
+        }
+    });
+}
+
+int mlhip_kmeans_assign(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* centroids, double* inertia,
+                        uint64_t* n_changed)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, K);
+        require(centroids && inertia && n_changed, "null argument");
+        run_kmeans(data, (int)K, centroids, false, nullptr);
+        const double* r = data->km_host.as<double>();
+        *inertia = r[0];
+        *n_changed = (uint64_t)std::llround(r[1]);
+    });
+}
+
+int mlhip_kmeans_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t* labels)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, 1);
+        require(labels, "null argument");
+        require(data->km_have_old, "no K-means assignment on the device yet");
+        HIP_CHECK(hipMemcpyAsync(labels, data->km_labels[data->km_cur].p, sizeof(uint32_t) * data->n, hipMemcpyDeviceToHost,
+                                 ctx->stream));
+        ctx->sync();
+    });
+}
+
+int mlhip_min_squared_distances(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* centroids, double* dist2)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, K);
+        require(centroids && dist2, "null argument");
+        data->km_mind.reserve(sizeof(double) * data->n_pad);
+        // Must not disturb the label history used for n_changed: run on a scratch copy of the state.
+        const int cur = data->km_cur;
+        const bool have = data->km_have_old;
+        run_kmeans(data, (int)K, centroids, false, data->km_mind.as<double>());
+        if (have) {
+            // The assignment wrote labels into the *other* buffer; keep the previous labels current.
+            data->km_cur = cur;
+        }
+        data->km_have_old = have;
+        HIP_CHECK(hipMemcpyAsync(dist2, data->km_mind.p, sizeof(double) * data->n, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->sync();
+    });
+}
+
+int mlhip_timing_enable(mlhip_ctx* ctx, int on)
+{
+    return guarded([&] { require(ctx, "null context"); ctx->timing = on != 0; });
+}
+int mlhip_timing_reset(mlhip_ctx* ctx)
+{
+    return guarded([&] { require(ctx, "null context"); ctx->timers.clear(); });
+}
+int mlhip_timing_get(mlhip_ctx* ctx, const char* name, double* avg_ms, uint64_t* launches)
+{
+    return guarded([&] {
+        require(ctx && name && avg_ms && launches, "null argument");
+        auto it = ctx->timers.find(name);
+        if (it == ctx->timers.end() || it->second.launches == 0) { *avg_ms = 0; *launches = 0; return; }
+        *avg_ms = it->second.total_ms / (double)it->second.launches;
+        *launches = it->second.launches;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,205 @@
+"""Parity of the HIP path (through the C ABI, include/mlhip.h) against the golden fixtures and the CPU oracle.
+Needs a GPU: run with `pytest -m gpu`.
+
+Tolerances (DESIGN.md "Tolerances"): log-likelihood 1e-12 relative; mixing/means 1e-11, covariances 1e-10
+relative (max-norm); responsibilities 1e-12 absolute; labels bit-exact."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+
+EM_CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "em_onestep_*.npz")))
+KM_CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "kmeans_onestep_*.npz")))
+
+
+def relerr(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(1e-300, np.max(np.abs(b)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from ml_amd import _lib
+    c = _lib.Context()
+    yield c
+    c.close()
+
+
+def _data(ctx, X):
+    from ml_amd import _lib
+    return _lib.Data(ctx, np.ascontiguousarray(X, dtype=np.float64))
+
+
+@pytest.mark.parametrize("case", EM_CASES)
+def test_em_step_matches_golden(ctx, case):
+    g = load_golden(case)
+    X = g["X"]
+    K = g["pi0"].size
+    dt = _data(ctx, X)
+    ll, pi1, mu1, S1 = dt.em_step(g["pi0"], g["mu0"], g["Sigma0"])
+    assert abs(ll - float(g["ll0"])) <= 1e-12 * abs(float(g["ll0"]))
+    assert relerr(pi1, g["pi1"]) < 1e-11
+    assert relerr(mu1, g["mu1"]) < 1e-11
+    assert relerr(S1, g["Sigma1"]) < 1e-10
+    R = dt.em_responsibilities(K)
+    assert np.max(np.abs(R - g["R0"])) < 1e-12
+    assert np.array_equal(dt.em_labels(K), g["labels0"])
+    # E-step-only / M-step-only entry points give the same numbers.
+    ll2 = dt.em_expectation(g["pi0"], g["mu0"], g["Sigma0"])
+    assert ll2 == ll
+    pi2, mu2, S2 = dt.em_maximisation(K)
+    assert np.array_equal(pi2, pi1) and np.array_equal(mu2, mu1) and np.array_equal(S2, S1)
+    # M-step from caller-given responsibilities (maximise_first path) and from hard labels.
+    pi3, mu3, S3 = dt.em_maximisation_from(g["R0"])
+    assert relerr(pi3, g["pi1"]) < 1e-11 and relerr(mu3, g["mu1"]) < 1e-11 and relerr(S3, g["Sigma1"]) < 1e-10
+    dt.close()
+
+
+@pytest.mark.parametrize("case", EM_CASES)
+def test_em_step_matches_oracle(ctx, oracle, case):
+    g = load_golden(case)
+    X = g["X"]
+    K = g["pi0"].size
+    em = oracle.EM(K)
+    em.set_parameters(g["mu0"], g["Sigma0"], g["pi0"])
+    em.expectation_step(X)
+    ll_ref = em.log_likelihood
+    R_ref = em.responsibilities
+    em.calculate_labels()
+    labels_ref = em.labels
+    em.maximisation_step(X)
+    dt = _data(ctx, X)
+    ll, pi1, mu1, S1 = dt.em_step(g["pi0"], g["mu0"], g["Sigma0"])
+    assert abs(ll - ll_ref) <= 1e-12 * abs(ll_ref)
+    assert relerr(pi1, em.mixing_probabilities) < 1e-11
+    assert relerr(mu1, em.means) < 1e-11
+    assert relerr(S1, em.covariances) < 1e-10
+    assert np.max(np.abs(dt.em_responsibilities(K) - R_ref)) < 1e-12
+    assert np.array_equal(dt.em_labels(K), labels_ref)
+    dt.close()
+
+
+def test_em_hard_labels_mstep(ctx, oracle):
+    g = load_golden("em_onestep_d4_K3.npz")
+    X, labels, K = g["X"], g["labels0"], 3
+    R = np.zeros((X.shape[0], K))
+    R[np.arange(X.shape[0]), labels] = 1
+    em = oracle.EM(K)
+    em.set_responsibilities(R, X.shape[1])
+    em.maximisation_step(X)
+    dt = _data(ctx, X)
+    pi1, mu1, S1 = dt.em_maximisation_from_labels(labels, K)
+    assert relerr(pi1, em.mixing_probabilities) < 1e-12
+    assert relerr(mu1, em.means) < 1e-12
+    assert relerr(S1, em.covariances) < 1e-10
+    dt.close()
+
+
+@pytest.mark.parametrize("case", EM_CASES)
+def test_sample_covariance(ctx, oracle, case):
+    X = load_golden(case)["X"]
+    dt = _data(ctx, X)
+    mean, cov = dt.sample_covariance()
+    assert relerr(mean, X.mean(axis=0)) < 1e-13
+    assert relerr(cov, oracle.sample_covariance(X)) < 1e-12
+    assert relerr(cov, np.cov(X.T)) < 1e-12
+    dt.close()
+
+
+@pytest.mark.parametrize("case", KM_CASES)
+def test_kmeans_step_matches_golden(ctx, oracle, case):
+    g = load_golden(case)
+    X, C0 = g["X"], g["C0"]
+    n, K = X.shape[0], C0.shape[0]
+    dt = _data(ctx, X)
+    inertia, changed, counts, C1 = dt.kmeans_step(C0)
+    assert changed == n                       # first call: everything counts as changed
+    assert np.array_equal(dt.kmeans_labels(), g["labels0"])
+    assert abs(inertia - float(g["inertia0"])) <= 1e-13 * float(g["inertia0"])
+    assert np.array_equal(counts, g["counts0"].astype(float))
+    assert relerr(C1, g["C1"]) < 1e-13
+    # Same centroids again -> nothing changes; per-sample distances equal the oracle's point query bit for bit.
+    inertia2, changed2 = dt.kmeans_assign(C0)
+    assert changed2 == 0 and inertia2 == inertia
+    km = oracle.KMeans(K)
+    km.set_centroids(C0, n)
+    d2 = dt.min_squared_distances(C0)
+    ref = np.array([km.assign_label(X[i])[1] for i in range(0, n, 7)])
+    assert np.max(np.abs(d2[::7] - ref)) <= 1e-15 * np.max(ref)
+    dt.close()
+
+
+def test_kmeans_empty_cluster_goes_to_origin(ctx):
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((1000, 3))
+    C0 = np.array([[0.0, 0, 0], [100.0, 100, 100]])     # second cluster attracts nothing
+    dt = _data(ctx, X)
+    inertia, changed, counts, C1 = dt.kmeans_step(C0)
+    assert counts[1] == 0 and np.array_equal(C1[1], np.zeros(3))   # ML/KMeans.cpp:184
+    assert counts[0] == 1000
+    dt.close()
+
+
+@pytest.mark.parametrize("n,d,K", [(1, 1, 1), (255, 5, 3), (257, 7, 17), (4096, 32, 64), (10007, 16, 16), (3000, 8, 256)])
+def test_em_step_ragged_shapes(ctx, oracle, n, d, K):
+    """Sizes that are not multiples of the tile / block sizes, padded dimensions, many components."""
+    rng = np.random.default_rng(n + d + K)
+    means = 3.0 * rng.standard_normal((K, d))
+    comp = rng.integers(0, K, n)
+    X = np.ascontiguousarray(means[comp] + rng.standard_normal((n, d)))
+    mu0 = means + 0.2 * rng.standard_normal((K, d))
+    S0 = np.stack([np.eye(d) * rng.uniform(0.8, 1.5) + 0.05 for _ in range(K)])
+    pi0 = np.full(K, 1.0 / K)
+    em = oracle.EM(K)
+    em.set_parameters(mu0, S0, pi0)
+    em.expectation_step(X)
+    ll_ref, R_ref = em.log_likelihood, em.responsibilities
+    dt = _data(ctx, X)
+    ll = dt.em_expectation(pi0, mu0, S0)
+    assert abs(ll - ll_ref) <= 1e-12 * abs(ll_ref)
+    assert np.max(np.abs(dt.em_responsibilities(K) - R_ref)) < 1e-12
+    if n >= 4 * K:   # otherwise some components are (nearly) empty and the M-step is degenerate
+        em.maximisation_step(X)
+        pi1, mu1, S1 = dt.em_maximisation(K)
+        assert relerr(pi1, em.mixing_probabilities) < 1e-11
+        assert relerr(mu1, em.means) < 1e-11
+        assert relerr(S1, em.covariances) < 1e-10
+    dt.close()
+
+
+def test_strided_input_and_device_upload(ctx):
+    from ml_amd import _lib
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    big = rng.standard_normal((500, 10))
+    X = np.ascontiguousarray(big[:, :6])
+    dt1 = _data(ctx, X)
+    # ld > d through the raw ABI
+    h = C.c_void_p()
+    _lib.check(_lib.lib.mlhip_data_upload(ctx.handle, _lib.dptr(big), 6, C.c_uint64(500), C.c_int64(10), C.byref(h)))
+    s1 = dt1.shift
+    out = np.empty(6)
+    _lib.check(_lib.lib.mlhip_data_shift(h, _lib.dptr(out)))
+    assert np.array_equal(s1, out)
+    assert np.max(np.abs(s1 - X.mean(axis=0))) < 1e-15
+    _lib.check(_lib.lib.mlhip_data_free(h))
+    dt1.close()
+
+
+def test_bad_arguments(ctx):
+    from ml_amd import _lib
+    X = np.zeros((10, 3))
+    dt = _data(ctx, X)
+    with pytest.raises(ValueError):
+        dt.em_responsibilities(2)            # no E-step yet
+    with pytest.raises(ValueError):
+        dt.kmeans_labels()
+    with pytest.raises(TypeError):
+        _lib.Data(ctx, np.zeros((10, 3), dtype=np.float32))
+    with pytest.raises(_lib.MlhipError):
+        _lib.Data(ctx, np.zeros((10, 33)))   # d > 32 unsupported (yet)
+    dt.close()
