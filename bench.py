@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Gaussian-mixture EM iterations/sec at N=10M, d=32, K=64, fp64 (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One step = one EM iteration = E-step + M-step statistics + statistics all-reduce + M-step closing arithmetic
+(K Cholesky/inverse) + convergence bookkeeping, i.e. one trip of the reference loop ML/EM.cpp:143-170, executed
+through the C ABI entry point mlhip_em_step on data already resident in HBM. The N samples are row-sharded
+over the ranks (strong scaling: the job size is fixed), the only exchange is one all-reduce of the K*561+1
+sufficient statistics per iteration through torch.distributed (backend nccl == RCCL over xGMI).
+
+Prints ONE JSON line on rank 0 (see the fields below)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_TOTAL, DIM, COMPONENTS = 10_000_000, 32, 64
+FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector == matrix peak (spec); measured ceilings: tools/microbench_fp64
+HBM_PEAK_GBS = 8000.0
+
+
+def algorithmic_flops(n, d, K):
+    """N*K*(2d^2 + 6d + 25) per EM iteration (full covariance)."""
+    return float(n) * K * (2 * d * d + 6 * d + 25)
+
+
+def estep_flops(n, d, K):
+    return float(n) * K * (d * d + 3 * d + 25)
+
+
+def mstats_flops(n, d, K):
+    return float(n) * K * (d * d + 3 * d)
+
+
+def cpu_baseline(mix, d, K, n_cpu, iters):
+    """The CPU restatement of the reference (oracle/, single thread like the reference) on a bounded sample."""
+    from oracle import oracle_ctypes as orc
+    X, _ = mix.sample(n_cpu, stream=999)
+    em = orc.EM(K)
+    em.set_parameters(mix.initial_means(), np.stack([np.cov(X.T)] * K), np.full(K, 1.0 / K))
+    sec_per_iter = em.time_iterations(X, iters)
+    return sec_per_iter, n_cpu
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=N_TOTAL, help="total samples (default: the BASELINE.json configuration)")
+    ap.add_argument("--dim", type=int, default=DIM)
+    ap.add_argument("--components", type=int, default=COMPONENTS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-samples", type=int, default=200_000)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+
+    import torch
+    import torch.distributed as dist
+    from ml_amd import _lib, synth
+    from ml_amd import dist as mldist
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n, d, K = args.n, args.dim, args.components
+    lo, hi = mldist.shard_bounds(n, world, rank)
+    mix = synth.Mixture(d, K)
+    X, _ = mix.sample(hi - lo, stream=rank)
+
+    ctx = _lib.Context(local_rank)
+    if world > 1:
+        mldist.install_allreduce(ctx, world, rank)
+    data = _lib.Data(ctx, X)
+    del X
+
+    # Start exactly like EM::fit without maximise_first (ML/EM.cpp:127-135): given means, shared sample covariance.
+    _, cov = data.sample_covariance()
+    pi = np.full(K, 1.0 / K)
+    mu = mix.initial_means()
+    S = np.stack([cov] * K)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    ll = None
+    for _ in range(args.warmup):
+        ll, pi, mu, S = data.em_step(pi, mu, S)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ll, pi, mu, S = data.em_step(pi, mu, S)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # Per-kernel device time (HIP events on the kernels' own stream), measured in a separate pass so that the
+    # event synchronisation does not perturb the timed region above.
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    for _ in range(3):
+        ll, pi, mu, S = data.em_step(pi, mu, S)
+    e_ms, _ = ctx.timing_get("em_estep")
+    m_ms, _ = ctx.timing_get("em_mstats")
+    ctx.timing_enable(False)
+
+    if rank == 0:
+        n_local = hi - lo
+        dom_name, dom_ms, dom_flops = ("em_estep", e_ms, estep_flops(n_local, d, K)) if e_ms >= m_ms else \
+                                      ("em_mstats", m_ms, mstats_flops(n_local, d, K))
+        achieved = dom_flops / (dom_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom_name)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "GMM-EM iterations/sec at N=10M d=32 K=64 (full covariance, fp64)",
+            "value": args.steps / elapsed,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"GMM-EM N={n} d={d} K={K} full covariance, row-sharded over {world} GPU(s)",
+                       "N": n, "d": d, "K": K, "parallelism": f"dp{world}",
+                       "final_mean_log_likelihood": ll},
+            "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel_ms": {"em_estep": e_ms, "em_mstats": m_ms},
+                         "iteration_algorithmic_tflops": algorithmic_flops(n_local, d, K) / (elapsed / args.steps) / 1e12},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            iters = 1
+            sec, n_cpu = cpu_baseline(mix, d, K, args.cpu_samples, iters)
+            out["cpu_baseline"] = {"value": 1.0 / (sec * n / n_cpu), "unit": "iterations/s", "cores": 1, "kind": "port",
+                                   "sample": f"{iters} EM iteration(s) of the single-threaded CPU restatement (oracle/) on "
+                                             f"{n_cpu} samples (d={d}, K={K}), time scaled x{n / n_cpu:g} to N={n} "
+                                             f"(cost is linear in N, ML/EM.cpp:205,245)",
+                                   "seconds_per_iteration_on_sample": sec}
+        print(json.dumps(out))
+    data.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
