@@ -1,0 +1,18 @@
+#pragma once
+/* Which GPU the facade classes run on. Not part of the reference API (the reference is CPU-only); device selection
+ * is deliberately kept out of the model classes so that ml::EM / ml::Clustering::KMeans keep their signatures. */
+#include "dll.hpp"
+
+struct mlhip_ctx;
+
+namespace ml {
+namespace device {
+/** Process-wide context used by the facade, created on first use (device: MLHIP_DEVICE, else LOCAL_RANK, else 0).
+@throw std::runtime_error If no HIP device is usable -- there is no CPU fallback. */
+DLL_DECLSPEC mlhip_ctx* context();
+/** Replaces the process-wide context (not owned); nullptr restores the lazily created default. */
+DLL_DECLSPEC void set_context(mlhip_ctx* ctx);
+/** Throws the C++ exception matching a failed C-ABI call (std::invalid_argument / std::domain_error / std::runtime_error). */
+DLL_DECLSPEC void check(int mlhip_status);
+}
+}

@@ -61,6 +61,11 @@ typedef int (*mlhip_allreduce_fn)(void* user, double* buf, size_t count, int on_
 int mlhip_ctx_set_allreduce(mlhip_ctx* ctx, mlhip_allreduce_fn fn, void* user, int on_device,
                             int world_size, int rank);
 
+/* In-place sum of `count` host doubles across ranks through the installed hook (no-op without one). The facade
+ * uses it to agree on initial parameters (rank 0 contributes them, the others contribute zeros). */
+int mlhip_ctx_allreduce(mlhip_ctx* ctx, double* buf, size_t count);
+int mlhip_ctx_world(const mlhip_ctx* ctx, int* world_size, int* rank);
+
 /* ---- resident data ------------------------------------------------------------------------------ */
 /* Copies this rank's d x n block to HBM (stored dimension-major for coalesced per-sample access) and
  * computes the statistics shift (global column mean; all-reduced when a hook is set). The host block is
@@ -111,6 +116,14 @@ int mlhip_em_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, uint32_t* labe
  * ML/EM.cpp:265-272). mean may be NULL. */
 int mlhip_sample_covariance(mlhip_ctx* ctx, mlhip_data* data, double* mean, double* covariance);
 
+/* Host helpers, no GPU needed: the layout of the all-reduced sufficient statistics and the M-step closing
+ * arithmetic applied to them (ML/EM.cpp:242, 250-257). Per component, F = (d+1)(d+2)/2 doubles: the packed lower
+ * triangle (row-major: entry (a,b), a >= b, at a(a+1)/2 + b) of  sum_i r_ik xt_i xt_i^T  with
+ * xt_i = [x_i - shift ; 1]; so S0 = (d,d), S1'_b = (d,b), M2'_ab = (a,b). `statistics` holds K such records. */
+int mlhip_em_statistics_count(uint32_t d, uint32_t* count_per_component);
+int mlhip_em_finalize_statistics(uint32_t d, uint32_t K, const double* statistics, const double* shift,
+                                 double n_global, double* mixing_out, double* means_out, double* covariances_out);
+
 /* Host helper, no GPU needed: covariance -> what EM::process_covariances (ML/EM.cpp:274-287) derives:
  * inverse (d*d), sqrt(det). Used by the facade for point queries (EM::assign_responsibilities). */
 int mlhip_process_covariance(uint32_t d, const double* covariance, double* inverse, double* sqrt_det);
@@ -128,6 +141,9 @@ int mlhip_kmeans_step(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double
 int mlhip_kmeans_assign(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* centroids,
                         double* inertia, uint64_t* n_changed);
 int mlhip_kmeans_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t* labels);
+/* Per-sample squared distance to the assigned centroid from the last assignment (n_local doubles): the very values
+ * KMeans::assign_label returns (:153-165), so a caller can re-create the reference's sequential inertia sum (:176). */
+int mlhip_kmeans_distances(mlhip_ctx* ctx, mlhip_data* data, double* dist2);
 /* min_k |x_i - c_k|^2 per sample of this rank's shard (the weights of KPP::init, ML/Clustering.cpp:44-51). */
 int mlhip_min_squared_distances(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* centroids, double* dist2);
 

@@ -339,6 +339,7 @@ void ensure_km_workspace(mlhip_data* dt, int K)
 {
     mlhip_ctx* ctx = dt->ctx;
     for (int b = 0; b < 2; ++b) dt->km_labels[b].reserve(sizeof(uint32_t) * dt->n_pad);
+    dt->km_mind.reserve(sizeof(double) * dt->n_pad);
     dt->km_cent.reserve(sizeof(double) * (size_t)K * dt->D);
     dt->km_partials.reserve(sizeof(double) * kmeans_scratch_doubles(dt->d, K, ctx->num_cus));
     const size_t ob = sizeof(double) * (2 + (size_t)K * (dt->d + 1));
@@ -348,7 +349,7 @@ void ensure_km_workspace(mlhip_data* dt, int K)
 }
 
 /// Assignment (+ optional accumulation); leaves all-reduced [inertia, changed, counts, sums] in km_host.
-void run_kmeans(mlhip_data* dt, int K, const double* centroids, bool accumulate, double* min_dist_dev)
+void run_kmeans(mlhip_data* dt, int K, const double* centroids, bool accumulate)
 {
     mlhip_ctx* ctx = dt->ctx;
     ensure_km_workspace(dt, K);
@@ -364,7 +365,7 @@ void run_kmeans(mlhip_data* dt, int K, const double* centroids, bool accumulate,
     a.labels = dt->km_labels[nxt].as<uint32_t>();
     a.old_labels = dt->km_labels[dt->km_cur].as<uint32_t>();
     a.have_old = dt->km_have_old ? 1 : 0;
-    a.min_dist = min_dist_dev;
+    a.min_dist = dt->km_mind.as<double>();
     a.accumulate = accumulate ? 1 : 0;
     a.partials = dt->km_partials.as<double>(); a.partials_capacity = dt->km_partials.bytes / sizeof(double);
     a.out = dt->km_out.as<double>();
@@ -393,6 +394,8 @@ void run_kmeans(mlhip_data* dt, int K, const double* centroids, bool accumulate,
 extern "C" {
 
 const char* mlhip_last_error(void) { return g_error.c_str(); }
+/* Internal: lets the C++ facade's C wrappers (mlpp_capi.cpp) report through the same slot. */
+void mlhip_set_last_error_(const char* msg) { g_error = msg ? msg : ""; }
 const char* mlhip_version(void) { return "0.1.0 (gfx950)"; }
 
 int mlhip_device_count(int* count)
@@ -470,6 +473,23 @@ int mlhip_ctx_set_allreduce(mlhip_ctx* ctx, mlhip_allreduce_fn fn, void* user, i
         ctx->reduce_on_device = on_device;
         ctx->world_size = fn ? world_size : 1;
         ctx->rank = fn ? rank : 0;
+    });
+}
+
+int mlhip_ctx_allreduce(mlhip_ctx* ctx, double* buf, size_t count)
+{
+    return guarded([&] {
+        require(ctx && (buf || count == 0), "null argument");
+        ctx->use();
+        ctx->allreduce_host(buf, count);
+    });
+}
+int mlhip_ctx_world(const mlhip_ctx* ctx, int* world_size, int* rank)
+{
+    return guarded([&] {
+        require(ctx, "null context");
+        if (world_size) *world_size = ctx->world_size;
+        if (rank) *rank = ctx->rank;
     });
 }
 
@@ -645,6 +665,23 @@ int mlhip_sample_covariance(mlhip_ctx* ctx, mlhip_data* data, double* mean, doub
     });
 }
 
+int mlhip_em_statistics_count(uint32_t d, uint32_t* count_per_component)
+{
+    return guarded([&] {
+        require(d >= 1 && count_per_component, "bad argument");
+        *count_per_component = (uint32_t)stats_count((int)d);
+    });
+}
+
+int mlhip_em_finalize_statistics(uint32_t d, uint32_t K, const double* statistics, const double* shift, double n_global,
+                                 double* mixing_out, double* means_out, double* covariances_out)
+{
+    return guarded([&] {
+        require(d >= 1 && K >= 1 && statistics && shift && mixing_out && means_out && covariances_out, "bad argument");
+        host::finalize_mstep((int)d, (int)K, statistics, shift, n_global, mixing_out, means_out, covariances_out);
+    });
+}
+
 int mlhip_process_covariance(uint32_t d, const double* covariance, double* inverse, double* sqrt_det)
 {
     return guarded([&] {
@@ -659,7 +696,7 @@ int mlhip_kmeans_step(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double
     return guarded([&] {
         check_em_args(ctx, data, K);
         require(centroids && inertia && n_changed && counts && centroids_out, "null argument");
-        run_kmeans(data, (int)K, centroids, true, nullptr);
+        run_kmeans(data, (int)K, centroids, true);
         const double* r = data->km_host.as<double>();
         const int d = data->d;
         *inertia = r[0];
@@ -679,7 +716,7 @@ int mlhip_kmeans_assign(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const doub
     return guarded([&] {
         check_em_args(ctx, data, K);
         require(centroids && inertia && n_changed, "null argument");
-        run_kmeans(data, (int)K, centroids, false, nullptr);
+        run_kmeans(data, (int)K, centroids, false);
         const double* r = data->km_host.as<double>();
         *inertia = r[0];
         *n_changed = (uint64_t)std::llround(r[1]);
@@ -698,16 +735,26 @@ int mlhip_kmeans_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t* labels)
     });
 }
 
+int mlhip_kmeans_distances(mlhip_ctx* ctx, mlhip_data* data, double* dist2)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, 1);
+        require(dist2, "null argument");
+        require(data->km_have_old, "no K-means assignment on the device yet");
+        HIP_CHECK(hipMemcpyAsync(dist2, data->km_mind.p, sizeof(double) * data->n, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->sync();
+    });
+}
+
 int mlhip_min_squared_distances(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* centroids, double* dist2)
 {
     return guarded([&] {
         check_em_args(ctx, data, K);
         require(centroids && dist2, "null argument");
-        data->km_mind.reserve(sizeof(double) * data->n_pad);
         // Must not disturb the label history used for n_changed: run on a scratch copy of the state.
         const int cur = data->km_cur;
         const bool have = data->km_have_old;
-        run_kmeans(data, (int)K, centroids, false, data->km_mind.as<double>());
+        run_kmeans(data, (int)K, centroids, false);
         if (have) {
             // The assignment wrote labels into the *other* buffer; keep the previous labels current.
             data->km_cur = cur;

@@ -1,0 +1,340 @@
+"""The reference's own tests (Tests/test_EM.cpp, Tests/test_KMeans.cpp, cppyml/tests/test_clustering.py) re-expressed
+on the product's Python surface (ml_amd.cppyml.clustering -> C ABI -> HIP kernels), plus full-fit parity against the
+CPU oracle run with the same seeds and initialisers. Needs a GPU: `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _clustering():
+    from ml_amd.cppyml import clustering
+    return clustering
+
+
+INIT = {"forgy": ("Forgy", "FORGY"), "random_partition": ("RandomPartition", "RANDOM_PARTITION"), "kpp": ("KPP", "KPP")}
+
+
+def _check_two_gaussians_em(oracle, init, maximise_first):
+    cl = _clustering()
+    data, _ = oracle.testdata_two_gaussians(400)
+    K, d, n = 2, 3, 400
+    em = cl.EM(K)
+    assert not em.converged
+    assert em.number_components == K
+    em.set_absolute_tolerance(1e-8)
+    em.set_relative_tolerance(1e-8)
+    em.set_maximum_steps(100)
+    ref = oracle.EM(K)
+    ref.set_absolute_tolerance(1e-8)
+    ref.set_relative_tolerance(1e-8)
+    ref.set_maximum_steps(100)
+    if init is not None:
+        em.set_means_initialiser(getattr(cl, INIT[init][0])())
+        ref.set_means_initialiser(getattr(oracle, INIT[init][1]))
+    em.set_maximise_first(maximise_first)
+    ref.set_maximise_first(maximise_first)
+    em.set_seed(63413131)
+    ref.set_seed(63413131)
+    assert em.fit(data), "EM::fit did not converge"
+    assert em.converged
+    assert em.mixing_probabilities.size == K
+    assert em.labels.size == n
+    assert em.means.shape == (d, K)
+    R = em.responsibilities
+    assert R.shape == (n, K)
+    for i in range(n):                                  # Tests/test_EM.cpp:58-62
+        u = em.assign_responsibilities(data[i])
+        assert np.linalg.norm(u - R[i]) <= 1e-15, i
+
+    means = oracle.TWO_GAUSSIANS_MEANS.copy()
+    covs = np.stack([np.diag(s ** 2) for s in oracle.TWO_GAUSSIANS_SIGMAS])
+    p0 = oracle.TWO_GAUSSIANS_P0
+    probs = np.array([p0, 1 - p0])
+    pi = em.mixing_probabilities
+    if (pi[0] < pi[1]) != (p0 < 1 - p0):
+        probs, means, covs = probs[::-1], means[::-1], covs[::-1]
+    assert np.linalg.norm(probs - pi) <= 2e-2
+    assert np.linalg.norm(means.T - em.means) <= 2e-2
+    for k in range(K):
+        assert np.linalg.norm(covs[k] - em.covariance(k)) <= 1e-2
+
+    # full-fit parity with the CPU oracle: same seed, same initialiser, same data
+    assert ref.fit(data)
+    assert em.steps_done == ref.steps_done
+    assert abs(em.log_likelihood - ref.log_likelihood) <= 1e-12 * abs(ref.log_likelihood)
+    assert np.max(np.abs(em.means.T - ref.means)) <= 1e-10 * np.max(np.abs(ref.means))
+    assert np.max(np.abs(pi - ref.mixing_probabilities)) <= 1e-10
+    for k in range(K):
+        assert np.max(np.abs(em.covariance(k) - ref.covariances[k])) <= 1e-10 * np.max(np.abs(ref.covariances[k]))
+    assert np.array_equal(em.labels, ref.labels)        # bit-exact cluster assignments at convergence
+    assert np.max(np.abs(R - ref.responsibilities)) <= 1e-12
+
+    em1 = cl.EM(1)                                      # Tests/test_EM.cpp:89-103
+    if init is not None:
+        em1.set_means_initialiser(getattr(cl, INIT[init][0])())
+    em1.set_maximise_first(maximise_first)
+    em1.fit(data)
+    assert em1.log_likelihood <= em.log_likelihood
+    assert np.linalg.norm(data.mean(axis=0) - em1.means[:, 0]) <= 1e-14
+    R1 = em1.responsibilities
+    labels1 = em1.labels
+    for i in range(n):
+        u = em1.assign_responsibilities(data[i])
+        assert np.linalg.norm(u - R1[i]) <= 1e-15
+        assert labels1[i] == 0
+
+
+def test_em_two_gaussians_forgy(oracle): _check_two_gaussians_em(oracle, "forgy", False)
+def test_em_two_gaussians_random_partition(oracle): _check_two_gaussians_em(oracle, "random_partition", False)
+def test_em_two_gaussians_kpp(oracle): _check_two_gaussians_em(oracle, "kpp", False)
+def test_em_two_gaussians_closest_mean(oracle): _check_two_gaussians_em(oracle, None, True)
+
+
+def test_em_user_responsibilities_initialiser_path(oracle):
+    """maximise_first with a non-default centroids initialiser inside ClosestCentroid."""
+    cl = _clustering()
+    data, _ = oracle.testdata_two_gaussians(400)
+    em, ref = cl.EM(2), oracle.EM(2)
+    em.set_responsibilities_initialiser(cl.ClosestCentroid(cl.KPP()))
+    ref.set_responsibilities_initialiser(oracle.KPP)
+    for m in (em, ref):
+        m.set_maximise_first(True)
+        m.set_seed(7)
+        m.set_maximum_steps(100)
+    assert em.fit(data) and ref.fit(data)
+    assert em.steps_done == ref.steps_done
+    assert abs(em.log_likelihood - ref.log_likelihood) <= 1e-12 * abs(ref.log_likelihood)
+    assert np.array_equal(em.labels, ref.labels)
+
+
+def test_em_not_converged_keeps_labels_unset(oracle):
+    """Tolerances 0 => never converges => exactly maximum_steps iterations, labels not computed (ML/EM.cpp:161-168)."""
+    cl = _clustering()
+    data, _ = oracle.testdata_two_gaussians(400)
+    em, ref = cl.EM(2), oracle.EM(2)
+    for m in (em, ref):
+        m.set_absolute_tolerance(0.0)
+        m.set_relative_tolerance(0.0)
+        m.set_maximum_steps(7)
+        m.set_seed(3)
+    assert not em.fit(data) and not ref.fit(data)
+    assert em.steps_done == 7 and not em.converged
+    assert abs(em.log_likelihood - ref.log_likelihood) <= 1e-12 * abs(ref.log_likelihood)
+    assert np.max(np.abs(em.means.T - ref.means)) <= 1e-10 * np.max(np.abs(ref.means))
+    assert np.array_equal(em.labels, np.zeros(400, dtype=np.uint32))
+
+
+def _check_two_gaussians_kmeans(oracle, init):
+    cl = _clustering()
+    data, truth = oracle.testdata_two_gaussians(400)
+    K, d, n = 2, 3, 400
+    km, ref = cl.KMeans(K), oracle.KMeans(K)
+    assert not km.converged
+    assert km.number_clusters == K
+    for m in (km, ref):
+        m.set_absolute_tolerance(1e-8)
+        m.set_maximum_steps(100)
+        m.set_seed(63413131)
+    if init is not None:
+        km.set_centroids_initialiser(getattr(cl, INIT[init][0])())
+        ref.set_centroids_initialiser(getattr(oracle, INIT[init][1]))
+    assert km.fit(data), "KMeans::fit did not converge"
+    assert km.converged
+    C = km.centroids
+    assert C.shape == (K, d)
+    labels = np.array(km.labels)
+    assert labels.size == n
+    inertia = 0.0
+    for i in range(n):                                  # Tests/test_KMeans.cpp:57-63
+        label, dist = km.assign_label(data[i])
+        assert label == labels[i]
+        assert abs(np.sum((C[label] - data[i]) ** 2) - dist) <= 1e-15
+        inertia += dist
+    assert abs(inertia - km.inertia) <= 1e-15
+    cent = oracle.TWO_GAUSSIANS_MEANS.copy()
+    truth = truth.copy()
+    if truth[0] != labels[0]:
+        truth = 1 - truth
+        cent = cent[::-1]
+    assert np.linalg.norm(cent - C) <= 2e-2
+    assert np.array_equal(truth, labels)
+
+    assert ref.fit(data)                                # parity with the CPU oracle
+    assert km.steps_done == ref.steps_done
+    assert np.array_equal(labels, ref.labels)
+    assert np.max(np.abs(C - ref.centroids)) <= 1e-13
+    assert abs(km.inertia - ref.inertia) <= 1e-13 * ref.inertia
+
+    km.set_seed(63413131)                               # Tests/test_KMeans.cpp:75-79 multi-init
+    km.set_number_initialisations(3)
+    assert km.fit(data)
+    assert km.inertia <= inertia
+    ref.set_seed(63413131)
+    ref.set_number_initialisations(3)
+    assert ref.fit(data)
+    assert np.array_equal(np.array(km.labels), ref.labels)
+    assert abs(km.inertia - ref.inertia) <= 1e-13 * ref.inertia
+
+    km1 = cl.KMeans(1)
+    if init is not None:
+        km1.set_centroids_initialiser(getattr(cl, INIT[init][0])())
+    km1.fit(data)
+    assert np.linalg.norm(data.mean(axis=0) - km1.centroids[0]) <= 1e-14
+    for i in range(n):
+        assert km1.assign_label(data[i])[0] == 0
+
+
+def test_kmeans_two_gaussians_forgy(oracle): _check_two_gaussians_kmeans(oracle, "forgy")
+def test_kmeans_two_gaussians_random_partition(oracle): _check_two_gaussians_kmeans(oracle, "random_partition")
+def test_kmeans_two_gaussians_kpp(oracle): _check_two_gaussians_kmeans(oracle, "kpp")
+
+
+def test_mousie_em_matches_sklearn_score(oracle):
+    """cppyml/tests/test_clustering.py:47-74 on the product."""
+    cl = _clustering()
+    g = load_golden("mousie_sklearn.npz")
+    X = np.ascontiguousarray(g["X"])
+    em = cl.EM(3)
+    em.set_seed(42)
+    em.set_absolute_tolerance(1e-10)
+    em.set_relative_tolerance(0)
+    em.set_means_initialiser(cl.KPP())
+    em.set_maximum_steps(1000)
+    assert em.fit(X)
+    assert abs(em.log_likelihood - float(g["sklearn_score"])) < 1e-10
+    u = em.assign_responsibilities(np.array([0, 0]))
+    assert len(u) == 3
+    assert abs(sum(u) - 1) <= 1e-15
+    assert min(u) >= 0
+    assert abs(max(u) - 1) < 1e-9
+    ref = oracle.EM(3)
+    ref.set_seed(42); ref.set_absolute_tolerance(1e-10); ref.set_relative_tolerance(0)
+    ref.set_means_initialiser(oracle.KPP); ref.set_maximum_steps(1000)
+    assert ref.fit(X)
+    assert abs(em.steps_done - ref.steps_done) <= 1     # stopping step may move by one at this tolerance
+    assert abs(em.log_likelihood - ref.log_likelihood) < 1e-11
+
+
+def test_mousie_kmeans(oracle):
+    """cppyml/tests/test_clustering.py:76-95 on the product."""
+    cl = _clustering()
+    X = np.ascontiguousarray(load_golden("mousie_sklearn.npz")["X"])
+    km = cl.KMeans(3)
+    km.set_seed(42)
+    km.set_absolute_tolerance(1e-10)
+    km.set_centroids_initialiser(cl.KPP())
+    km.set_maximum_steps(1000)
+    km.set_number_initialisations(10)
+    assert km.fit(X)
+    assert km.inertia > 0
+    assert min(km.labels) == 0 and max(km.labels) == 2
+    assert km.centroids.shape == (3, 2)
+    for i, c in enumerate(km.centroids):
+        label, dist = km.assign_label(c)
+        assert label == i and dist == 0
+    ref = oracle.KMeans(3)
+    ref.set_seed(42); ref.set_absolute_tolerance(1e-10); ref.set_centroids_initialiser(oracle.KPP)
+    ref.set_maximum_steps(1000); ref.set_number_initialisations(10)
+    assert ref.fit(X)
+    assert np.array_equal(np.array(km.labels), ref.labels)
+    assert np.max(np.abs(km.centroids - ref.centroids)) <= 1e-13
+
+
+def test_bm_em_plumbing_config(oracle):
+    """BASELINE.json configs[0]: bm_EM-style plumbing run (N=10k, K=3) on the reference's own 'mousie' generator
+    (Benchmarks/bm_EM.cpp:11-43: KPP, tol 1e-14 -- here 1e-10 so that the stopping step is rounding-stable)."""
+    cl = _clustering()
+    X, _ = oracle.testdata_mousie(10000)
+    em, ref = cl.EM(3), oracle.EM(3)
+    em.set_means_initialiser(cl.KPP())
+    ref.set_means_initialiser(oracle.KPP)
+    for m in (em, ref):
+        m.set_absolute_tolerance(1e-10)
+        m.set_relative_tolerance(1e-10)
+        m.set_maximise_first(False)
+    assert em.fit(X) == ref.fit(X)
+    assert abs(em.steps_done - ref.steps_done) <= 1
+    assert abs(em.log_likelihood - ref.log_likelihood) <= 1e-10 * abs(ref.log_likelihood)
+    assert np.max(np.abs(em.means.T - ref.means)) <= 1e-8
+    if em.steps_done == ref.steps_done:
+        assert np.array_equal(em.labels, ref.labels)
+
+
+def test_synthetic_config_a_fixed_iterations(oracle):
+    """N=10k, d=4, K=3, 50 fixed iterations (tolerances 0) from a fixed start: trajectory parity after 50 steps."""
+    from ml_amd import synth
+    cl = _clustering()
+    mix = synth.Mixture(4, 3, seed=5)
+    X, _ = mix.sample(10000)
+    start = mix.initial_means()
+    em, ref = cl.EM(3), oracle.EM(3)
+    em.set_means_initialiser(cl.FixedCentroids(start))
+    ref.set_means_initialiser(oracle.FIXED, start)
+    for m in (em, ref):
+        m.set_absolute_tolerance(0.0)
+        m.set_relative_tolerance(0.0)
+        m.set_maximum_steps(50)
+    assert not em.fit(X) and not ref.fit(X)
+    assert em.steps_done == 50
+    assert abs(em.log_likelihood - ref.log_likelihood) <= 1e-12 * abs(ref.log_likelihood)
+    assert np.max(np.abs(em.means.T - ref.means)) <= 1e-10 * np.max(np.abs(ref.means))
+    for k in range(3):
+        assert np.max(np.abs(em.covariance(k) - ref.covariances[k])) <= 1e-10 * np.max(np.abs(ref.covariances[k]))
+    assert np.max(np.abs(em.responsibilities - ref.responsibilities)) <= 1e-11
+
+
+def test_converged_labels_bit_exact_d16_K16(oracle):
+    """Converge-run (tol 1e-10) at d=16, K=16: labels bit-exact, parameters within tolerance."""
+    from ml_amd import synth
+    cl = _clustering()
+    mix = synth.Mixture(16, 16, seed=9)
+    X, _ = mix.sample(20000)
+    start = mix.initial_means()
+    em, ref = cl.EM(16), oracle.EM(16)
+    em.set_means_initialiser(cl.FixedCentroids(start))
+    ref.set_means_initialiser(oracle.FIXED, start)
+    for m in (em, ref):
+        m.set_absolute_tolerance(1e-10)
+        m.set_relative_tolerance(1e-10)
+        m.set_maximum_steps(200)
+    assert em.fit(X) and ref.fit(X)
+    assert em.steps_done == ref.steps_done
+    assert np.array_equal(em.labels, ref.labels)
+    assert abs(em.log_likelihood - ref.log_likelihood) <= 1e-12 * abs(ref.log_likelihood)
+    assert np.max(np.abs(em.means.T - ref.means)) <= 1e-10 * np.max(np.abs(ref.means))
+
+
+def test_nccl_single_rank_hook_device_path():
+    """The device-pointer all-reduce hook (torch.distributed 'nccl' == RCCL) with world_size 1: validates the zero-copy
+    wrapping of the library's statistics buffer and the stream hand-off. Results must equal the hook-free run bit for bit."""
+    import torch
+    import torch.distributed as dist
+    from ml_amd import _lib, synth
+    from ml_amd import dist as mldist
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    mix = synth.Mixture(8, 4, seed=2)
+    X, _ = mix.sample(5000)
+    pi0, mu0 = np.full(4, 0.25), mix.initial_means()
+    S0 = np.stack([np.cov(X.T)] * 4)
+    ctx = _lib.Context(0)
+    dt = _lib.Data(ctx, X)
+    base = dt.em_step(pi0, mu0, S0)
+    dt.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        mldist.install_allreduce(ctx, 1, 0)
+        dt = _lib.Data(ctx, X)
+        hooked = dt.em_step(pi0, mu0, S0)
+        dt.close()
+        ctx.set_allreduce(None, False, 1, 0)
+    finally:
+        dist.destroy_process_group()
+    assert base[0] == hooked[0]
+    for a, b in zip(base[1:], hooked[1:]):
+        assert np.array_equal(a, b)
+    ctx.close()
