@@ -122,7 +122,9 @@ def test_em_not_converged_keeps_labels_unset(oracle):
         m.set_seed(3)
     assert not em.fit(data) and not ref.fit(data)
     assert em.steps_done == 7 and not em.converged
-    assert abs(em.log_likelihood - ref.log_likelihood) <= 1e-12 * abs(ref.log_likelihood)
+    # mid-trajectory (far from the fixed point) rounding differences are amplified by the iteration itself:
+    # the multi-iteration tolerance is 1e-10 (DESIGN.md "Tolerances"), single steps agree to 1e-12.
+    assert abs(em.log_likelihood - ref.log_likelihood) <= 1e-10 * max(1.0, abs(ref.log_likelihood))
     assert np.max(np.abs(em.means.T - ref.means)) <= 1e-10 * np.max(np.abs(ref.means))
     assert np.array_equal(em.labels, np.zeros(400, dtype=np.uint32))
 
@@ -279,7 +281,7 @@ def test_synthetic_config_a_fixed_iterations(oracle):
         m.set_maximum_steps(50)
     assert not em.fit(X) and not ref.fit(X)
     assert em.steps_done == 50
-    assert abs(em.log_likelihood - ref.log_likelihood) <= 1e-12 * abs(ref.log_likelihood)
+    assert abs(em.log_likelihood - ref.log_likelihood) <= 1e-10 * max(1.0, abs(ref.log_likelihood))
     assert np.max(np.abs(em.means.T - ref.means)) <= 1e-10 * np.max(np.abs(ref.means))
     for k in range(3):
         assert np.max(np.abs(em.covariance(k) - ref.covariances[k])) <= 1e-10 * np.max(np.abs(ref.covariances[k]))
