@@ -27,6 +27,8 @@ struct EstepArgs {
 };
 /// Returns the grid size used (= number of ll partials written), or <0 if D is not instantiated.
 int launch_em_estep(const EstepArgs& a, hipStream_t stream);
+/// Matrix-core variant (em_estep_mfma.hip); params use the estep_mfma_param_stride(D) record layout.
+int launch_em_estep_mfma(const EstepArgs& a, int num_cus, hipStream_t stream);
 
 enum MstatsMode : int {
     kFromLogResp = 0,   // r = exp(lw - lse)          (after an E-step)

@@ -4,9 +4,8 @@
 //
 // One lane owns one sample (coordinates in VGPRs, X dimension-major in HBM -> coalesced loads); the
 // centroid of the current cluster is wave-uniform and arrives through scalar loads. Distances are the
-// direct form sum_j (x_j - c_j)^2 accumulated in ascending j with separately rounded multiply and add
-// (no FMA contraction), i.e. exactly the IEEE operations the host-side assign_label performs, so the
-// per-sample distance and the argmin (strict '<', scan from k = 0, first minimum wins, label 0 default)
+// direct form sum_j (x_j - c_j)^2 accumulated in ascending j as s = fma(t, t, s) -- exactly the IEEE
+// operations the host-side assign_label performs (std::fma), so the per-sample distance and the argmin (strict '<', scan from k = 0, first minimum wins, label 0 default)
 // are bit-identical to the host point query. The expanded |x|^2 - 2x.c + |c|^2 form is deliberately not
 // used: its cancellation can flip labels of nearly equidistant samples.
 //
@@ -49,8 +48,8 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(
             double s = 0.0;
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                const double t = __dsub_rn(x[j], c[j]);
-                s = __dadd_rn(s, __dmul_rn(t, t));
+                const double t = x[j] - c[j];
+                s = __builtin_fma(t, t, s);
             }
             if (s < best) { best = s; arg = (uint32_t)k; }
         }

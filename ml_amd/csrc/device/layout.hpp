@@ -25,6 +25,14 @@ inline int padded_dim(int d)
 /// with Sigma = L L^T and coef = log(pi) - sum_j log L_jj.
 inline int estep_param_stride(int D) { return D + D * (D + 1) / 2 + 1; }
 
+/// Matrix-core E-step (dimensions 12..32, multiples of 4): W is cut into 16-row blocks J and 4-column slabs ls; only
+/// the slabs on or below the block diagonal exist. Record of one component, estep_mfma_param_stride(D) doubles:
+///   [ slab c = (J, ls) in (J-major) order: 64 doubles, lane l holds W[16J + (l&15)][4ls + (l>>4)] | mean(D) | coef ].
+inline int estep_mfma_slabs_of(int D, int J) { const int ls = D / 4; return 4 * (J + 1) < ls ? 4 * (J + 1) : ls; }
+inline int estep_mfma_slab_count(int D) { return D <= 16 ? estep_mfma_slabs_of(D, 0) : estep_mfma_slabs_of(D, 0) + estep_mfma_slabs_of(D, 1); }
+inline int estep_mfma_param_stride(int D) { return estep_mfma_slab_count(D) * 64 + D + 1; }
+inline bool estep_mfma_supported(int D) { return D >= 12 && D <= 32 && D % 4 == 0; }
+
 /// Sufficient statistics of one component: packed lower triangle (row-major) of sum_i r_i xt_i xt_i^T,
 /// xt = [x - shift ; 1] (length d+1). Entry (a,b), a >= b, sits at a(a+1)/2 + b; so
 ///   S0 = (d,d), S1'_b = (d,b), M2'_ab = (a,b).

@@ -45,6 +45,48 @@ void process_covariance(int d, const double* cov, double* inverse, double* sqrt_
     *sqrt_det = sd;
 }
 
+namespace {
+/// W = L^-1 (lower triangular, column-major d x d) and sum_j log L_jj for one covariance.
+double whitening_matrix(int d, const double* cov, std::vector<double>& L, std::vector<double>& W)
+{
+    cholesky_lower(d, cov, L.data());
+    for (int c = 0; c < d; ++c) {
+        for (int i = 0; i < d; ++i) {
+            if (i < c) { W[c * d + i] = 0.0; continue; }
+            double t = (i == c) ? 1.0 : 0.0;
+            for (int l = c; l < i; ++l) t -= L[l * d + i] * W[c * d + l];
+            W[c * d + i] = t / L[i * d + i];
+        }
+    }
+    double log_det_half = 0.0;
+    for (int j = 0; j < d; ++j) log_det_half += std::log(L[j * d + j]);
+    return log_det_half;
+}
+}  // namespace
+
+void build_estep_params_mfma(int d, int D, int K, const double* mixing, const double* means, const double* covariances,
+                             double* records)
+{
+    const int PS = estep_mfma_param_stride(D);
+    const int NC = estep_mfma_slab_count(D);
+    const int JB = (D + 15) / 16;
+    std::vector<double> L((size_t)d * d), W((size_t)d * d);
+    for (int k = 0; k < K; ++k) {
+        double* rec = records + (size_t)k * PS;
+        for (int i = 0; i < PS; ++i) rec[i] = 0.0;
+        const double log_det_half = whitening_matrix(d, covariances + (size_t)k * d * d, L, W);
+        int c = 0;
+        for (int J = 0; J < JB; ++J)
+            for (int ls = 0; ls < estep_mfma_slabs_of(D, J); ++ls, ++c)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int row = 16 * J + (lane & 15), col = 4 * ls + (lane >> 4);
+                    rec[c * 64 + lane] = (row < d && col <= row) ? W[col * d + row] : 0.0;
+                }
+        for (int j = 0; j < d; ++j) rec[NC * 64 + j] = means[(size_t)k * d + j];
+        rec[NC * 64 + D] = std::log(mixing[k]) - log_det_half;
+    }
+}
+
 void build_estep_params(int d, int D, int K, const double* mixing, const double* means, const double* covariances,
                         double* records)
 {
@@ -54,21 +96,10 @@ void build_estep_params(int d, int D, int K, const double* mixing, const double*
         double* rec = records + (size_t)k * PS;
         for (int i = 0; i < PS; ++i) rec[i] = 0.0;
         for (int j = 0; j < d; ++j) rec[j] = means[(size_t)k * d + j];
-        cholesky_lower(d, covariances + (size_t)k * d * d, L.data());
-        // W = L^-1 by forward substitution, column by column (W is lower triangular).
-        for (int c = 0; c < d; ++c) {
-            for (int i = 0; i < d; ++i) {
-                if (i < c) { W[c * d + i] = 0.0; continue; }
-                double t = (i == c) ? 1.0 : 0.0;
-                for (int l = c; l < i; ++l) t -= L[l * d + i] * W[c * d + l];
-                W[c * d + i] = t / L[i * d + i];
-            }
-        }
+        const double log_det_half = whitening_matrix(d, covariances + (size_t)k * d * d, L, W);
         double* w = rec + D;
         for (int j = 0; j < d; ++j)
             for (int l = 0; l <= j; ++l) w[j * (j + 1) / 2 + l] = W[l * d + j];
-        double log_det_half = 0.0;
-        for (int j = 0; j < d; ++j) log_det_half += std::log(L[j * d + j]);
         rec[PS - 1] = std::log(mixing[k]) - log_det_half;
     }
 }

@@ -3,6 +3,7 @@
 #include "ML/KMeans.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <iostream>
 #include <limits>
 #include <stdexcept>
@@ -79,7 +80,7 @@ std::pair<unsigned int, double> KMeans::assign_label(ConstVectorRef x) const
         double dist = 0;
         for (Index j = 0; j < d; ++j) {
             const double t = x[j] - c[j];
-            dist += t * t;
+            dist = std::fma(t, t, dist);
         }
         if (dist < nearest) { nearest = dist; label = k; }
     }

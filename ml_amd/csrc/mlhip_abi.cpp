@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -248,7 +249,8 @@ void ensure_em_workspace(mlhip_data* dt, int K)
     dt->lw.reserve(sizeof(double) * dt->ldr * K);
     dt->lse.reserve(sizeof(double) * dt->n_pad);
     dt->ll_partials.reserve(sizeof(double) * kMaxLlPartials);
-    const size_t ps = (size_t)estep_param_stride(dt->D) * K * sizeof(double);
+    size_t ps = (size_t)estep_param_stride(dt->D) * K * sizeof(double);
+    if (estep_mfma_supported(dt->D)) ps = std::max(ps, (size_t)estep_mfma_param_stride(dt->D) * K * sizeof(double));
     dt->params_dev.reserve(ps);
     dt->params_host.reserve(ps);
     dt->partials.reserve(sizeof(double) * em_mstats_scratch_doubles(dt->d, K, ctx->num_cus));
@@ -262,16 +264,29 @@ void run_estep(mlhip_data* dt, int K, const double* mixing, const double* means,
 {
     mlhip_ctx* ctx = dt->ctx;
     ensure_em_workspace(dt, K);
-    host::build_estep_params(dt->d, dt->D, K, mixing, means, covs, dt->params_host.as<double>());
-    HIP_CHECK(hipMemcpyAsync(dt->params_dev.p, dt->params_host.p, sizeof(double) * estep_param_stride(dt->D) * K,
-                             hipMemcpyHostToDevice, ctx->stream));
+    // Matrix-core kernel for d in 12..32, scalar-fed VALU kernel below that (MLHIP_ESTEP=valu|mfma overrides, for A/B runs).
+    bool use_mfma = estep_mfma_supported(dt->D);
+    if (const char* e = std::getenv("MLHIP_ESTEP")) {
+        if (std::strcmp(e, "valu") == 0) use_mfma = false;
+    }
+    if (use_mfma) {
+        host::build_estep_params_mfma(dt->d, dt->D, K, mixing, means, covs, dt->params_host.as<double>());
+        HIP_CHECK(hipMemcpyAsync(dt->params_dev.p, dt->params_host.p, sizeof(double) * estep_mfma_param_stride(dt->D) * K,
+                                 hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        host::build_estep_params(dt->d, dt->D, K, mixing, means, covs, dt->params_host.as<double>());
+        HIP_CHECK(hipMemcpyAsync(dt->params_dev.p, dt->params_host.p, sizeof(double) * estep_param_stride(dt->D) * K,
+                                 hipMemcpyHostToDevice, ctx->stream));
+    }
     EstepArgs a{};
     a.xt = dt->xt.as<double>(); a.ldx = dt->ldx; a.n = dt->n; a.D = dt->D;
     a.params = dt->params_dev.as<double>(); a.K = K;
     a.lw = dt->lw.as<double>(); a.ldr = dt->ldr; a.lse = dt->lse.as<double>();
     a.ll_partials = dt->ll_partials.as<double>(); a.n_ll_partials = kMaxLlPartials;
     int grid = 0;
-    ctx->timed("em_estep", [&] { grid = launch_em_estep(a, ctx->stream); });
+    ctx->timed("em_estep", [&] {
+        grid = use_mfma ? launch_em_estep_mfma(a, ctx->num_cus, ctx->stream) : launch_em_estep(a, ctx->stream);
+    });
     if (grid < 0) throw Unsupported("E-step kernel not instantiated for this dimension");
     HIP_CHECK(hipGetLastError());
     dt->n_ll = grid;
