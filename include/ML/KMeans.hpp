@@ -63,6 +63,7 @@ private:
 
     bool fit_once(ConstMatrixRef data, mlhip_data* device_data);
     void fetch_assignment(mlhip_data* device_data, std::size_t sample_size);
+    void sequential_inertia(mlhip_data* device_data, std::size_t sample_size);
 };
 
 }  // namespace Clustering

@@ -47,6 +47,41 @@ __global__ __launch_bounds__(256) void colsum_stage1(const double* __restrict__ 
     if (threadIdx.x == 0) scratch[(size_t)j * gridDim.x + blockIdx.x] = red[0];
 }
 
+__global__ __launch_bounds__(256) void colmax_stage1(const double* __restrict__ xt, size_t ldx, uint64_t n,
+                                                      double* __restrict__ scratch)
+{
+    __shared__ double red[256];
+    const int j = blockIdx.y;
+    const uint64_t chunk = (n + gridDim.x - 1) / gridDim.x;
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk;
+    uint64_t hi = lo + chunk;
+    if (hi > n) hi = n;
+    double m = 0.0;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) m = fmax(m, fabs(xt[(size_t)j * ldx + i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) scratch[(size_t)j * gridDim.x + blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void colmax_stage2(const double* __restrict__ scratch, int parts, double* __restrict__ out)
+{
+    __shared__ double red[256];
+    const int j = blockIdx.x;
+    double m = 0.0;
+    for (int b = threadIdx.x; b < parts; b += 256) m = fmax(m, scratch[(size_t)j * parts + b]);
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[j] = red[0];
+}
+
 __global__ __launch_bounds__(256) void colsum_stage2(const double* __restrict__ scratch, int parts, double* __restrict__ sums)
 {
     __shared__ double red[256];
@@ -71,6 +106,13 @@ void launch_transpose_to_dim_major(const double* src, int64_t lds, int d, uint64
     const unsigned blocks = (unsigned)((n + 63) / 64);
     hipLaunchKernelGGL(transpose_kernel, dim3(blocks), dim3(256), sizeof(double) * 64 * (d + 1), stream, src, lds, d, n, dst,
                        ldd, i0);
+}
+
+void launch_column_maxabs(const double* xt, size_t ldx, int d, uint64_t n, double* scratch, double* maxabs, hipStream_t stream)
+{
+    const int parts = 1024;
+    hipLaunchKernelGGL(colmax_stage1, dim3(parts, d), dim3(256), 0, stream, xt, ldx, n, scratch);
+    hipLaunchKernelGGL(colmax_stage2, dim3(d), dim3(256), 0, stream, scratch, parts, maxabs);
 }
 
 void launch_column_sums(const double* xt, size_t ldx, int d, uint64_t n, double* scratch, double* sums, hipStream_t stream)

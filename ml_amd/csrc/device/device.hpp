@@ -15,6 +15,8 @@ namespace mlhip {
 void launch_transpose_to_dim_major(const double* src, int64_t lds, int d, uint64_t n, double* dst, size_t ldd,
                                    uint64_t i0, hipStream_t stream);
 /// sums[j] = sum_i xt[j*ldx + i] (deterministic two-stage reduction); scratch >= d * 1024 doubles.
+/// maxabs[j] = max_i |xt[j*ldx + i]|; scratch >= d * 1024 doubles.
+void launch_column_maxabs(const double* xt, size_t ldx, int d, uint64_t n, double* scratch, double* maxabs, hipStream_t stream);
 void launch_column_sums(const double* xt, size_t ldx, int d, uint64_t n, double* scratch, double* sums, hipStream_t stream);
 
 // ---- EM ----------------------------------------------------------------------------------------------
@@ -64,6 +66,7 @@ void launch_em_responsibilities(const RespArgs& a, hipStream_t stream);
 struct KmeansArgs {
     const double* xt; size_t ldx; uint32_t n; int D; int d;
     const double* centroids; int K;            // device, [K][D] (padded coordinates zero)
+    const double* scale;                       // device, d doubles: per-dimension power-of-two scale of the exact sums
     uint32_t* labels; const uint32_t* old_labels; int have_old;
     double* min_dist;                          // out (may be null): per-sample min squared distance
     int accumulate;                            // also accumulate per-cluster sums / counts

@@ -41,6 +41,51 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+/// Component record in registers: the W slabs in A-operand order, the mean in B-operand row order, the constant.
+template <int D> struct Rec {
+    double a[Shape<D>::NC];
+    double mu[Shape<D>::LS];
+    double coef;
+};
+
+template <int D>
+__device__ __forceinline__ void load_rec(Rec<D>& r, const double* __restrict__ rec, int lane, int g)
+{
+    using S = Shape<D>;
+#pragma unroll
+    for (int c = 0; c < S::NC; ++c) r.a[c] = rec[c * 64 + lane];
+#pragma unroll
+    for (int ls = 0; ls < S::LS; ++ls) r.mu[ls] = rec[S::NC * 64 + 4 * ls + g];
+    r.coef = rec[S::NC * 64 + D];
+}
+
+/// Sum over the 4 lane groups (g = lane>>4) of v[sb], delivered so that group g ends with the total of v[g]:
+/// a reduce-scatter in two swap steps (rows g <-> g^1 with v_permlane16_swap, halves g <-> g^2 with
+/// v_permlane32_swap) -- 6 VALU swaps and 3 adds instead of 16 ds_bpermute and 8 adds.
+__device__ __forceinline__ double reduce_scatter_groups(double v0, double v1, double v2, double v3)
+{
+    auto swap16 = [](double& a, double& b) {   // odd rows of a <-> even rows of b
+        const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+        const auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        a = __hiloint2double((int)hi[0], (int)lo[0]);
+        b = __hiloint2double((int)hi[1], (int)lo[1]);
+    };
+    auto swap32 = [](double& a, double& b) {   // upper half of a <-> lower half of b
+        const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+        const auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        a = __hiloint2double((int)hi[0], (int)lo[0]);
+        b = __hiloint2double((int)hi[1], (int)lo[1]);
+    };
+    swap16(v0, v1);            // even rows: v0 own, v1 <- odd row's v0 ; odd rows: v0 <- even row's v1, v1 own
+    swap16(v2, v3);
+    double t01 = v0 + v1;      // even rows: sum of v0 over the pair, odd rows: sum of v1
+    double t23 = v2 + v3;      // even rows: v2, odd rows: v3
+    swap32(t01, t23);          // lower half: t23 <- upper's t01 ; upper half: t01 <- lower's t23
+    return t01 + t23;          // g=0: v0, g=1: v1, g=2: v2, g=3: v3 totals
+}
+
 template <int D>
 __global__ __launch_bounds__(256, 2) void em_estep_mfma_kernel(const double* __restrict__ xt, size_t ldx, uint32_t n,
                                                                 uint32_t n_groups, const double* __restrict__ params,
@@ -49,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void em_estep_mfma_kernel(const double* __r
                                                                 double* __restrict__ ll_partials)
 {
     using S = Shape<D>;
-    constexpr int LS = S::LS, JB = S::JB, NC = S::NC, PS = S::PS;
+    constexpr int LS = S::LS, JB = S::JB, PS = S::PS;
     __shared__ double red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, s = lane & 15;
@@ -66,17 +111,10 @@ __global__ __launch_bounds__(256, 2) void em_estep_mfma_kernel(const double* __r
             for (int sb = 0; sb < 4; ++sb) xb[ls][sb] = xt[(size_t)(4 * ls + g) * ldx + base + 16 * sb + s];
 
         double m = -__builtin_inf(), ssum = 0.0;
-        for (int k = 0; k < K; ++k) {
-            const double* __restrict__ rec = params + (size_t)k * PS;
-            double a[NC];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) a[c] = rec[c * 64 + lane];
-            double mu[LS];
-#pragma unroll
-            for (int ls = 0; ls < LS; ++ls) mu[ls] = rec[NC * 64 + 4 * ls + g];
-            const double coef = rec[NC * 64 + D];
 
-            double q = 0.0;
+        // One component: 4 sample blocks x (block-triangular MFMA chain, squares), then the log-domain epilogue.
+        auto component = [&](const Rec<D>& r, int k) {
+            double qs[4];
 #pragma unroll
             for (int sb = 0; sb < 4; ++sb) {
                 d4 acc[JB];
@@ -84,30 +122,41 @@ __global__ __launch_bounds__(256, 2) void em_estep_mfma_kernel(const double* __r
                 for (int J = 0; J < JB; ++J) acc[J] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int ls = 0; ls < LS; ++ls) {
-                    const double z = xb[ls][sb] - mu[ls];
+                    const double z = xb[ls][sb] - r.mu[ls];
 #pragma unroll
                     for (int J = 0; J < JB; ++J) {
                         if (ls < S::slabs_of(J)) {
                             const int c = (J == 0 ? 0 : S::slabs_of(0)) + ls;
-                            acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c], z, acc[J], 0, 0, 0);
+                            acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(r.a[c], z, acc[J], 0, 0, 0);
                         }
                     }
                 }
-                double qs = 0.0;
+                double t = 0.0;
 #pragma unroll
                 for (int J = 0; J < JB; ++J)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) qs = __builtin_fma(acc[J][r], acc[J][r], qs);
-                qs += __shfl_xor(qs, 16, 64);
-                qs += __shfl_xor(qs, 32, 64);
-                q = (g == sb) ? qs : q;        // lane (g, s) keeps sample 16g + s
+                    for (int rr = 0; rr < 4; ++rr) t = __builtin_fma(acc[J][rr], acc[J][rr], t);
+                qs[sb] = t;
             }
-            const double lw = __builtin_fma(-0.5, q, coef);
+            const double q = reduce_scatter_groups(qs[0], qs[1], qs[2], qs[3]);   // lane (g, s) gets sample 16g + s
+            const double lw = __builtin_fma(-0.5, q, r.coef);
             lw_out[(size_t)k * ldr + base + lane] = lw;
             const double e = exp(-fabs(lw - m));
             const bool up = lw > m;
             ssum = up ? __builtin_fma(ssum, e, 1.0) : ssum + e;
             m = up ? lw : m;
+        };
+
+        // Software pipeline over components: the record of component k+1 is in flight while k is computed.
+        Rec<D> r0, r1;
+        load_rec<D>(r0, params, lane, g);
+        for (int k = 0; k < K; k += 2) {
+            if (k + 1 < K) load_rec<D>(r1, params + (size_t)(k + 1) * PS, lane, g);
+            component(r0, k);
+            if (k + 1 < K) {
+                if (k + 2 < K) load_rec<D>(r0, params + (size_t)(k + 2) * PS, lane, g);
+                component(r1, k + 1);
+            }
         }
         const double lse = m + log(ssum);
         lse_out[base + lane] = lse;

@@ -46,8 +46,6 @@ __global__ __launch_bounds__(256, 2) void em_mstats_kernel(
     const int da = d + 1;          // augmented length; slot `da` of every row holds 0 for padding columns
     const int XS = (da + 1) | 1;   // odd row stride (doubles)
     constexpr int RS = RBW * 16 + 1;
-    double* Xs = smem;             // [TS][XS]
-    double* Rs = smem + TS * XS;   // [TS][RS]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rbg = blockIdx.y % n_rbg, cbg = blockIdx.y / n_rbg;
@@ -70,40 +68,78 @@ __global__ __launch_bounds__(256, 2) void em_mstats_kernel(
 #pragma unroll
         for (int c = 0; c < CBW; ++c) acc[r][c] = d4{0.0, 0.0, 0.0, 0.0};
 
-    const uint32_t n_tiles = (n + TS - 1) / TS;
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint32_t i0 = tile * TS;
-        __syncthreads();   // previous tile fully consumed
-        // ---- stage xt tile: Xs[s][j] = x[j][i0+s] - shift[j]; Xs[s][d] = 1; Xs[s][da] = 0
-        for (int e = tid; e < TS * d; e += 256) {
-            const int s = e & (TS - 1), j = e / TS;
-            Xs[s * XS + j] = xt[(size_t)j * ldx + i0 + s] - shift[j];
+    // ---- software pipeline over tiles: the global loads of tile t+1 are in flight during the MFMA phase of tile t;
+    // the LDS tiles are double-buffered so one barrier per tile suffices (a wave can only start overwriting buffer b
+    // after the barrier of the tile in between, which every wave reaches after it finished reading buffer b).
+    // staging role: sample sS, element class qS (256 = 4 * TS). qS is the wave index: readfirstlane makes that
+    // visible to the compiler, so the per-row base addresses live in SGPRs instead of 64-bit VGPR pairs.
+    const int sS = tid & (TS - 1), qS = __builtin_amdgcn_readfirstlane(tid / TS);
+    double xv[kMaxDim / 4], rv[RBW * 4], lv = 0.0;
+    uint32_t lab = 0xffffffffu;
+    bool live = false;
+
+    auto prefetch = [&](uint32_t tile) {
+        const uint32_t i = tile * TS + sS;
+        live = i < n;
+#pragma unroll
+        for (int it = 0; it < kMaxDim / 4; ++it) {
+            const int j = qS + 4 * it;
+            xv[it] = j < d ? xt[(size_t)j * ldx + i] : 0.0;
         }
-        if (tid < TS) {
-            Xs[tid * XS + d] = 1.0;
-            Xs[tid * XS + da] = 0.0;
-        }
-        // ---- stage responsibilities: Rs[s][kk] for the RBW*16 components of this row-block group
-        for (int e = tid; e < TS * RBW * 16; e += 256) {
-            const int s = e & (TS - 1), kk = e / TS;
-            const int k = rb0 * 16 + kk;
-            const uint32_t i = i0 + s;
-            double r = 0.0;
-            if (k < K && i < n) {
-                if (mode == kFromLogResp) r = exp(lw[(size_t)k * ldr + i] - lse[i]);
-                else if (mode == kFromResp) r = lw[(size_t)k * ldr + i];
-                else if (mode == kFromLabels) r = (labels[i] == (uint32_t)k) ? 1.0 : 0.0;
-                else r = 1.0;
+        if (mode == kFromLogResp || mode == kFromResp) {
+#pragma unroll
+            for (int it = 0; it < RBW * 4; ++it) {
+                const int k = rb0 * 16 + qS + 4 * it;
+                rv[it] = (k < K && live) ? lw[(size_t)k * ldr + i] : (mode == kFromLogResp ? -__builtin_inf() : 0.0);
             }
-            Rs[s * RS + kk] = r;
+            if (mode == kFromLogResp) lv = live ? lse[i] : 0.0;
+        } else if (mode == kFromLabels) {
+            lab = live ? labels[i] : 0xffffffffu;
         }
+    };
+    auto stage = [&](double* Xb, double* Rb) {
+        if (mode == kFromLogResp) {
+#pragma unroll
+            for (int it = 0; it < RBW * 4; ++it) {
+                rv[it] = exp(rv[it] - lv);                 // exp(-inf) == 0 for padding
+                __builtin_amdgcn_sched_barrier(0);         // one exp at a time: keeps its temporaries from piling up
+            }
+        } else if (mode == kFromLabels) {
+#pragma unroll
+            for (int it = 0; it < RBW * 4; ++it) rv[it] = (lab == (uint32_t)(rb0 * 16 + qS + 4 * it)) ? 1.0 : 0.0;
+        } else if (mode == kOnes) {
+#pragma unroll
+            for (int it = 0; it < RBW * 4; ++it) rv[it] = (rb0 * 16 + qS + 4 * it < K && live) ? 1.0 : 0.0;
+        }
+#pragma unroll
+        for (int it = 0; it < kMaxDim / 4; ++it) {
+            const int j = qS + 4 * it;
+            if (j < d) Xb[sS * XS + j] = xv[it] - shift[j];
+        }
+        if (qS == 0) {
+            Xb[sS * XS + d] = 1.0;
+            Xb[sS * XS + da] = 0.0;
+        }
+#pragma unroll
+        for (int it = 0; it < RBW * 4; ++it) Rb[sS * RS + qS + 4 * it] = rv[it];
+    };
+
+    const uint32_t n_tiles = (n + TS - 1) / TS;
+    const int tile_doubles = TS * XS + TS * RS;
+    int buf = 0;
+    if (blockIdx.x < n_tiles) prefetch(blockIdx.x);
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
+        double* Xb = smem + buf * tile_doubles;
+        double* Rb = Xb + TS * XS;
+        stage(Xb, Rb);
         __syncthreads();
+        if (tile + gridDim.x < n_tiles) prefetch(tile + gridDim.x);
         // ---- contraction: 16 groups of 4 samples
-#pragma unroll 2
+#pragma unroll 1
         for (int sg = 0; sg < TS / 4; ++sg) {
             const int s = sg * 4 + (lane >> 4);
-            const double* xr = Xs + s * XS;
-            const double* rr = Rs + s * RS + (lane & 15);
+            const double* xr = Xb + s * XS;
+            const double* rr = Rb + s * RS + (lane & 15);
             double av[RBW];
 #pragma unroll
             for (int r = 0; r < RBW; ++r) av[r] = rr[r * 16];
@@ -201,7 +237,7 @@ void launch_t(const MstatsArgs& a, const Plan& p, int grid_x, int KP, int FP, hi
 {
     const int da = a.d + 1;
     const int XS = (da + 1) | 1;
-    const size_t smem = sizeof(double) * ((size_t)TS * XS + (size_t)TS * (RBW * 16 + 1));
+    const size_t smem = 2 * sizeof(double) * ((size_t)TS * XS + (size_t)TS * (RBW * 16 + 1));   // double-buffered
     hipLaunchKernelGGL((em_mstats_kernel<RBW, CBW>), dim3(grid_x, p.n_rbg * p.n_cbg), dim3(256), smem, stream, a.xt, a.ldx,
                        a.n, a.d, a.shift, a.lw, a.ldr, a.lse, a.labels, a.K, a.mode, p.n_rbg, p.CB, a.partials, KP, FP);
 }

@@ -9,32 +9,55 @@
 // are bit-identical to the host point query. The expanded |x|^2 - 2x.c + |c|^2 form is deliberately not
 // used: its cancellation can flip labels of nearly equidistant samples.
 //
-// Update statistics: per-workgroup LDS-privatised sums/counts (ds_add_f64), written out per workgroup
-// and combined in a fixed order by kmeans_reduce_kernel.
+// Update statistics (per-cluster coordinate sums and counts) are accumulated EXACTLY: every coordinate is scaled by a
+// per-dimension power of two (chosen at upload from max|x_j| so that |t| < 2^94), cut into three 32-bit limbs and added
+// with 64-bit INTEGER atomics (ds_add_u64 on workgroup-private LDS accumulators, or global atomics when K*(3d+1)
+// words do not fit). Integer addition is associative, so the sums do not depend on the order in which lanes, waves,
+// workgroups or GPUs contribute: the update step is bitwise reproducible run to run (floating-point atomics are not),
+// which the reference's own test relies on (same seed => same fit => inertia of 3 initialisations <= inertia of the
+// first, Tests/test_KMeans.cpp:75-79). A limb sum cannot overflow: 2^32 samples x 2^32 per limb < 2^64.
 #include "device.hpp"
 
 namespace mlhip {
 namespace {
 
+typedef unsigned long long u64;
+
+/// t (|t| < 2^94, integer part only is kept) -> limbs: t = i2 * 2^64 + u1 * 2^32 + u0 (+ dropped fraction), u0,u1 in [0, 2^32).
+__device__ __forceinline__ void split_limbs(double t, u64& w0, u64& w1, u64& w2)
+{
+    const double h2 = floor(t * 0x1p-64);
+    const double r = __builtin_fma(-h2, 0x1p64, t);         // exact, in [0, 2^64)
+    const double h1 = floor(r * 0x1p-32);
+    const double l = __builtin_fma(-h1, 0x1p32, r);          // exact, in [0, 2^32)
+    w2 = (u64)(long long)(int)h2;                            // |h2| < 2^30
+    w1 = (u64)(unsigned)h1;
+    w0 = (u64)(unsigned)l;                                   // truncates the fraction below one unit
+}
+
 template <int D, bool USE_LDS>
 __global__ __launch_bounds__(256) void kmeans_assign_kernel(
     const double* __restrict__ xt, size_t ldx, uint32_t n, int d, const double* __restrict__ cent, int K,
-    uint32_t* __restrict__ labels, const uint32_t* __restrict__ old_labels, int have_old,
-    double* __restrict__ min_dist, int accumulate, double* __restrict__ partials, size_t pstride)
+    const double* __restrict__ scale, uint32_t* __restrict__ labels, const uint32_t* __restrict__ old_labels,
+    int have_old, double* __restrict__ min_dist, int accumulate, double* __restrict__ partials, size_t pstride)
 {
-    extern __shared__ double acc_lds[];   // [K][d+1] when use_lds
+    extern __shared__ u64 acc_lds[];      // [K][3d+1] when USE_LDS
     __shared__ double red[8];
     const int tid = threadIdx.x;
-    const int W = d + 1;
-    double* my_part = partials + (size_t)blockIdx.x * pstride;   // [inertia, changed, K*(d+1) ...]
+    const int W = 3 * d + 1;
+    double* my_part = partials + (size_t)blockIdx.x * pstride;   // [inertia, changed, K*(3d+1) integer words]
+    u64* my_words = reinterpret_cast<u64*>(my_part + 2);
     if (accumulate) {
         if (USE_LDS) {
-            for (int e = tid; e < K * W; e += 256) acc_lds[e] = 0.0;
+            for (int e = tid; e < K * W; e += 256) acc_lds[e] = 0;
         } else {
-            for (int e = tid; e < K * W; e += 256) my_part[2 + e] = 0.0;
+            for (int e = tid; e < K * W; e += 256) my_words[e] = 0;
         }
         __syncthreads();
     }
+    double sc[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) sc[j] = j < d ? scale[j] : 0.0;
 
     double inertia = 0.0, changed = 0.0;
     for (uint32_t i = blockIdx.x * 256u + tid; i < n; i += gridDim.x * 256u) {
@@ -58,19 +81,18 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(
         inertia += best;
         changed += (!have_old || old_labels[i] != arg) ? 1.0 : 0.0;
         if (accumulate) {
-            if (USE_LDS) {
-                double* row = acc_lds + (size_t)arg * W;
+            u64* row = (USE_LDS ? acc_lds : my_words) + (size_t)arg * W;
 #pragma unroll
-                for (int j = 0; j < D; ++j)
-                    if (j < d) unsafeAtomicAdd(row + j, x[j]);
-                unsafeAtomicAdd(row + d, 1.0);
-            } else {
-                double* row = my_part + 2 + (size_t)arg * W;
-#pragma unroll
-                for (int j = 0; j < D; ++j)
-                    if (j < d) unsafeAtomicAdd(row + j, x[j]);
-                unsafeAtomicAdd(row + d, 1.0);
+            for (int j = 0; j < D; ++j) {
+                if (j < d) {
+                    u64 w0, w1, w2;
+                    split_limbs(x[j] * sc[j], w0, w1, w2);
+                    atomicAdd(row + 3 * j, w0);
+                    atomicAdd(row + 3 * j + 1, w1);
+                    atomicAdd(row + 3 * j + 2, w2);
+                }
             }
+            atomicAdd(row + 3 * d, (u64)1);
         }
     }
     // block sums of inertia / changed (fixed order)
@@ -89,36 +111,61 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(
         my_part[1] = red[4] + red[5] + red[6] + red[7];
     }
     if (accumulate && USE_LDS) {
-        for (int e = tid; e < K * W; e += 256) my_part[2 + e] = acc_lds[e];
+        for (int e = tid; e < K * W; e += 256) my_words[e] = acc_lds[e];
     }
 }
 
-/// out = [inertia, n_changed, counts(K), sums(K*d)] = fixed-order sum of the per-workgroup partials.
+/// out = [inertia, n_changed, counts(K), sums(K*d)]: inertia / changed are fixed-order sums of the per-workgroup
+/// partials; counts and coordinate sums are exact integer sums of the limb words, converted to double once.
 __global__ __launch_bounds__(256) void kmeans_reduce_kernel(const double* __restrict__ partials, int n_blocks, size_t pstride,
-                                                             int K, int d, int accumulate, double* __restrict__ out)
+                                                             int K, int d, int accumulate, const double* __restrict__ scale,
+                                                             double* __restrict__ out)
 {
-    const int W = d + 1;
-    const int total = 2 + (accumulate ? K * W : 0);
+    const int W = 3 * d + 1;
+    const int total = 2 + (accumulate ? K * (d + 1) : 0);
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
-    double s = 0.0;
-    for (int b = 0; b < n_blocks; ++b) s += partials[(size_t)b * pstride + e];
-    if (e < 2) { out[e] = s; return; }
-    const int k = (e - 2) / W, j = (e - 2) - k * W;
-    if (j == d) out[2 + k] = s;                       // count
-    else out[2 + K + (size_t)k * d + j] = s;          // coordinate sum
+    if (e < 2) {
+        double s = 0.0;
+        for (int b = 0; b < n_blocks; ++b) s += partials[(size_t)b * pstride + e];
+        out[e] = s;
+        return;
+    }
+    const int k = (e - 2) / (d + 1), j = (e - 2) - k * (d + 1);
+    const u64* words = reinterpret_cast<const u64*>(partials + 2) + (size_t)k * W;
+    const size_t wstride = pstride;   // doubles and words are both 8 bytes
+    if (j == d) {
+        u64 c = 0;
+        for (int b = 0; b < n_blocks; ++b) c += words[(size_t)b * wstride + 3 * d];
+        out[2 + k] = (double)c;
+    } else {
+        u64 w0 = 0, w1 = 0, w2 = 0;
+        for (int b = 0; b < n_blocks; ++b) {
+            const u64* p = words + (size_t)b * wstride + 3 * j;
+            w0 += p[0];
+            w1 += p[1];
+            w2 += p[2];
+        }
+        // value = (w2 * 2^64 + w1 * 2^32 + w0) / scale; propagate carries so that the top word carries the sign and the
+        // lower words are < 2^32, then combine from the small end (at most ~1.5 ulp from the exact sum, deterministic).
+        w1 += w0 >> 32;  w0 &= 0xffffffffull;
+        const long long top = (long long)w2 + (long long)(w1 >> 32);
+        w1 &= 0xffffffffull;
+        const double v = __builtin_fma((double)top, 0x1p64, __builtin_fma((double)w1, 0x1p32, (double)w0));
+        out[2 + K + (size_t)k * d + j] = v / scale[j];
+    }
 }
 
 template <int D>
 void launch_t(const KmeansArgs& a, int grid, int use_lds, size_t pstride, hipStream_t stream)
 {
-    const size_t smem = use_lds ? sizeof(double) * (size_t)a.K * (a.d + 1) : 0;
+    const size_t smem = use_lds ? sizeof(u64) * (size_t)a.K * (3 * a.d + 1) : 0;
     if (use_lds)
         hipLaunchKernelGGL((kmeans_assign_kernel<D, true>), dim3(grid), dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d,
-                           a.centroids, a.K, a.labels, a.old_labels, a.have_old, a.min_dist, a.accumulate, a.partials, pstride);
+                           a.centroids, a.K, a.scale, a.labels, a.old_labels, a.have_old, a.min_dist, a.accumulate, a.partials, pstride);
     else
         hipLaunchKernelGGL((kmeans_assign_kernel<D, false>), dim3(grid), dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d,
-                           a.centroids, a.K, a.labels, a.old_labels, a.have_old, a.min_dist, a.accumulate, a.partials, pstride);
+                           a.centroids, a.K, a.scale, a.labels, a.old_labels, a.have_old, a.min_dist, a.accumulate, a.partials, pstride);
 }
 
 inline int kmeans_grid(int num_cus) { return num_cus * 4; }
@@ -127,17 +174,17 @@ inline int kmeans_grid(int num_cus) { return num_cus * 4; }
 
 size_t kmeans_scratch_doubles(int d, int K, int num_cus)
 {
-    return (size_t)kmeans_grid(num_cus) * (2 + (size_t)K * (d + 1));
+    return (size_t)kmeans_grid(num_cus) * (2 + (size_t)K * (3 * d + 1));
 }
 
 int launch_kmeans_assign(const KmeansArgs& a, int num_cus, hipStream_t stream)
 {
-    const size_t pstride = 2 + (size_t)a.K * (a.d + 1);
+    const size_t pstride = 2 + (size_t)a.K * (3 * a.d + 1);
     int grid = kmeans_grid(num_cus);
     const uint32_t blocks_needed = (a.n + 255) / 256;
     if ((uint32_t)grid > blocks_needed) grid = (int)(blocks_needed ? blocks_needed : 1);
     if ((size_t)grid * pstride > a.partials_capacity) return -2;
-    const int use_lds = (size_t)a.K * (a.d + 1) * sizeof(double) <= 64 * 1024;
+    const int use_lds = (size_t)a.K * (3 * a.d + 1) * sizeof(u64) <= 64 * 1024;
     switch (a.D) {
     case 1: launch_t<1>(a, grid, use_lds, pstride, stream); break;
     case 2: launch_t<2>(a, grid, use_lds, pstride, stream); break;
@@ -158,10 +205,10 @@ int launch_kmeans_assign(const KmeansArgs& a, int num_cus, hipStream_t stream)
 
 void launch_kmeans_reduce(const KmeansArgs& a, int n_partials, hipStream_t stream)
 {
-    const size_t pstride = 2 + (size_t)a.K * (a.d + 1);
+    const size_t pstride = 2 + (size_t)a.K * (3 * a.d + 1);
     const int total = 2 + (a.accumulate ? a.K * (a.d + 1) : 0);
     hipLaunchKernelGGL(kmeans_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, a.partials, n_partials, pstride,
-                       a.K, a.d, a.accumulate, a.out);
+                       a.K, a.d, a.accumulate, a.scale, a.out);
 }
 
 }  // namespace mlhip

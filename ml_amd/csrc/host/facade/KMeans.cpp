@@ -91,6 +91,12 @@ void KMeans::fetch_assignment(mlhip_data* device_data, std::size_t sample_size)
 {
     mlhip_ctx* ctx = device::context();
     check(mlhip_kmeans_labels(ctx, device_data, labels_.data()));
+    sequential_inertia(device_data, sample_size);
+}
+
+void KMeans::sequential_inertia(mlhip_data* device_data, std::size_t sample_size)
+{
+    mlhip_ctx* ctx = device::context();
     int world = 1;
     check(mlhip_ctx_world(ctx, &world, nullptr));
     if (world == 1 && sample_size <= kSequentialInertiaLimit) {
@@ -217,6 +223,9 @@ bool KMeans::fit_once(ConstMatrixRef data, mlhip_data* device_data)
             }
         }
     }
+    // The multi-initialisation loop compares inertias of different runs with '<' (ML/KMeans.cpp:35): give it the
+    // reference's sequentially accumulated value, not the device's tree sum.
+    sequential_inertia(device_data, sample_size);
     return converged_;
 }
 

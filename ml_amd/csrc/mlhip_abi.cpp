@@ -146,7 +146,7 @@ struct mlhip_data {
     int n_ll = 0;
     bool have_estep = false;
     // K-means workspace
-    DevBuf km_labels[2], km_cent, km_partials, km_out, km_mind;
+    DevBuf km_labels[2], km_cent, km_partials, km_out, km_mind, km_scale;
     PinnedBuf km_host;
     int km_cur = 0;
     bool km_have_old = false;
@@ -154,7 +154,7 @@ struct mlhip_data {
     ~mlhip_data()
     {
         for (DevBuf* b : {&xt, &shift_dev, &lw, &lse, &ll_partials, &params_dev, &partials, &stats_dev, &resp_dev,
-                          &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_partials, &km_out, &km_mind})
+                          &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_partials, &km_out, &km_mind, &km_scale})
             b->release();
         params_host.release(); stats_host.release(); km_host.release();
     }
@@ -355,6 +355,25 @@ void ensure_km_workspace(mlhip_data* dt, int K)
     mlhip_ctx* ctx = dt->ctx;
     for (int b = 0; b < 2; ++b) dt->km_labels[b].reserve(sizeof(uint32_t) * dt->n_pad);
     dt->km_mind.reserve(sizeof(double) * dt->n_pad);
+    if (!dt->km_scale.p) {
+        // Per-dimension power-of-two scale of the exact fixed-point sums: |x_j| * scale_j < 2^94 (device/kmeans.hip).
+        DevBuf scratch, mx;
+        scratch.reserve(sizeof(double) * 1024 * dt->d);
+        mx.reserve(sizeof(double) * dt->d);
+        launch_column_maxabs(dt->xt.as<double>(), dt->ldx, dt->d, dt->n, scratch.as<double>(), mx.as<double>(), ctx->stream);
+        std::vector<double> m(dt->d);
+        HIP_CHECK(hipMemcpyAsync(m.data(), mx.p, sizeof(double) * dt->d, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->sync();
+        scratch.release(); mx.release();
+        for (int j = 0; j < dt->d; ++j) {
+            int e = 0;
+            if (m[j] > 0 && std::isfinite(m[j])) (void)std::frexp(m[j], &e);   // m < 2^e
+            m[j] = std::ldexp(1.0, 94 - e);
+        }
+        dt->km_scale.reserve(sizeof(double) * dt->d);
+        HIP_CHECK(hipMemcpyAsync(dt->km_scale.p, m.data(), sizeof(double) * dt->d, hipMemcpyHostToDevice, ctx->stream));
+        ctx->sync();
+    }
     dt->km_cent.reserve(sizeof(double) * (size_t)K * dt->D);
     dt->km_partials.reserve(sizeof(double) * kmeans_scratch_doubles(dt->d, K, ctx->num_cus));
     const size_t ob = sizeof(double) * (2 + (size_t)K * (dt->d + 1));
@@ -377,6 +396,7 @@ void run_kmeans(mlhip_data* dt, int K, const double* centroids, bool accumulate)
     KmeansArgs a{};
     a.xt = dt->xt.as<double>(); a.ldx = dt->ldx; a.n = dt->n; a.D = dt->D; a.d = dt->d;
     a.centroids = dt->km_cent.as<double>(); a.K = K;
+    a.scale = dt->km_scale.as<double>();
     a.labels = dt->km_labels[nxt].as<uint32_t>();
     a.old_labels = dt->km_labels[dt->km_cur].as<uint32_t>();
     a.have_old = dt->km_have_old ? 1 : 0;

@@ -98,12 +98,14 @@ void add_a_xxT(const double* x, std::size_t n, Mat& dest, const double a)
 // =================================================================================================
 
 // (x - c).squaredNorm() as used at ML/Clustering.cpp:47,78,81 and ML/KMeans.cpp:158. [eigen-order]
+// The reference's release build (-march=native, SConstruct:20) fuses the multiply-add; std::fma pins that choice
+// here independently of the compiler's contraction setting.
 static double squared_distance(const double* x, const double* c, std::size_t d)
 {
     double s = 0;
     for (std::size_t j = 0; j < d; ++j) {
         const double t = x[j] - c[j];
-        s += t * t;
+        s = std::fma(t, t, s);
     }
     return s;
 }

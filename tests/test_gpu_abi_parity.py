@@ -133,6 +133,31 @@ def test_kmeans_step_matches_golden(ctx, oracle, case):
     dt.close()
 
 
+def test_kmeans_update_is_bitwise_reproducible_and_exact(ctx):
+    """The update sums are exact fixed-point integer sums: bit-identical run to run, and equal to the correctly rounded
+    exact sum (math.fsum) up to the final conversion."""
+    import math
+    rng = np.random.default_rng(12)
+    n, d, K = 50_000, 5, 7
+    X = np.ascontiguousarray(rng.standard_normal((n, d)) * np.array([1e-3, 1.0, 50.0, 1e4, 3.0]) + np.array([0, 5, -7, 1e5, 0.1]))
+    C0 = X[rng.choice(n, K, replace=False)]
+    runs = []
+    for _ in range(3):
+        dt = _data(ctx, X)
+        runs.append(dt.kmeans_step(C0))
+        labels = dt.kmeans_labels()
+        dt.close()
+    for r in runs[1:]:
+        assert r[0] == runs[0][0] and np.array_equal(r[2], runs[0][2]) and np.array_equal(r[3], runs[0][3])
+    _, _, counts, C1 = runs[0]
+    for k in range(K):
+        sel = X[labels == k]
+        assert counts[k] == sel.shape[0]
+        for j in range(d):
+            exact = math.fsum(sel[:, j]) / sel.shape[0]
+            assert abs(C1[k, j] - exact) <= 4e-16 * abs(exact)
+
+
 def test_kmeans_empty_cluster_goes_to_origin(ctx):
     rng = np.random.default_rng(5)
     X = rng.standard_normal((1000, 3))
