@@ -12,6 +12,31 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
         "(or `make -C ml_amd/csrc`). ml_amd has no CPU fallback.")
 
+
+
+def _preload_shared_hip_runtime():
+    """A process must run ONE HIP runtime. PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 with the
+    same sonames as /opt/rocm's, and the dynamic loader keeps whichever copy is loaded first: if this library pulled in
+    the system copy first, a later `import torch` would bind to a runtime it was not built against and report no GPU.
+    So when a torch installation is present (it is only ever used for torch.distributed collectives), load its
+    runtime libraries first -- without importing torch. MLHIP_HIP_RUNTIME=system opts out."""
+    if os.environ.get("MLHIP_HIP_RUNTIME", "").lower() == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            path = os.path.join(libdir, name)
+            if os.path.exists(path):
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass   # fall back to the system runtime named in libmlhip.so's DT_NEEDED
+
+
+_preload_shared_hip_runtime()
 lib = C.CDLL(LIB_PATH)
 
 OK, E_INVALID_ARGUMENT, E_DOMAIN, E_RUNTIME, E_NO_DEVICE, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
