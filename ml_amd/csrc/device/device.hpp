@@ -34,18 +34,18 @@ int launch_em_estep_mfma(const EstepArgs& a, int num_cus, hipStream_t stream);
 
 enum MstatsMode : int {
     kFromLogResp = 0,   // r = exp(lw - lse)          (after an E-step)
-    kFromResp = 1,      // r = lw                     (caller-given responsibilities)
-    kFromLabels = 2,    // r = (labels[i] == k)
-    kOnes = 3           // r = 1 (K = 1)              (sample covariance)
+    kFromResp = 1       // r = lw                     (plain responsibilities: caller-given, one-hot, or all ones)
 };
 struct MstatsArgs {
     const double* xt; size_t ldx; uint32_t n; int d;        // d = true dimension
     const double* shift;                                     // device, d doubles
-    const double* lw; size_t ldr; const double* lse; const uint32_t* labels; int K; int mode;
+    const double* lw; size_t ldr; const double* lse; int K; int mode;   // lw: [K][ldr], ldr >= n_pad
     double* partials; size_t partials_capacity;              // scratch (doubles)
     const double* ll_partials; int n_ll_partials;            // summed into stats[K*F] (may be null/0)
     double* stats;                                           // out: device, K*F + 1 doubles
 };
+/// resp[k*ldr + i] = (labels[i] == k), or 1 everywhere when labels == nullptr; columns n..n_pad-1 are zeroed.
+void launch_fill_responsibilities(const uint32_t* labels, uint32_t n, int K, double* resp, size_t ldr, hipStream_t stream);
 /// Doubles of scratch the statistics kernel needs for (d, K).
 size_t em_mstats_scratch_doubles(int d, int K, int num_cus);
 /// Main statistics kernel; returns the number of per-workgroup partials written (>0) or <0 on error.

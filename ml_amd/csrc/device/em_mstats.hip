@@ -17,34 +17,25 @@
 // column-block) tile space when it does not fit one workgroup's registers. A wave holds RBW x CBW
 // 16x16 accumulators (8 VGPRs each). Per-workgroup partial sums go to scratch and are combined in a
 // fixed order by em_reduce_kernel (no atomics: bitwise reproducible).
-#include "device.hpp"
+#include <cstdlib>
+
+#include "em_mstats_common.hpp"
 
 namespace mlhip {
 namespace {
 
-typedef double d4 __attribute__((ext_vector_type(4)));
+using namespace mstats;
 
-constexpr int TS = 64;   // samples per LDS tile
-
-__device__ __forceinline__ void feature_pair(int col, int F, int da, int& a, int& b)
-{
-    if (col >= F) { a = b = da; return; }   // padding column -> zero slot
-    int r = (int)((__builtin_sqrt(8.0 * col + 1.0) - 1.0) * 0.5);
-    while ((r + 1) * (r + 2) / 2 <= col) ++r;
-    while (r * (r + 1) / 2 > col) --r;
-    a = r;
-    b = col - r * (r + 1) / 2;
-}
-
-template <int RBW, int CBW>
+/// EXP = true : r = exp(lw - lse)   (log-responsibilities left by an E-step)
+/// EXP = false: r = lw               (plain responsibilities: caller-given, one-hot from labels, or all ones)
+template <int RBW, int CBW, bool EXP>
 __global__ __launch_bounds__(256, 2) void em_mstats_kernel(
-    const double* __restrict__ xt, size_t ldx, uint32_t n, int d, const double* __restrict__ shift,
-    const double* __restrict__ lw, size_t ldr, const double* __restrict__ lse, const uint32_t* __restrict__ labels,
-    int K, int mode, int n_rbg, int CB_total, double* __restrict__ partials, int KP, int FP)
+    const double* __restrict__ xt, size_t ldx, uint32_t n, int d, int D, const double* __restrict__ shift,
+    const double* __restrict__ lw, size_t ldr, const double* __restrict__ lse, int K, int n_rbg, int CB_total,
+    double* __restrict__ partials, int KP, int FP)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int da = d + 1;          // augmented length; slot `da` of every row holds 0 for padding columns
-    const int XS = (da + 1) | 1;   // odd row stride (doubles)
     constexpr int RS = RBW * 16 + 1;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -71,57 +62,41 @@ __global__ __launch_bounds__(256, 2) void em_mstats_kernel(
     // ---- software pipeline over tiles: the global loads of tile t+1 are in flight during the MFMA phase of tile t;
     // the LDS tiles are double-buffered so one barrier per tile suffices (a wave can only start overwriting buffer b
     // after the barrier of the tile in between, which every wave reaches after it finished reading buffer b).
-    // staging role: sample sS, element class qS (256 = 4 * TS). qS is the wave index: readfirstlane makes that
-    // visible to the compiler, so the per-row base addresses live in SGPRs instead of 64-bit VGPR pairs.
+    // Staging role of a thread: sample sS of the tile, element class qS = its wave index (256 = 4 * TS). All loads are
+    // unconditional (row indices clamped into the allocation, the value is discarded when staged) so that they are
+    // issued back to back and nothing waits for them before the MFMA loop.
     const int sS = tid & (TS - 1), qS = __builtin_amdgcn_readfirstlane(tid / TS);
     double xv[kMaxDim / 4], rv[RBW * 4], lv = 0.0;
-    uint32_t lab = 0xffffffffu;
-    bool live = false;
 
     auto prefetch = [&](uint32_t tile) {
-        const uint32_t i = tile * TS + sS;
-        live = i < n;
+        const uint32_t i = tile * TS + sS;           // < n_pad: always inside the allocation
 #pragma unroll
-        for (int it = 0; it < kMaxDim / 4; ++it) {
-            const int j = qS + 4 * it;
-            xv[it] = j < d ? xt[(size_t)j * ldx + i] : 0.0;
-        }
-        if (mode == kFromLogResp || mode == kFromResp) {
+        for (int it = 0; it < kMaxDim / 4; ++it) xv[it] = xt[(size_t)min(qS + 4 * it, D - 1) * ldx + i];
 #pragma unroll
-            for (int it = 0; it < RBW * 4; ++it) {
-                const int k = rb0 * 16 + qS + 4 * it;
-                rv[it] = (k < K && live) ? lw[(size_t)k * ldr + i] : (mode == kFromLogResp ? -__builtin_inf() : 0.0);
-            }
-            if (mode == kFromLogResp) lv = live ? lse[i] : 0.0;
-        } else if (mode == kFromLabels) {
-            lab = live ? labels[i] : 0xffffffffu;
-        }
+        for (int it = 0; it < RBW * 4; ++it) rv[it] = lw[(size_t)min(rb0 * 16 + qS + 4 * it, K - 1) * ldr + i];
+        if (EXP) lv = lse[i];
     };
-    auto stage = [&](double* Xb, double* Rb) {
-        if (mode == kFromLogResp) {
+    auto stage = [&](double* Xb, double* Rb, uint32_t tile) {
+        const bool live = tile * TS + sS < n;
 #pragma unroll
-            for (int it = 0; it < RBW * 4; ++it) {
-                rv[it] = exp(rv[it] - lv);                 // exp(-inf) == 0 for padding
-                __builtin_amdgcn_sched_barrier(0);         // one exp at a time: keeps its temporaries from piling up
+        for (int it = 0; it < RBW * 4; ++it) {
+            double r = rv[it];
+            if (EXP) {
+                r = exp(r - lv);
+                __builtin_amdgcn_sched_barrier(0);     // one exp at a time: keeps its temporaries from piling up
             }
-        } else if (mode == kFromLabels) {
-#pragma unroll
-            for (int it = 0; it < RBW * 4; ++it) rv[it] = (lab == (uint32_t)(rb0 * 16 + qS + 4 * it)) ? 1.0 : 0.0;
-        } else if (mode == kOnes) {
-#pragma unroll
-            for (int it = 0; it < RBW * 4; ++it) rv[it] = (rb0 * 16 + qS + 4 * it < K && live) ? 1.0 : 0.0;
+            const bool valid = live && (rb0 * 16 + qS + 4 * it < K);
+            Rb[sS * RS + qS + 4 * it] = valid ? r : 0.0;
         }
 #pragma unroll
         for (int it = 0; it < kMaxDim / 4; ++it) {
             const int j = qS + 4 * it;
-            if (j < d) Xb[sS * XS + j] = xv[it] - shift[j];
+            if (j < d) Xb[sS * XS + j] = xv[it] - shift[j];   // wave-uniform index: scalar load
         }
         if (qS == 0) {
             Xb[sS * XS + d] = 1.0;
             Xb[sS * XS + da] = 0.0;
         }
-#pragma unroll
-        for (int it = 0; it < RBW * 4; ++it) Rb[sS * RS + qS + 4 * it] = rv[it];
     };
 
     const uint32_t n_tiles = (n + TS - 1) / TS;
@@ -131,15 +106,19 @@ __global__ __launch_bounds__(256, 2) void em_mstats_kernel(
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
         double* Xb = smem + buf * tile_doubles;
         double* Rb = Xb + TS * XS;
-        stage(Xb, Rb);
+        stage(Xb, Rb, tile);
         __syncthreads();
-        if (tile + gridDim.x < n_tiles) prefetch(tile + gridDim.x);
-        // ---- contraction: 16 groups of 4 samples
+        const uint32_t next = tile + gridDim.x;
+        prefetch(next < n_tiles ? next : tile);      // the last iteration re-reads its own tile (discarded)
+        // ---- contraction: 16 groups of 4 samples. Lane group g = lane>>4 takes sample sg + 16 g: rows 16 apart are
+        // 32 banks apart for both tiles (odd strides 35 / 33 doubles), so the two rows of a half-wave never collide.
+        // Not unrolled: the accumulators leave too few registers for a second set of operands (unrolling spills).
+        const double* xbase = Xb + 16 * (lane >> 4) * XS;
+        const double* rbase = Rb + 16 * (lane >> 4) * RS + (lane & 15);
 #pragma unroll 1
         for (int sg = 0; sg < TS / 4; ++sg) {
-            const int s = sg * 4 + (lane >> 4);
-            const double* xr = Xb + s * XS;
-            const double* rr = Rb + s * RS + (lane & 15);
+            const double* xr = xbase + sg * XS;
+            const double* rr = rbase + sg * RS;
             double av[RBW];
 #pragma unroll
             for (int r = 0; r < RBW; ++r) av[r] = rr[r * 16];
@@ -168,6 +147,16 @@ __global__ __launch_bounds__(256, 2) void em_mstats_kernel(
                 }
             }
         }
+}
+
+/// resp[k*ldr + i] = (labels[i] == k) for i < n (one-hot responsibilities, ML/Clustering.cpp:88), or 1 if labels == null.
+__global__ __launch_bounds__(256) void fill_resp_kernel(const uint32_t* __restrict__ labels, uint32_t n_pad, uint32_t n, int K,
+                                                         double* __restrict__ resp, size_t ldr)
+{
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_pad; i += gridDim.x * 256u) {
+        const uint32_t lab = (labels && i < n) ? labels[i] : 0xffffffffu;
+        for (int k = 0; k < K; ++k) resp[(size_t)k * ldr + i] = (i < n && (!labels || lab == (uint32_t)k)) ? 1.0 : 0.0;
+    }
 }
 
 /// stats[k*F + f] = sum_b partials[b][k][f]  (b ascending: deterministic), stats[K*F] = sum of ll partials.
@@ -200,84 +189,98 @@ __global__ __launch_bounds__(256) void em_reduce_kernel(const double* __restrict
     }
 }
 
-struct Plan {
-    int RBW, CBW;       // per-wave register blocking
-    int RB, CB;         // total 16-blocks
-    int n_rbg, n_cbg;   // grid.y decomposition
-    int grid_x;
-};
-
-Plan make_plan(int d, int K, int num_cus)
-{
-    Plan p;
-    const int F = stats_count(d);
-    p.RB = (K + 15) / 16;
-    p.CB = (F + 15) / 16;
-    const int cb_per_wave = (p.CB + 3) / 4;
-    // Prefer covering all column blocks in one group (no re-staging of X), then as many row blocks as fit.
-    p.RBW = p.RB >= 4 && cb_per_wave <= 3 ? 4 : (p.RB >= 2 ? 2 : 1);
-    // accumulators per wave limited to 18 tiles (144 registers) so that two workgroups share a CU
-    int cbw_max = 18 / p.RBW;
-    if (cbw_max > 9) cbw_max = 9;
-    static const int choices[] = {1, 2, 3, 5, 9};
-    p.CBW = 9;
-    for (int c : choices)
-        if (c >= cb_per_wave || c == 9) { p.CBW = c; break; }
-    if (p.CBW > cbw_max) p.CBW = cbw_max >= 9 ? 9 : (cbw_max >= 5 ? 5 : (cbw_max >= 3 ? 3 : (cbw_max >= 2 ? 2 : 1)));
-    p.n_rbg = (p.RB + p.RBW - 1) / p.RBW;
-    p.n_cbg = (p.CB + 4 * p.CBW - 1) / (4 * p.CBW);
-    int gx = 2 * num_cus / (p.n_rbg * p.n_cbg);   // two workgroups per CU
-    if (gx < 1) gx = 1;
-    p.grid_x = gx;
-    return p;
-}
-
 template <int RBW, int CBW>
-void launch_t(const MstatsArgs& a, const Plan& p, int grid_x, int KP, int FP, hipStream_t stream)
+void launch_t(const MstatsArgs& a, const Plan& p, int grid_x, hipStream_t stream)
 {
-    const int da = a.d + 1;
-    const int XS = (da + 1) | 1;
     const size_t smem = 2 * sizeof(double) * ((size_t)TS * XS + (size_t)TS * (RBW * 16 + 1));   // double-buffered
-    hipLaunchKernelGGL((em_mstats_kernel<RBW, CBW>), dim3(grid_x, p.n_rbg * p.n_cbg), dim3(256), smem, stream, a.xt, a.ldx,
-                       a.n, a.d, a.shift, a.lw, a.ldr, a.lse, a.labels, a.K, a.mode, p.n_rbg, p.CB, a.partials, KP, FP);
+    const dim3 grid(grid_x, p.n_rbg * p.n_cbg);
+    if (a.mode == kFromLogResp)
+        hipLaunchKernelGGL((em_mstats_kernel<RBW, CBW, true>), grid, dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d,
+                           padded_dim(a.d), a.shift, a.lw, a.ldr, a.lse, a.K, p.n_rbg, p.CB, a.partials, p.KP, p.FP);
+    else
+        hipLaunchKernelGGL((em_mstats_kernel<RBW, CBW, false>), grid, dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d,
+                           padded_dim(a.d), a.shift, a.lw, a.ldr, a.lse, a.K, p.n_rbg, p.CB, a.partials, p.KP, p.FP);
 }
 
 }  // namespace
 
+namespace mstats {
+
+Plan make_plan(int d, int K, int num_cus)
+{
+    Plan p{};
+    const int F = stats_count(d);
+    p.RB = (K + 15) / 16;
+    p.CB = (F + 15) / 16;
+    static const bool force_narrow = [] { const char* e = std::getenv("MLHIP_MSTATS"); return e && e[0] == 'n'; }();
+    p.wide = p.CB >= 5 && !force_narrow;
+    if (p.wide) {
+        // One 512-thread workgroup per CU; its 8 waves take the column blocks round-robin (wave w: w, w+8, ...), every
+        // wave holds all (<= 4) row blocks of the group: RBW x CBW <= 20 accumulator tiles.
+        p.RBW = p.RB >= 4 ? 4 : (p.RB >= 2 ? 2 : 1);
+        p.CBW = (p.CB + 7) / 8;
+        if (p.CBW > 5) p.CBW = 5;
+        p.n_rbg = (p.RB + p.RBW - 1) / p.RBW;
+        p.n_cbg = (p.CB + 8 * p.CBW - 1) / (8 * p.CBW);
+        p.KP = p.n_rbg * p.RBW * 16;
+        p.FP = p.n_cbg * 8 * p.CBW * 16;
+        p.grid_x = num_cus / (p.n_rbg * p.n_cbg);
+    } else {
+        // Few column blocks (small d): 256-thread workgroups, 4 waves split the column blocks, two workgroups per CU.
+        const int cb_per_wave = (p.CB + 3) / 4;
+        p.RBW = p.RB >= 4 ? 4 : (p.RB >= 2 ? 2 : 1);
+        p.CBW = cb_per_wave >= 2 ? 2 : 1;
+        p.n_rbg = (p.RB + p.RBW - 1) / p.RBW;
+        p.n_cbg = (p.CB + 4 * p.CBW - 1) / (4 * p.CBW);
+        p.KP = p.n_rbg * p.RBW * 16;
+        p.FP = p.n_cbg * 4 * p.CBW * 16;
+        p.grid_x = 2 * num_cus / (p.n_rbg * p.n_cbg);
+    }
+    if (p.grid_x < 1) p.grid_x = 1;
+    return p;
+}
+
+}  // namespace mstats
+
 size_t em_mstats_scratch_doubles(int d, int K, int num_cus)
 {
     const Plan p = make_plan(d, K, num_cus);
-    const size_t KP = (size_t)p.n_rbg * p.RBW * 16, FP = (size_t)p.n_cbg * 4 * p.CBW * 16;
-    return (size_t)p.grid_x * KP * FP;
+    return (size_t)p.grid_x * p.KP * p.FP;
 }
 
 int launch_em_mstats(const MstatsArgs& a, int num_cus, hipStream_t stream)
 {
     const Plan p = make_plan(a.d, a.K, num_cus);
-    const int KP = p.n_rbg * p.RBW * 16, FP = p.n_cbg * 4 * p.CBW * 16;
     const uint32_t n_tiles = (a.n + TS - 1) / TS;
     int grid_x = p.grid_x;
     if ((uint32_t)grid_x > n_tiles) grid_x = (int)(n_tiles ? n_tiles : 1);
-    if ((size_t)grid_x * KP * FP > a.partials_capacity) return -2;
+    if ((size_t)grid_x * p.KP * p.FP > a.partials_capacity) return -2;
+    if (p.wide) return launch_wide(a, p, grid_x, stream);
 
 #define MLHIP_CASE(R, C) \
-    if (p.RBW == R && p.CBW == C) { launch_t<R, C>(a, p, grid_x, KP, FP, stream); } else
-    MLHIP_CASE(1, 1) MLHIP_CASE(1, 2) MLHIP_CASE(1, 3) MLHIP_CASE(1, 5) MLHIP_CASE(1, 9)
-    MLHIP_CASE(2, 1) MLHIP_CASE(2, 2) MLHIP_CASE(2, 3) MLHIP_CASE(2, 5) MLHIP_CASE(2, 9)
-    MLHIP_CASE(4, 1) MLHIP_CASE(4, 2) MLHIP_CASE(4, 3)
+    if (p.RBW == R && p.CBW == C) { launch_t<R, C>(a, p, grid_x, stream); } else
+    MLHIP_CASE(1, 1) MLHIP_CASE(1, 2) MLHIP_CASE(2, 1) MLHIP_CASE(2, 2) MLHIP_CASE(4, 1) MLHIP_CASE(4, 2)
     { return -1; }
 #undef MLHIP_CASE
     return grid_x;
 }
 
+void launch_fill_responsibilities(const uint32_t* labels, uint32_t n, int K, double* resp, size_t ldr, hipStream_t stream)
+{
+    const uint32_t n_pad = (n + kSampleTile - 1) / kSampleTile * kSampleTile;
+    uint32_t blocks = n_pad / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(fill_resp_kernel, dim3(blocks), dim3(256), 0, stream, labels, n_pad ? n_pad : kSampleTile, n, K, resp, ldr);
+}
+
 void launch_em_reduce(const MstatsArgs& a, int num_cus, int grid_x, hipStream_t stream)
 {
     const Plan p = make_plan(a.d, a.K, num_cus);
-    const int KP = p.n_rbg * p.RBW * 16, FP = p.n_cbg * 4 * p.CBW * 16;
     const int F = stats_count(a.d);
     const int total = a.K * F;
     const int red_blocks = (total + 255) / 256 + 1;
-    hipLaunchKernelGGL(em_reduce_kernel, dim3(red_blocks), dim3(256), 0, stream, a.partials, grid_x, KP, FP, a.K, F,
+    hipLaunchKernelGGL(em_reduce_kernel, dim3(red_blocks), dim3(256), 0, stream, a.partials, grid_x, p.KP, p.FP, a.K, F,
                        a.ll_partials, a.n_ll_partials, a.stats);
 }
 

@@ -1,0 +1,168 @@
+// M-step sufficient statistics, wide variant (>= 5 column blocks, i.e. d >= 8): see em_mstats.hip for the formulation
+// (one fp64-MFMA GEMM stats[K x F] = R^T Phi with Phi generated in registers). This file holds the decomposition used
+// for the headline shapes:
+//
+//   * one 512-thread workgroup per CU; the 64-sample tile (x~ rows and responsibilities of up to 64 components) is staged
+//     ONCE per CU; the exp(lw - lse) normalisation is applied while staging, once per (sample, component);
+//   * wave w takes column blocks w, w+8, w+16, ... (round-robin: at d = 32 waves 0-3 hold 5, waves 4-7 hold 4 of the 36
+//     blocks, and the two waves sharing a SIMD -- w and w+4 -- together always hold 9) and ALL row blocks of the group:
+//     RBW x CBW <= 4 x 5 accumulator tiles, so every generated B operand (one multiply, two LDS reads) feeds 4 MFMAs;
+//   * software pipeline over tiles: global loads of tile t+1 are issued (unconditionally, clamped addresses) right after
+//     the barrier and stay in flight during the MFMA phase of tile t; LDS tiles are double-buffered -> one barrier per
+//     tile.
+#include "em_mstats_common.hpp"
+
+namespace mlhip {
+namespace mstats {
+namespace {
+
+constexpr int NW = 8;   // waves per workgroup
+
+template <int RBW, int CBW, bool EXP>
+__global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
+    const double* __restrict__ xt, size_t ldx, uint32_t n, int d, int D, const double* __restrict__ shift,
+    const double* __restrict__ lw, size_t ldr, const double* __restrict__ lse, int K, int n_rbg, int CB_total,
+    double* __restrict__ partials, int KP, int FP)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int RS = RBW * 16 + 1;     // odd row stride of the responsibility tile
+    constexpr int NXV = kMaxDim / NW;    // x rows staged per thread (4)
+    constexpr int NRV = RBW * 16 / NW;   // responsibility rows staged per thread (2 * RBW)
+    const int da = d + 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rbg = blockIdx.y % n_rbg, cbg = blockIdx.y / n_rbg;
+    const int rb0 = rbg * RBW;
+    const int F = da * (da + 1) / 2;
+
+    // column block c of this wave: cbg*8*CBW + c*8 + wave
+    int offa[CBW], offb[CBW];
+#pragma unroll
+    for (int c = 0; c < CBW; ++c) {
+        const int cb = (cbg * CBW + c) * NW + wave;
+        int a, b;
+        feature_pair(cb * 16 + (lane & 15), cb < CB_total ? F : 0, da, a, b);
+        offa[c] = a;
+        offb[c] = b;
+    }
+    bool active[CBW];
+#pragma unroll
+    for (int c = 0; c < CBW; ++c) active[c] = (cbg * CBW + c) * NW + wave < CB_total;   // wave-uniform
+
+    d4 acc[RBW][CBW];
+#pragma unroll
+    for (int r = 0; r < RBW; ++r)
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) acc[r][c] = d4{0.0, 0.0, 0.0, 0.0};
+
+    // staging role: sample sS of the tile, rows wave, wave+8, ...
+    const int sS = lane;
+    double xv[NXV], rv[NRV], lv = 0.0;
+    auto prefetch = [&](uint32_t tile) {
+        const uint32_t i = tile * TS + sS;           // < n_pad: always inside the allocation
+#pragma unroll
+        for (int it = 0; it < NXV; ++it) xv[it] = xt[(size_t)min(wave + NW * it, D - 1) * ldx + i];
+#pragma unroll
+        for (int it = 0; it < NRV; ++it) rv[it] = lw[(size_t)min(rb0 * 16 + wave + NW * it, K - 1) * ldr + i];
+        if (EXP) lv = lse[i];
+    };
+    auto stage = [&](double* Xb, double* Rb, uint32_t tile) {
+        const bool live = tile * TS + sS < n;
+#pragma unroll
+        for (int it = 0; it < NRV; ++it) {
+            double r = rv[it];
+            if (EXP) r = exp(r - lv);
+            const bool valid = live && (rb0 * 16 + wave + NW * it < K);
+            Rb[sS * RS + wave + NW * it] = valid ? r : 0.0;
+        }
+#pragma unroll
+        for (int it = 0; it < NXV; ++it) {
+            const int j = wave + NW * it;
+            if (j < d) Xb[sS * XS + j] = xv[it] - shift[j];   // wave-uniform index: scalar load
+        }
+        if (wave == 0) {
+            Xb[sS * XS + d] = 1.0;
+            Xb[sS * XS + da] = 0.0;
+        }
+    };
+
+    const uint32_t n_tiles = (n + TS - 1) / TS;
+    constexpr int tile_doubles = TS * XS + TS * RS;
+    int buf = 0;
+    if (blockIdx.x < n_tiles) prefetch(blockIdx.x);
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
+        double* Xb = smem + buf * tile_doubles;
+        double* Rb = Xb + TS * XS;
+        stage(Xb, Rb, tile);
+        __syncthreads();
+        const uint32_t next = tile + gridDim.x;
+        prefetch(next < n_tiles ? next : tile);      // the last iteration re-reads its own tile (discarded)
+        // ---- contraction: 16 groups of 4 samples. Lane group g = lane>>4 takes sample sg + 16 g: rows 16 apart are
+        // 32 banks apart for both tiles (odd strides), so the two rows of a half-wave never collide.
+        const double* xbase = Xb + 16 * (lane >> 4) * XS;
+        const double* rbase = Rb + 16 * (lane >> 4) * RS + (lane & 15);
+#pragma unroll 2
+        for (int sg = 0; sg < TS / 4; ++sg) {
+            const double* xr = xbase + sg * XS;
+            const double* rr = rbase + sg * RS;
+            double av[RBW];
+#pragma unroll
+            for (int r = 0; r < RBW; ++r) av[r] = rr[r * 16];
+#pragma unroll
+            for (int c = 0; c < CBW; ++c) {
+                if (active[c]) {
+                    const double bv = xr[offa[c]] * xr[offb[c]];
+#pragma unroll
+                    for (int r = 0; r < RBW; ++r)
+                        acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], bv, acc[r][c], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: partials[blockIdx.x][k][f]; C/D layout of v_mfma_f64_16x16x4: col = lane&15, row = (lane>>4) + 4*reg
+    double* out = partials + (size_t)blockIdx.x * KP * FP;
+#pragma unroll
+    for (int r = 0; r < RBW; ++r)
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) {
+            const int cb = (cbg * CBW + c) * NW + wave;
+            if (cb < CB_total) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int k = (rb0 + r) * 16 + (lane >> 4) + 4 * g;
+                    out[(size_t)k * FP + cb * 16 + (lane & 15)] = acc[r][c][g];
+                }
+            }
+        }
+}
+
+template <int RBW, int CBW>
+void launch_t(const MstatsArgs& a, const Plan& p, int grid_x, hipStream_t stream)
+{
+    const size_t smem = 2 * sizeof(double) * ((size_t)TS * XS + (size_t)TS * (RBW * 16 + 1));   // double-buffered
+    const dim3 grid(grid_x, p.n_rbg * p.n_cbg);
+    if (a.mode == kFromLogResp)
+        hipLaunchKernelGGL((em_mstats_wide_kernel<RBW, CBW, true>), grid, dim3(512), smem, stream, a.xt, a.ldx, a.n, a.d,
+                           padded_dim(a.d), a.shift, a.lw, a.ldr, a.lse, a.K, p.n_rbg, p.CB, a.partials, p.KP, p.FP);
+    else
+        hipLaunchKernelGGL((em_mstats_wide_kernel<RBW, CBW, false>), grid, dim3(512), smem, stream, a.xt, a.ldx, a.n, a.d,
+                           padded_dim(a.d), a.shift, a.lw, a.ldr, a.lse, a.K, p.n_rbg, p.CB, a.partials, p.KP, p.FP);
+}
+
+}  // namespace
+
+int launch_wide(const MstatsArgs& a, const Plan& p, int grid_x, hipStream_t stream)
+{
+#define MLHIP_CASE(R, C) \
+    if (p.RBW == R && p.CBW == C) { launch_t<R, C>(a, p, grid_x, stream); } else
+    MLHIP_CASE(1, 1) MLHIP_CASE(1, 2) MLHIP_CASE(1, 3) MLHIP_CASE(1, 4) MLHIP_CASE(1, 5)
+    MLHIP_CASE(2, 1) MLHIP_CASE(2, 2) MLHIP_CASE(2, 3) MLHIP_CASE(2, 4) MLHIP_CASE(2, 5)
+    MLHIP_CASE(4, 1) MLHIP_CASE(4, 2) MLHIP_CASE(4, 3) MLHIP_CASE(4, 4) MLHIP_CASE(4, 5)
+    { return -1; }
+#undef MLHIP_CASE
+    return grid_x;
+}
+
+}  // namespace mstats
+}  // namespace mlhip

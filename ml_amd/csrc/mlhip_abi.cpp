@@ -293,9 +293,9 @@ void run_estep(mlhip_data* dt, int K, const double* mixing, const double* means,
     dt->have_estep = true;
 }
 
-/// Runs the statistics kernel in `mode`, all-reduces, leaves [K*F stats, ll_sum] in stats_host.
-void run_mstats(mlhip_data* dt, int K, int mode, const double* resp_dev, size_t ld_resp, const uint32_t* labels_dev,
-                bool with_ll)
+/// Runs the statistics kernel on log-responsibilities (mode kFromLogResp: the E-step's lw/lse) or on plain
+/// responsibilities `resp_dev` ([K][ld_resp], ld_resp >= n_pad), all-reduces, leaves [K*F stats, ll_sum] in stats_host.
+void run_mstats(mlhip_data* dt, int K, int mode, const double* resp_dev, size_t ld_resp, bool with_ll)
 {
     mlhip_ctx* ctx = dt->ctx;
     ensure_em_workspace(dt, K);
@@ -305,7 +305,6 @@ void run_mstats(mlhip_data* dt, int K, int mode, const double* resp_dev, size_t 
     a.lw = (mode == kFromResp) ? resp_dev : dt->lw.as<double>();
     a.ldr = (mode == kFromResp) ? ld_resp : dt->ldr;
     a.lse = dt->lse.as<double>();
-    a.labels = labels_dev;
     a.K = K; a.mode = mode;
     a.partials = dt->partials.as<double>(); a.partials_capacity = dt->partials.bytes / sizeof(double);
     a.ll_partials = with_ll ? dt->ll_partials.as<double>() : nullptr;
@@ -587,7 +586,7 @@ int mlhip_em_maximisation(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, double* 
         check_em_args(ctx, data, K);
         require(mixing_out && means_out && covariances_out, "null argument");
         require(data->have_estep && data->em_K == (int)K, "no E-step results on the device for this K");
-        run_mstats(data, (int)K, kFromLogResp, nullptr, 0, nullptr, true);
+        run_mstats(data, (int)K, kFromLogResp, nullptr, 0, true);
         finalize_out(data, (int)K, mixing_out, means_out, covariances_out);
     });
 }
@@ -600,7 +599,7 @@ int mlhip_em_step(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* mi
         check_em_args(ctx, data, K);
         require(mixing && means && covariances && log_likelihood && mixing_out && means_out && covariances_out, "null argument");
         run_estep(data, (int)K, mixing, means, covariances);
-        run_mstats(data, (int)K, kFromLogResp, nullptr, 0, nullptr, true);
+        run_mstats(data, (int)K, kFromLogResp, nullptr, 0, true);
         *log_likelihood = ll_from_stats(data, (int)K);
         finalize_out(data, (int)K, mixing_out, means_out, covariances_out);
     });
@@ -619,7 +618,7 @@ int mlhip_em_maximisation_from(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, con
         if (data->n)
             HIP_CHECK(hipMemcpy2DAsync(data->resp_dev.p, sizeof(double) * data->ldr, resp, sizeof(double) * ldr,
                                        sizeof(double) * data->n, K, hipMemcpyHostToDevice, ctx->stream));
-        run_mstats(data, (int)K, kFromResp, data->resp_dev.as<double>(), data->ldr, nullptr, false);
+        run_mstats(data, (int)K, kFromResp, data->resp_dev.as<double>(), data->ldr, false);
         finalize_out(data, (int)K, mixing_out, means_out, covariances_out);
     });
 }
@@ -633,7 +632,10 @@ int mlhip_em_maximisation_from_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t
         ensure_em_workspace(data, (int)K);
         data->labels_dev.reserve(sizeof(uint32_t) * data->n_pad);
         HIP_CHECK(hipMemcpyAsync(data->labels_dev.p, labels, sizeof(uint32_t) * data->n, hipMemcpyHostToDevice, ctx->stream));
-        run_mstats(data, (int)K, kFromLabels, nullptr, 0, data->labels_dev.as<uint32_t>(), false);
+        // One-hot responsibilities are materialised in the (still unused) log-responsibility buffer of the workspace.
+        data->have_estep = false;
+        launch_fill_responsibilities(data->labels_dev.as<uint32_t>(), data->n, (int)K, data->lw.as<double>(), data->ldr, ctx->stream);
+        run_mstats(data, (int)K, kFromResp, data->lw.as<double>(), data->ldr, false);
         finalize_out(data, (int)K, mixing_out, means_out, covariances_out);
     });
 }
@@ -683,7 +685,9 @@ int mlhip_sample_covariance(mlhip_ctx* ctx, mlhip_data* data, double* mean, doub
         // K = 1, r = 1: S_0 = sum_i xt_i xt_i^T about the global mean. The E-step workspace for another K is
         // left untouched only if K == 1; otherwise it is rebuilt on the next E-step.
         ensure_em_workspace(data, 1);
-        run_mstats(data, 1, kOnes, nullptr, 0, nullptr, false);
+        data->have_estep = false;
+        launch_fill_responsibilities(nullptr, data->n, 1, data->lw.as<double>(), data->ldr, ctx->stream);
+        run_mstats(data, 1, kFromResp, data->lw.as<double>(), data->ldr, false);
         const double* s = data->stats_host.as<double>();
         const int d = data->d;
         const double n = (double)data->n_global;
