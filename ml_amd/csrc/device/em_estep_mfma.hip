@@ -41,24 +41,6 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-/// Component record in registers: the W slabs in A-operand order, the mean in B-operand row order, the constant.
-template <int D> struct Rec {
-    double a[Shape<D>::NC];
-    double mu[Shape<D>::LS];
-    double coef;
-};
-
-template <int D>
-__device__ __forceinline__ void load_rec(Rec<D>& r, const double* __restrict__ rec, int lane, int g)
-{
-    using S = Shape<D>;
-#pragma unroll
-    for (int c = 0; c < S::NC; ++c) r.a[c] = rec[c * 64 + lane];
-#pragma unroll
-    for (int ls = 0; ls < S::LS; ++ls) r.mu[ls] = rec[S::NC * 64 + 4 * ls + g];
-    r.coef = rec[S::NC * 64 + D];
-}
-
 /// Sum over the 4 lane groups (g = lane>>4) of v[sb], delivered so that group g ends with the total of v[g]:
 /// a reduce-scatter in two swap steps (rows g <-> g^1 with v_permlane16_swap, halves g <-> g^2 with
 /// v_permlane32_swap) -- 6 VALU swaps and 3 adds instead of 16 ds_bpermute and 8 adds.
@@ -86,6 +68,18 @@ __device__ __forceinline__ double reduce_scatter_groups(double v0, double v1, do
     return t01 + t23;          // g=0: v0, g=1: v1, g=2: v2, g=3: v3 totals
 }
 
+/// Slab schedule of one component, ordered by column slab ls so that z = x - mu is formed once per (ls, sample block):
+/// step t -> (J, ls). For ls < slabs_of(0) both row blocks use the slab column, J = 0 first.
+template <int D> struct Steps {
+    using S = Shape<D>;
+    static constexpr int both = S::JB == 2 ? S::slabs_of(0) : 0;   // column slabs used by two row blocks
+    static constexpr int J(int t) { return S::JB == 1 ? 0 : (t < 2 * both ? (t & 1) : 1); }
+    static constexpr int ls(int t) { return S::JB == 1 ? t : (t < 2 * both ? t / 2 : t - both); }
+    /// index of the slab in the host-side record (J-major: all J = 0 slabs first)
+    static constexpr int slab(int t) { return J(t) == 0 ? ls(t) : S::slabs_of(0) + ls(t); }
+    static constexpr bool first_of_ls(int t) { return S::JB == 1 || t >= 2 * both || (t & 1) == 0; }
+};
+
 template <int D>
 __global__ __launch_bounds__(256, 2) void em_estep_mfma_kernel(const double* __restrict__ xt, size_t ldx, uint32_t n,
                                                                 uint32_t n_groups, const double* __restrict__ params,
@@ -94,7 +88,10 @@ __global__ __launch_bounds__(256, 2) void em_estep_mfma_kernel(const double* __r
                                                                 double* __restrict__ ll_partials)
 {
     using S = Shape<D>;
-    constexpr int LS = S::LS, JB = S::JB, PS = S::PS;
+    using T = Steps<D>;
+    constexpr int LS = S::LS, JB = S::JB, NC = S::NC, PS = S::PS;
+    // rolling prefetch window of W slabs; W divides NC so that the slot of a step is a compile-time constant
+    constexpr int W = (NC % 4 == 0) ? 4 : (NC % 3 == 0) ? 3 : (NC % 5 == 0) ? 5 : NC;
     __shared__ double red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, s = lane & 15;
@@ -112,51 +109,58 @@ __global__ __launch_bounds__(256, 2) void em_estep_mfma_kernel(const double* __r
 
         double m = -__builtin_inf(), ssum = 0.0;
 
-        // One component: 4 sample blocks x (block-triangular MFMA chain, squares), then the log-domain epilogue.
-        auto component = [&](const Rec<D>& r, int k) {
+        // Rolling window over the slab stream of all components: slot t % W holds the slab of step t (and the mean
+        // entry of its column slab); it is refilled with step t + W -- possibly of the next component -- as soon as
+        // its 4 MFMAs are issued, so W slabs (about W * 256 MFMA cycles) of loads are always in flight.
+        double aw[W], muw[W];
+        auto fetch = [&](int slot, int k, int t) {
+            const double* __restrict__ rec = params + (size_t)k * PS;
+            aw[slot] = rec[T::slab(t) * 64 + lane];
+            muw[slot] = rec[NC * 64 + 4 * T::ls(t) + g];
+        };
+#pragma unroll
+        for (int t = 0; t < W; ++t) fetch(t, 0, t);
+
+        for (int k = 0; k < K; ++k) {
+            const double coef = params[(size_t)k * PS + NC * 64 + D];
+            const int kn = k + 1 < K ? k + 1 : k;       // the last component prefetches itself again (discarded)
+            d4 acc[4][JB];
+            double z[4];
+#pragma unroll
+            for (int t = 0; t < NC; ++t) {
+                const double a = aw[t % W];
+                if (T::first_of_ls(t)) {
+#pragma unroll
+                    for (int sb = 0; sb < 4; ++sb) z[sb] = xb[T::ls(t)][sb] - muw[t % W];
+                }
+                if (t + W < NC) fetch(t % W, k, t + W); else fetch(t % W, kn, t + W - NC);
+#pragma unroll
+                for (int sb = 0; sb < 4; ++sb) {
+                    // first slab of a row block starts its chain from zero
+                    const bool first = (T::ls(t) == 0);
+                    acc[sb][T::J(t)] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, z[sb], first ? d4{0.0, 0.0, 0.0, 0.0} : acc[sb][T::J(t)], 0, 0, 0);
+                }
+                // Pin the slab-major order: without it the scheduler regroups the MFMAs into per-sample-block chains
+                // (fewer live accumulators) and pays the MFMA->VALU hazard wait after each of the 8 chains.
+                __builtin_amdgcn_sched_barrier(0);
+            }
             double qs[4];
 #pragma unroll
             for (int sb = 0; sb < 4; ++sb) {
-                d4 acc[JB];
-#pragma unroll
-                for (int J = 0; J < JB; ++J) acc[J] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int ls = 0; ls < LS; ++ls) {
-                    const double z = xb[ls][sb] - r.mu[ls];
-#pragma unroll
-                    for (int J = 0; J < JB; ++J) {
-                        if (ls < S::slabs_of(J)) {
-                            const int c = (J == 0 ? 0 : S::slabs_of(0)) + ls;
-                            acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(r.a[c], z, acc[J], 0, 0, 0);
-                        }
-                    }
-                }
-                double t = 0.0;
+                double t2 = 0.0;
 #pragma unroll
                 for (int J = 0; J < JB; ++J)
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) t = __builtin_fma(acc[J][rr], acc[J][rr], t);
-                qs[sb] = t;
+                    for (int rr = 0; rr < 4; ++rr) t2 = __builtin_fma(acc[sb][J][rr], acc[sb][J][rr], t2);
+                qs[sb] = t2;
             }
             const double q = reduce_scatter_groups(qs[0], qs[1], qs[2], qs[3]);   // lane (g, s) gets sample 16g + s
-            const double lw = __builtin_fma(-0.5, q, r.coef);
+            const double lw = __builtin_fma(-0.5, q, coef);
             lw_out[(size_t)k * ldr + base + lane] = lw;
             const double e = exp(-fabs(lw - m));
             const bool up = lw > m;
             ssum = up ? __builtin_fma(ssum, e, 1.0) : ssum + e;
             m = up ? lw : m;
-        };
-
-        // Software pipeline over components: the record of component k+1 is in flight while k is computed.
-        Rec<D> r0, r1;
-        load_rec<D>(r0, params, lane, g);
-        for (int k = 0; k < K; k += 2) {
-            if (k + 1 < K) load_rec<D>(r1, params + (size_t)(k + 1) * PS, lane, g);
-            component(r0, k);
-            if (k + 1 < K) {
-                if (k + 2 < K) load_rec<D>(r0, params + (size_t)(k + 2) * PS, lane, g);
-                component(r1, k + 1);
-            }
         }
         const double lse = m + log(ssum);
         lse_out[base + lane] = lse;

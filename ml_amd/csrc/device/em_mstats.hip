@@ -218,8 +218,7 @@ Plan make_plan(int d, int K, int num_cus)
         // One 512-thread workgroup per CU; its 8 waves take the column blocks round-robin (wave w: w, w+8, ...), every
         // wave holds all (<= 4) row blocks of the group: RBW x CBW <= 20 accumulator tiles.
         p.RBW = p.RB >= 4 ? 4 : (p.RB >= 2 ? 2 : 1);
-        p.CBW = (p.CB + 7) / 8;
-        if (p.CBW > 5) p.CBW = 5;
+        p.CBW = (p.CB + 7) / 8;   // <= 5 for d <= 32 (CB <= 36), so there is a single column group
         p.n_rbg = (p.RB + p.RBW - 1) / p.RBW;
         p.n_cbg = (p.CB + 8 * p.CBW - 1) / (8 * p.CBW);
         p.KP = p.n_rbg * p.RBW * 16;

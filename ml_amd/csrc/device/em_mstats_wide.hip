@@ -45,9 +45,9 @@ __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
         offa[c] = a;
         offb[c] = b;
     }
-    bool active[CBW];
-#pragma unroll
-    for (int c = 0; c < CBW; ++c) active[c] = (cbg * CBW + c) * NW + wave < CB_total;   // wave-uniform
+    // With CBW = ceil(CB / 8) column blocks per wave and a single column group, only a wave's LAST block can fall
+    // outside the matrix (wave-uniform); all others are unconditional, which keeps them in one basic block.
+    const bool last_active = (cbg * CBW + CBW - 1) * NW + wave < CB_total;
 
     d4 acc[RBW][CBW];
 #pragma unroll
@@ -109,13 +109,20 @@ __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
 #pragma unroll
             for (int r = 0; r < RBW; ++r) av[r] = rr[r * 16];
 #pragma unroll
-            for (int c = 0; c < CBW; ++c) {
-                if (active[c]) {
-                    const double bv = xr[offa[c]] * xr[offb[c]];
+            for (int c = 0; c < CBW - 1; ++c) {
+                const double bv = xr[offa[c]] * xr[offb[c]];
 #pragma unroll
-                    for (int r = 0; r < RBW; ++r)
-                        acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], bv, acc[r][c], 0, 0, 0);
-                }
+                for (int r = 0; r < RBW; ++r)
+                    acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], bv, acc[r][c], 0, 0, 0);
+            }
+            // The last block's operand is formed unconditionally (padding columns read the zero slot), so its LDS
+            // reads are scheduled with the others; only its MFMAs are skipped by the waves that do not own a block.
+            constexpr int c = CBW - 1;
+            const double bv = xr[offa[c]] * xr[offb[c]];
+            if (last_active) {
+#pragma unroll
+                for (int r = 0; r < RBW; ++r)
+                    acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], bv, acc[r][c], 0, 0, 0);
             }
         }
     }
