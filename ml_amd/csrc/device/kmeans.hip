@@ -23,6 +23,10 @@ namespace {
 
 typedef unsigned long long u64;
 
+// 1024-thread workgroups: the workgroup-private LDS accumulators (K*(3d+1) words, 51 KB at K=256, d=8) would otherwise
+// cap the CU at 3 small workgroups = 3 waves per SIMD, too few to cover the dependent FMA chain of a distance.
+constexpr int BS = 1024;
+
 /// t (|t| < 2^94, integer part only is kept) -> limbs: t = i2 * 2^64 + u1 * 2^32 + u0 (+ dropped fraction), u0,u1 in [0, 2^32).
 __device__ __forceinline__ void split_limbs(double t, u64& w0, u64& w1, u64& w2)
 {
@@ -36,22 +40,22 @@ __device__ __forceinline__ void split_limbs(double t, u64& w0, u64& w1, u64& w2)
 }
 
 template <int D, bool USE_LDS>
-__global__ __launch_bounds__(256) void kmeans_assign_kernel(
+__global__ __launch_bounds__(BS) void kmeans_assign_kernel(
     const double* __restrict__ xt, size_t ldx, uint32_t n, int d, const double* __restrict__ cent, int K,
     const double* __restrict__ scale, uint32_t* __restrict__ labels, const uint32_t* __restrict__ old_labels,
     int have_old, double* __restrict__ min_dist, int accumulate, double* __restrict__ partials, size_t pstride)
 {
     extern __shared__ u64 acc_lds[];      // [K][3d+1] when USE_LDS
-    __shared__ double red[8];
+    __shared__ double red[2 * (BS / 64)];
     const int tid = threadIdx.x;
     const int W = 3 * d + 1;
     double* my_part = partials + (size_t)blockIdx.x * pstride;   // [inertia, changed, K*(3d+1) integer words]
     u64* my_words = reinterpret_cast<u64*>(my_part + 2);
     if (accumulate) {
         if (USE_LDS) {
-            for (int e = tid; e < K * W; e += 256) acc_lds[e] = 0;
+            for (int e = tid; e < K * W; e += BS) acc_lds[e] = 0;
         } else {
-            for (int e = tid; e < K * W; e += 256) my_words[e] = 0;
+            for (int e = tid; e < K * W; e += BS) my_words[e] = 0;
         }
         __syncthreads();
     }
@@ -60,21 +64,45 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(
     for (int j = 0; j < D; ++j) sc[j] = j < d ? scale[j] : 0.0;
 
     double inertia = 0.0, changed = 0.0;
-    for (uint32_t i = blockIdx.x * 256u + tid; i < n; i += gridDim.x * 256u) {
+    for (uint32_t i = blockIdx.x * (uint32_t)BS + tid; i < n; i += gridDim.x * (uint32_t)BS) {
         double x[D];
 #pragma unroll
         for (int j = 0; j < D; ++j) x[j] = xt[(size_t)j * ldx + i];
         double best = __builtin_inf();
         uint32_t arg = 0;
-        for (int k = 0; k < K; ++k) {
-            const double* __restrict__ c = cent + (size_t)k * D;   // wave-uniform -> scalar loads
-            double s = 0.0;
+        // The centroid of cluster k is wave-uniform and arrives through scalar loads; the one of cluster k+1 is
+        // requested before the distance to k is computed (register double buffer for D <= 16, where 2*D doubles fit
+        // the SGPR file), so the scalar-memory latency is off the critical path.
+        if constexpr (D <= 16) {
+            double cn[D];
 #pragma unroll
-            for (int j = 0; j < D; ++j) {
-                const double t = x[j] - c[j];
-                s = __builtin_fma(t, t, s);
+            for (int j = 0; j < D; ++j) cn[j] = cent[j];
+            for (int k = 0; k < K; ++k) {
+                double cc[D];
+#pragma unroll
+                for (int j = 0; j < D; ++j) cc[j] = cn[j];
+                const double* __restrict__ nx = cent + (size_t)(k + 1 < K ? k + 1 : k) * D;
+#pragma unroll
+                for (int j = 0; j < D; ++j) cn[j] = nx[j];
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    const double t = x[j] - cc[j];
+                    s = __builtin_fma(t, t, s);
+                }
+                if (s < best) { best = s; arg = (uint32_t)k; }
             }
-            if (s < best) { best = s; arg = (uint32_t)k; }
+        } else {
+            for (int k = 0; k < K; ++k) {
+                const double* __restrict__ c = cent + (size_t)k * D;
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    const double t = x[j] - c[j];
+                    s = __builtin_fma(t, t, s);
+                }
+                if (s < best) { best = s; arg = (uint32_t)k; }
+            }
         }
         labels[i] = arg;
         if (min_dist) min_dist[i] = best;
@@ -101,17 +129,20 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(
         inertia += __shfl_down(inertia, off, 64);
         changed += __shfl_down(changed, off, 64);
     }
+    constexpr int NWV = BS / 64;
     if ((tid & 63) == 0) {
         red[tid >> 6] = inertia;
-        red[4 + (tid >> 6)] = changed;
+        red[NWV + (tid >> 6)] = changed;
     }
     __syncthreads();
     if (tid == 0) {
-        my_part[0] = red[0] + red[1] + red[2] + red[3];
-        my_part[1] = red[4] + red[5] + red[6] + red[7];
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < NWV; ++w) { a += red[w]; b += red[NWV + w]; }   // fixed order
+        my_part[0] = a;
+        my_part[1] = b;
     }
     if (accumulate && USE_LDS) {
-        for (int e = tid; e < K * W; e += 256) my_words[e] = acc_lds[e];
+        for (int e = tid; e < K * W; e += BS) my_words[e] = acc_lds[e];
     }
 }
 
@@ -161,14 +192,14 @@ void launch_t(const KmeansArgs& a, int grid, int use_lds, size_t pstride, hipStr
 {
     const size_t smem = use_lds ? sizeof(u64) * (size_t)a.K * (3 * a.d + 1) : 0;
     if (use_lds)
-        hipLaunchKernelGGL((kmeans_assign_kernel<D, true>), dim3(grid), dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d,
+        hipLaunchKernelGGL((kmeans_assign_kernel<D, true>), dim3(grid), dim3(BS), smem, stream, a.xt, a.ldx, a.n, a.d,
                            a.centroids, a.K, a.scale, a.labels, a.old_labels, a.have_old, a.min_dist, a.accumulate, a.partials, pstride);
     else
-        hipLaunchKernelGGL((kmeans_assign_kernel<D, false>), dim3(grid), dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d,
+        hipLaunchKernelGGL((kmeans_assign_kernel<D, false>), dim3(grid), dim3(BS), smem, stream, a.xt, a.ldx, a.n, a.d,
                            a.centroids, a.K, a.scale, a.labels, a.old_labels, a.have_old, a.min_dist, a.accumulate, a.partials, pstride);
 }
 
-inline int kmeans_grid(int num_cus) { return num_cus * 4; }
+inline int kmeans_grid(int num_cus) { return num_cus * 2; }   // two 1024-thread workgroups (32 waves) per CU
 
 }  // namespace
 
@@ -181,7 +212,7 @@ int launch_kmeans_assign(const KmeansArgs& a, int num_cus, hipStream_t stream)
 {
     const size_t pstride = 2 + (size_t)a.K * (3 * a.d + 1);
     int grid = kmeans_grid(num_cus);
-    const uint32_t blocks_needed = (a.n + 255) / 256;
+    const uint32_t blocks_needed = (a.n + BS - 1) / BS;
     if ((uint32_t)grid > blocks_needed) grid = (int)(blocks_needed ? blocks_needed : 1);
     if ((size_t)grid * pstride > a.partials_capacity) return -2;
     const int use_lds = (size_t)a.K * (3 * a.d + 1) * sizeof(u64) <= 64 * 1024;

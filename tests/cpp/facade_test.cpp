@@ -1,0 +1,174 @@
+// C++ drop-in check of the facade headers (include/ML/*.hpp): compiled with plain g++ (no hipcc, no Eigen) against
+// libmlhip.so. Mirrors the structure of the reference's Tests/test_EM.cpp / test_KMeans.cpp / test_LinearAlgebra.cpp:
+// mode "host" runs what needs no GPU (exceptions, exact fits, helpers), mode "gpu" adds full fits.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <random>
+#include <stdexcept>
+#include <vector>
+
+#include "ML/Clustering.hpp"
+#include "ML/EM.hpp"
+#include "ML/KMeans.hpp"
+#include "ML/LinearAlgebra.hpp"
+
+static int failures = 0;
+#define CHECK(cond) do { if (!(cond)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); ++failures; } } while (0)
+#define CHECK_THROWS(expr, type) do { bool ok_ = false; try { expr; } catch (const type&) { ok_ = true; } catch (...) {} \
+    if (!ok_) { std::printf("FAIL %s:%d: %s did not throw %s\n", __FILE__, __LINE__, #expr, #type); ++failures; } } while (0)
+
+using ml::MatrixXd;
+using ml::VectorXd;
+
+static void host_checks()
+{
+    // constructor / setter errors (ML/EM.cpp:35-82, ML/KMeans.cpp:21,124-148)
+    CHECK_THROWS(ml::EM(0), std::invalid_argument);
+    ml::EM em(2);
+    CHECK(!em.converged());
+    CHECK(em.number_components() == 2 && em.number_clusters() == 2);
+    CHECK_THROWS(em.set_absolute_tolerance(-1), std::domain_error);
+    CHECK_THROWS(em.set_relative_tolerance(-1), std::domain_error);
+    CHECK_THROWS(em.set_maximum_steps(1), std::invalid_argument);
+    CHECK_THROWS(em.set_means_initialiser(nullptr), std::invalid_argument);
+    CHECK_THROWS(em.set_responsibilities_initialiser(nullptr), std::invalid_argument);
+    CHECK_THROWS(em.covariance(2), std::invalid_argument);
+    CHECK_THROWS(ml::Clustering::ClosestCentroid(nullptr), std::invalid_argument);
+    CHECK_THROWS(ml::Clustering::KMeans(0), std::invalid_argument);
+    ml::Clustering::KMeans km(2);
+    CHECK_THROWS(km.set_absolute_tolerance(-1), std::domain_error);
+    CHECK_THROWS(km.set_maximum_steps(1), std::invalid_argument);
+    CHECK_THROWS(km.set_number_initialisations(0), std::invalid_argument);
+    CHECK_THROWS(km.set_centroids_initialiser(nullptr), std::invalid_argument);
+
+    // deterministic exact fits (Tests/test_EM.cpp:126-144, Tests/test_KMeans.cpp:108-128); data 3 x 2, column = sample
+    MatrixXd data(3, 2);
+    const double v[6] = {-1, 1, 0.5, 0, 0.5, 0.5};
+    std::memcpy(data.data(), v, sizeof(v));
+    CHECK(em.fit(data));
+    CHECK(km.fit(data));
+    CHECK(km.inertia() == 0.0);
+    for (unsigned i = 0; i < 2; ++i) {
+        CHECK(em.labels()[i] == i && km.labels()[i] == i);
+        for (int j = 0; j < 3; ++j) CHECK(em.means()(j, i) == data(j, i) && km.centroids()(j, i) == data(j, i));
+    }
+    ml::Clustering::Model& as_model = em;   // the abstract interface is intact
+    CHECK(as_model.converged() && as_model.centroids().cols() == 2);
+    MatrixXd too_few(3, 1);
+    CHECK_THROWS(em.fit(too_few), std::invalid_argument);
+    MatrixXd no_rows(0, 5);
+    CHECK_THROWS(em.fit(no_rows), std::invalid_argument);
+    CHECK_THROWS(km.fit(too_few), std::invalid_argument);
+
+    // LinearAlgebra (Tests/test_LinearAlgebra.cpp)
+    std::default_random_engine rng(5);
+    std::uniform_real_distribution<double> u(-1, 1);
+    for (int n : {4, 1024}) {
+        MatrixXd A(n, n);
+        VectorXd x(n);
+        for (int i = 0; i < n; ++i) { x[i] = u(rng); for (int j = 0; j <= i; ++j) A(i, j) = A(j, i) = u(rng); }
+        double expected = 0;
+        for (int i = 0; i < n; ++i) { double t = 0; for (int j = 0; j < n; ++j) t += A(i, j) * x[j]; expected += x[i] * t; }
+        CHECK(std::abs(ml::LinearAlgebra::xAx_symmetric(A, x) - expected) <= std::abs(expected) * 1e-14);
+        MatrixXd xx;
+        ml::LinearAlgebra::xxT(x, xx);
+        MatrixXd B(A);
+        ml::LinearAlgebra::add_a_xxT(x, B, 0.6);
+        double err = 0, norm = 0;
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+            err += std::pow(xx(i, j) - x[i] * x[j], 2) + std::pow(B(i, j) - (A(i, j) + 0.6 * x[i] * x[j]), 2);
+            norm += std::pow(A(i, j) + 0.6 * x[i] * x[j], 2);
+        }
+        CHECK(std::sqrt(err) <= std::sqrt(norm) * 1e-15);
+    }
+    MatrixXd A23(2, 3);
+    VectorXd x2(2);
+    CHECK_THROWS(ml::LinearAlgebra::xAx_symmetric(A23, x2), std::invalid_argument);
+    MatrixXd A33(3, 3);
+    CHECK_THROWS(ml::LinearAlgebra::xAx_symmetric(A33, x2), std::invalid_argument);
+    CHECK_THROWS(ml::LinearAlgebra::add_a_xxT(x2, A33, 0.6), std::invalid_argument);
+}
+
+// Tests/test_EM.cpp:8-104 and Tests/test_KMeans.cpp:8-106 (same libstdc++ draws, same invariants)
+static void gpu_checks()
+{
+    std::default_random_engine rng;
+    std::uniform_real_distribution<double> u01(0, 1);
+    std::normal_distribution<double> standard_normal;
+    const unsigned K = 2, d = 3, n = 400;
+    const double p0 = 0.25;
+    const double means[2][3] = {{0.4, 0.11, 0.5}, {-1.2, 2.2, 1.6}};
+    const double sigmas[2][3] = {{0.05, 0.04, 0.01}, {0.2, 0.1, 0.2}};
+    MatrixXd data(d, n);
+    std::vector<unsigned> truth(n);
+    for (unsigned i = 0; i < n; ++i) {
+        const unsigned k = u01(rng) < p0 ? 0 : 1;
+        truth[i] = k;
+        for (unsigned l = 0; l < d; ++l) data(l, i) = standard_normal(rng) * sigmas[k][l] + means[k][l];
+    }
+
+    ml::EM em(K);
+    em.set_absolute_tolerance(1e-8);
+    em.set_relative_tolerance(1e-8);
+    em.set_maximum_steps(100);
+    em.set_means_initialiser(std::make_shared<ml::Clustering::KPP>());
+    em.set_seed(63413131);
+    CHECK(em.fit(data));
+    CHECK(em.converged());
+    CHECK(em.labels().size() == n && em.means().rows() == d && em.means().cols() == K);
+    CHECK(em.responsibilities().rows() == n && em.responsibilities().cols() == K);
+    VectorXd uu(K);
+    for (unsigned i = 0; i < n; ++i) {
+        em.assign_responsibilities(ml::ConstVectorRef(data.col(i), d), uu);
+        double e2 = 0;
+        for (unsigned k = 0; k < K; ++k) e2 += std::pow(uu[k] - em.responsibilities()(i, k), 2);
+        CHECK(std::sqrt(e2) <= 1e-15);
+    }
+    const bool swap = (em.mixing_probabilities()[0] < em.mixing_probabilities()[1]) != (p0 < 1 - p0);
+    for (unsigned k = 0; k < K; ++k) {
+        const unsigned t = swap ? 1 - k : k;
+        CHECK(std::abs(em.mixing_probabilities()[k] - (t == 0 ? p0 : 1 - p0)) <= 2e-2);
+        for (unsigned l = 0; l < d; ++l) {
+            CHECK(std::abs(em.means()(l, k) - means[t][l]) <= 2e-2);
+            CHECK(std::abs(em.covariance(k)(l, l) - sigmas[t][l] * sigmas[t][l]) <= 1e-2);
+        }
+    }
+    ml::EM em1(1);
+    em1.fit(data);
+    CHECK(em1.log_likelihood() <= em.log_likelihood());
+
+    ml::Clustering::KMeans km(K);
+    km.set_absolute_tolerance(1e-8);
+    km.set_maximum_steps(100);
+    km.set_seed(63413131);
+    CHECK(km.fit(data));
+    double inertia = 0;
+    for (unsigned i = 0; i < n; ++i) {
+        const auto ld = km.assign_label(ml::ConstVectorRef(data.col(i), d));
+        CHECK(ld.first == km.labels()[i]);
+        inertia += ld.second;
+    }
+    CHECK(std::abs(inertia - km.inertia()) <= 1e-15);
+    const bool kswap = truth[0] != km.labels()[0];
+    for (unsigned i = 0; i < n; ++i) CHECK((kswap ? 1 - truth[i] : truth[i]) == km.labels()[i]);
+    km.set_seed(63413131);
+    km.set_number_initialisations(3);
+    CHECK(km.fit(data));
+    CHECK(km.inertia() <= inertia);
+}
+
+int main(int argc, char** argv)
+{
+    const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
+    try {
+        host_checks();
+        if (gpu) gpu_checks();
+    } catch (const std::exception& e) {
+        std::printf("FAIL unexpected exception: %s\n", e.what());
+        ++failures;
+    }
+    std::printf(failures ? "%d FAILURES\n" : "OK (%d failures)\n", failures);
+    return failures ? 1 : 0;
+}
