@@ -93,3 +93,86 @@ def test_two_rank_statistics_allreduce_matches_single_rank_oracle(oracle):
     assert np.max(np.abs(pi - em.mixing_probabilities)) < 1e-14
     assert np.max(np.abs(mu - em.means)) < 1e-13 * np.max(np.abs(em.means))
     assert np.max(np.abs(S - em.covariances)) < 1e-12 * np.max(np.abs(em.covariances))
+
+
+# ---- two ranks on one real GPU (host-side gloo all-reduce): the whole product path, row-sharded ---------------------
+
+def _gpu_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        import torch.distributed as dist
+        from ml_amd import _lib, synth
+        from ml_amd import dist as mldist
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        d, K, n = 8, 5, 6001
+        mix = synth.Mixture(d, K, seed=4)
+        X, _ = mix.sample(n)
+        lo, hi = mldist.shard_bounds(n, world, rank)
+        ctx = _lib.Context(0)
+        mldist.install_allreduce(ctx, world, rank, on_device=False)
+        data = _lib.Data(ctx, np.ascontiguousarray(X[lo:hi]))
+        assert data.n_global == n
+        mean, cov = data.sample_covariance()
+        pi, mu, S = np.full(K, 1.0 / K), mix.initial_means(), np.stack([cov] * K)
+        lls = []
+        for _ in range(3):
+            ll, pi, mu, S = data.em_step(pi, mu, S)
+            lls.append(ll)
+        labels = data.em_labels(K)
+        inertia, changed, counts, C1 = data.kmeans_step(mu)
+        q.put((rank, lo, hi, data.shift, cov, lls, pi, mu, S, labels, inertia, changed, counts, C1))
+        data.close()
+        ctx.close()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), str(e)))
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_match_single_rank():
+    """Row-sharded EM / K-means over 2 processes (gloo host hook) == the single-process run on the whole data."""
+    import torch.multiprocessing as mp
+    from ml_amd import _lib, synth
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = _free_port()
+    procs = [mpctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in results:
+        assert r[1] != "error", r[2]
+    results.sort(key=lambda r: r[0])
+    a, b = results
+    # replicated quantities are bit-identical on both ranks
+    for i in (3, 4, 6, 7, 8, 10, 12, 13):
+        assert np.array_equal(np.asarray(a[i]), np.asarray(b[i])), i
+    assert a[5] == b[5]
+
+    d, K, n = 8, 5, 6001
+    mix = synth.Mixture(d, K, seed=4)
+    X, _ = mix.sample(n)
+    ctx = _lib.Context(0)
+    data = _lib.Data(ctx, X)
+    mean, cov = data.sample_covariance()
+    assert np.max(np.abs(a[3] - data.shift)) <= 1e-15 * np.max(np.abs(data.shift)) + 1e-16
+    assert np.max(np.abs(a[4] - cov)) <= 1e-13 * np.max(np.abs(cov))
+    pi, mu, S = np.full(K, 1.0 / K), mix.initial_means(), np.stack([cov] * K)
+    for it in range(3):
+        ll, pi, mu, S = data.em_step(pi, mu, S)
+        assert abs(ll - a[5][it]) <= 1e-12 * abs(ll)
+    assert np.max(np.abs(pi - a[6])) <= 1e-12
+    assert np.max(np.abs(mu - a[7])) <= 1e-11 * np.max(np.abs(mu))
+    assert np.max(np.abs(S - a[8])) <= 1e-10 * np.max(np.abs(S))
+    labels = data.em_labels(K)
+    assert np.array_equal(labels, np.concatenate([a[9], b[9]]))       # shards tile the rows in order
+    inertia, changed, counts, C1 = data.kmeans_step(a[7])
+    assert abs(inertia - a[10]) <= 1e-13 * inertia
+    assert changed == a[11] == n
+    assert np.array_equal(counts, a[12])
+    assert np.max(np.abs(C1 - a[13])) <= 1e-14 * np.max(np.abs(C1))
+    data.close()
+    ctx.close()
