@@ -31,6 +31,8 @@ struct EstepArgs {
 int launch_em_estep(const EstepArgs& a, hipStream_t stream);
 /// Matrix-core variant (em_estep_mfma.hip); params use the estep_mfma_param_stride(D) record layout.
 int launch_em_estep_mfma(const EstepArgs& a, int num_cus, hipStream_t stream);
+/// 4x4-block triangular variant (em_estep_mfma4.hip); params use the estep_mfma4_param_stride(D) record layout.
+int launch_em_estep_mfma4(const EstepArgs& a, int num_cus, hipStream_t stream);
 
 enum MstatsMode : int {
     kFromLogResp = 0,   // r = exp(lw - lse)          (after an E-step)

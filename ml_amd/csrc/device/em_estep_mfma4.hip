@@ -1,0 +1,200 @@
+// E-step of Gaussian-mixture EM on the gfx950 fp64 matrix cores with ELEMENT-BLOCK triangular work (dimensions 12..32)
+// -- replaces EM::expectation_step (reference ML/EM.cpp:190-219) and its xAx_symmetric calls (ML/LinearAlgebra.cpp:8-31).
+//
+// Same arithmetic as em_estep_mfma.hip (z = x - mu_k, y = W_k z with W_k = L_k^-1 lower triangular, q = |y|^2,
+// lw = log pi_k - sum log L_jj - q/2, online log-sum-exp), but on v_mfma_f64_4x4x4_4b_f64: one instruction multiplies
+// FOUR independent 4x4 blocks, D_b[4 rows][4 samples] += A_b[4 x 4] * B_b[4 x 4 samples]. With the same 4x4 block of W in
+// all four A blocks and four different sample quads in B, one instruction advances 4 rows of y for 16 samples, and only
+// the 4x4 blocks of W on or below the diagonal are ever issued: Q(Q+1)/2 = 36 of 64 at d = 32, i.e. 1152 flop per
+// (sample, component) instead of the 1536 of 16x16 blocks -- the matrix-core rate is the same for both shapes
+// (tools/microbench_fp64: 75.9 vs 72.1 TFLOP/s).
+//
+// Lane layout of the instruction (probed on the hardware, tools/probe_mfma4.hip):
+//   A[b][i][k] <- lane 16k + 4b + i,   B[b][k][j] <- lane 16k + 4b + j,   D[b][i][j] -> lane 16i + 4b + j.
+// With j + 4b = sample-in-16 this is the B / D layout of the 16x16x4 kernel (lane & 15 = sample, lane >> 4 = k or row),
+// so the coordinates stay in VGPRs as xb[column quad][sample block], every accumulator is ONE double per lane
+// (acc[sample block][row quad]) and the |y|^2 reduce-scatter / log-domain epilogue are unchanged.
+#include "device.hpp"
+
+namespace mlhip {
+namespace {
+
+template <int D> struct Blocks {
+    static constexpr int Q = D / 4;                   // 4-wide quads of rows / columns
+    static constexpr int NB = Q * (Q + 1) / 2;        // blocks on or below the diagonal
+    static constexpr int PS = NB * 16 + D + 1;        // doubles per component record
+    // step t (column-quad major): t -> (C, R), R = C..Q-1
+    static constexpr int start_of(int C) { return C * Q - C * (C - 1) / 2; }
+    static constexpr int C(int t) { int c = 0; while (c + 1 < Q && start_of(c + 1) <= t) ++c; return c; }
+    static constexpr int R(int t) { return C(t) + (t - start_of(C(t))); }
+    static constexpr bool first_of_C(int t) { return t == start_of(C(t)); }
+    // rolling prefetch window: the largest divisor of NB that is <= 9
+    static constexpr int window() { for (int w = 9; w > 1; --w) if (NB % w == 0) return w; return 1; }
+};
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+/// See em_estep_mfma.hip: group g = lane>>4 ends with the sum over groups of v[g] (v_permlane16/32_swap reduce-scatter).
+__device__ __forceinline__ double reduce_scatter_groups(double v0, double v1, double v2, double v3)
+{
+    auto swap16 = [](double& a, double& b) {
+        const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+        const auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        a = __hiloint2double((int)hi[0], (int)lo[0]);
+        b = __hiloint2double((int)hi[1], (int)lo[1]);
+    };
+    auto swap32 = [](double& a, double& b) {
+        const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+        const auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        a = __hiloint2double((int)hi[0], (int)lo[0]);
+        b = __hiloint2double((int)hi[1], (int)lo[1]);
+    };
+    swap16(v0, v1);
+    swap16(v2, v3);
+    double t01 = v0 + v1, t23 = v2 + v3;
+    swap32(t01, t23);
+    return t01 + t23;
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void em_estep_mfma4_kernel(const double* __restrict__ xt, size_t ldx, uint32_t n,
+                                                                 uint32_t n_groups, const double* __restrict__ params,
+                                                                 int K, double* __restrict__ lw_out, size_t ldr,
+                                                                 double* __restrict__ lse_out,
+                                                                 double* __restrict__ ll_partials)
+{
+    using B = Blocks<D>;
+    constexpr int Q = B::Q, NB = B::NB, PS = B::PS;
+    constexpr int W = 4;                           // LDS read-ahead window (blocks)
+    constexpr int NLD = (PS + 255) / 256;          // doubles of a record each thread moves to LDS
+    __shared__ double red[4];
+    __shared__ double recs[2][NLD * 256];          // the component record, staged once per workgroup, double-buffered
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, s = lane & 15;
+    const int aoff = g * 4 + (lane & 3);          // A operand: entry [k = lane>>4][i = lane&3] of a 16-double block
+    double ll_acc = 0.0;
+
+    // The 4 waves of a workgroup walk the components in lockstep (they share the staged record), each on its own
+    // 64-sample group: a workgroup iteration covers 4 consecutive groups (n_groups is a multiple of 4).
+    for (uint32_t grp = blockIdx.x * 4 + wave; grp < n_groups; grp += gridDim.x * 4) {
+        const uint32_t base = grp * 64;
+        // coordinates in B-operand layout: xb[C][sb] = x[dim 4C + g][sample base + 16sb + s]
+        double xb[Q][4];
+#pragma unroll
+        for (int C = 0; C < Q; ++C)
+#pragma unroll
+            for (int sb = 0; sb < 4; ++sb) xb[C][sb] = xt[(size_t)(4 * C + g) * ldx + base + 16 * sb + s];
+
+        double m = -__builtin_inf(), ssum = 0.0;
+
+        // record 0 -> LDS buffer 0 (the barrier at the top of the component loop publishes it)
+        double stage[NLD];
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) stage[it] = params[min(tid + 256 * it, PS - 1)];
+        __syncthreads();                            // everyone is done with the previous group's last record
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) recs[0][tid + 256 * it] = stage[it];
+
+        for (int k = 0; k < K; ++k) {
+            const double* __restrict__ rec = recs[k & 1];
+            __syncthreads();                        // record k visible; every wave has finished component k-1
+            // record k+1: global -> registers now (in flight during the MFMA phase), registers -> LDS at the end
+            const double* __restrict__ nxt = params + (size_t)(k + 1 < K ? k + 1 : k) * PS;
+#pragma unroll
+            for (int it = 0; it < NLD; ++it) stage[it] = nxt[min(tid + 256 * it, PS - 1)];
+
+            const double coef = rec[NB * 16 + D];
+            double aw[W], acc[4][Q], z[4];
+#pragma unroll
+            for (int t = 0; t < W && t < NB; ++t) aw[t] = rec[t * 16 + aoff];
+            // Nested static loops (column quad C, then row quad R >= C): every index below is a compile-time constant
+            // after unrolling, so the accumulators and the window stay in registers.
+#pragma unroll
+            for (int C = 0; C < Q; ++C) {
+                const double mu = rec[NB * 16 + 4 * C + g];
+#pragma unroll
+                for (int R = C; R < Q; ++R) {
+                    const int t = C * Q - C * (C - 1) / 2 + (R - C);     // step index in column-quad-major order
+                    const double a = aw[t % W];
+                    if (R == C) {
+#pragma unroll
+                        for (int sb = 0; sb < 4; ++sb) z[sb] = xb[C][sb] - mu;
+                    }
+                    if (t + W < NB) aw[t % W] = rec[(t + W) * 16 + aoff];   // refill the slot (LDS broadcast read)
+#pragma unroll
+                    for (int sb = 0; sb < 4; ++sb)
+                        acc[sb][R] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, z[sb], C == 0 ? 0.0 : acc[sb][R], 0, 0, 0);
+                    // Pin the block order (column-quad major, the 4 sample blocks back to back); see em_estep_mfma.hip.
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            double qs[4];
+#pragma unroll
+            for (int sb = 0; sb < 4; ++sb) {
+                double t2 = 0.0;
+#pragma unroll
+                for (int R = 0; R < Q; ++R) t2 = __builtin_fma(acc[sb][R], acc[sb][R], t2);
+                qs[sb] = t2;
+            }
+            const double q = reduce_scatter_groups(qs[0], qs[1], qs[2], qs[3]);   // lane (g, s) gets sample 16g + s
+            const double lw = __builtin_fma(-0.5, q, coef);
+            lw_out[(size_t)k * ldr + base + lane] = lw;
+            const double e = exp(-fabs(lw - m));
+            const bool up = lw > m;
+            ssum = up ? __builtin_fma(ssum, e, 1.0) : ssum + e;
+            m = up ? lw : m;
+            // publish record k+1 in the other buffer: nobody reads it now (last read during k-1, before this
+            // iteration's barrier), the next iteration's barrier makes it visible.
+#pragma unroll
+            for (int it = 0; it < NLD; ++it) recs[(k + 1) & 1][tid + 256 * it] = stage[it];
+        }
+        const double lse = m + log(ssum);
+        lse_out[base + lane] = lse;
+        if (base + lane < n) ll_acc += lse;
+    }
+    ll_acc = wave_sum(ll_acc);
+    if (lane == 0) red[wave] = ll_acc;
+    __syncthreads();
+    if (threadIdx.x == 0) ll_partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+template <int D>
+int launch_t(const EstepArgs& a, int num_cus, hipStream_t stream)
+{
+    const uint32_t n_pad = (a.n + kSampleTile - 1) / kSampleTile * kSampleTile;
+    const uint32_t n_groups = n_pad / 64;
+    uint32_t grid = (n_groups + 3) / 4;
+    const uint32_t cap = (uint32_t)num_cus * 2;          // 2 workgroups (8 waves) per CU, persistent
+    if (grid > cap) grid = cap;
+    if (grid > (uint32_t)a.n_ll_partials) grid = (uint32_t)a.n_ll_partials;
+    hipLaunchKernelGGL(em_estep_mfma4_kernel<D>, dim3(grid), dim3(256), 0, stream, a.xt, a.ldx, a.n, n_groups, a.params, a.K,
+                       a.lw, a.ldr, a.lse, a.ll_partials);
+    return (int)grid;
+}
+
+static_assert(Blocks<32>::NB == 36 && Blocks<12>::NB == 6, "block count");
+static_assert(Blocks<32>::C(0) == 0 && Blocks<32>::R(7) == 7 && Blocks<32>::C(8) == 1 && Blocks<32>::R(8) == 1 && Blocks<32>::C(35) == 7, "block order");
+
+}  // namespace
+
+int launch_em_estep_mfma4(const EstepArgs& a, int num_cus, hipStream_t stream)
+{
+    switch (a.D) {
+    case 12: return launch_t<12>(a, num_cus, stream);
+    case 16: return launch_t<16>(a, num_cus, stream);
+    case 20: return launch_t<20>(a, num_cus, stream);
+    case 24: return launch_t<24>(a, num_cus, stream);
+    case 28: return launch_t<28>(a, num_cus, stream);
+    case 32: return launch_t<32>(a, num_cus, stream);
+    default: return -1;
+    }
+}
+
+}  // namespace mlhip

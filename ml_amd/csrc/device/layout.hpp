@@ -33,6 +33,12 @@ inline int estep_mfma_slab_count(int D) { return D <= 16 ? estep_mfma_slabs_of(D
 inline int estep_mfma_param_stride(int D) { return estep_mfma_slab_count(D) * 64 + D + 1; }
 inline bool estep_mfma_supported(int D) { return D >= 12 && D <= 32 && D % 4 == 0; }
 
+/// 4x4-block E-step (v_mfma_f64_4x4x4_4b_f64; dimensions 12..32, multiples of 4): W is cut into 4x4 blocks (R, C); only
+/// blocks on or below the diagonal exist, ordered by column quad C, then row quad R. Record of one component,
+/// estep_mfma4_param_stride(D) doubles: [ block t: 16 doubles, entry [k][i] = W[4R + i][4C + k] | mean(D) | coef ].
+inline int estep_mfma4_block_count(int D) { const int q = D / 4; return q * (q + 1) / 2; }
+inline int estep_mfma4_param_stride(int D) { return estep_mfma4_block_count(D) * 16 + D + 1; }
+
 /// Sufficient statistics of one component: packed lower triangle (row-major) of sum_i r_i xt_i xt_i^T,
 /// xt = [x - shift ; 1] (length d+1). Entry (a,b), a >= b, sits at a(a+1)/2 + b; so
 ///   S0 = (d,d), S1'_b = (d,b), M2'_ab = (a,b).

@@ -87,6 +87,30 @@ void build_estep_params_mfma(int d, int D, int K, const double* mixing, const do
     }
 }
 
+void build_estep_params_mfma4(int d, int D, int K, const double* mixing, const double* means, const double* covariances,
+                              double* records)
+{
+    const int PS = estep_mfma4_param_stride(D);
+    const int NB = estep_mfma4_block_count(D);
+    const int Q = D / 4;
+    std::vector<double> L((size_t)d * d), W((size_t)d * d);
+    for (int k = 0; k < K; ++k) {
+        double* rec = records + (size_t)k * PS;
+        for (int i = 0; i < PS; ++i) rec[i] = 0.0;
+        const double log_det_half = whitening_matrix(d, covariances + (size_t)k * d * d, L, W);
+        int t = 0;
+        for (int C = 0; C < Q; ++C)
+            for (int R = C; R < Q; ++R, ++t)
+                for (int kk = 0; kk < 4; ++kk)
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = 4 * R + i, col = 4 * C + kk;
+                        rec[t * 16 + kk * 4 + i] = (row < d && col <= row) ? W[col * d + row] : 0.0;
+                    }
+        for (int j = 0; j < d; ++j) rec[NB * 16 + j] = means[(size_t)k * d + j];
+        rec[NB * 16 + D] = std::log(mixing[k]) - log_det_half;
+    }
+}
+
 void build_estep_params(int d, int D, int K, const double* mixing, const double* means, const double* covariances,
                         double* records)
 {

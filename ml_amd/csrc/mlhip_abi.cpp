@@ -250,7 +250,10 @@ void ensure_em_workspace(mlhip_data* dt, int K)
     dt->lse.reserve(sizeof(double) * dt->n_pad);
     dt->ll_partials.reserve(sizeof(double) * kMaxLlPartials);
     size_t ps = (size_t)estep_param_stride(dt->D) * K * sizeof(double);
-    if (estep_mfma_supported(dt->D)) ps = std::max(ps, (size_t)estep_mfma_param_stride(dt->D) * K * sizeof(double));
+    if (estep_mfma_supported(dt->D)) {
+        ps = std::max(ps, (size_t)estep_mfma_param_stride(dt->D) * K * sizeof(double));
+        ps = std::max(ps, (size_t)estep_mfma4_param_stride(dt->D) * K * sizeof(double));
+    }
     dt->params_dev.reserve(ps);
     dt->params_host.reserve(ps);
     dt->partials.reserve(sizeof(double) * em_mstats_scratch_doubles(dt->d, K, ctx->num_cus));
@@ -265,11 +268,18 @@ void run_estep(mlhip_data* dt, int K, const double* mixing, const double* means,
     mlhip_ctx* ctx = dt->ctx;
     ensure_em_workspace(dt, K);
     // Matrix-core kernel for d in 12..32, scalar-fed VALU kernel below that (MLHIP_ESTEP=valu|mfma overrides, for A/B runs).
-    bool use_mfma = estep_mfma_supported(dt->D);
+    // d in 12..32: 4x4-block triangular matrix-core kernel (mfma4); MLHIP_ESTEP=mfma16 selects the 16x16x4 block-
+    // triangular one, MLHIP_ESTEP=valu the scalar-fed VALU kernel (the only one below d = 12).
+    bool use_mfma = estep_mfma_supported(dt->D), use_mfma4 = use_mfma;
     if (const char* e = std::getenv("MLHIP_ESTEP")) {
-        if (std::strcmp(e, "valu") == 0) use_mfma = false;
+        if (std::strcmp(e, "valu") == 0) use_mfma = use_mfma4 = false;
+        if (std::strcmp(e, "mfma16") == 0) use_mfma4 = false;
     }
-    if (use_mfma) {
+    if (use_mfma4) {
+        host::build_estep_params_mfma4(dt->d, dt->D, K, mixing, means, covs, dt->params_host.as<double>());
+        HIP_CHECK(hipMemcpyAsync(dt->params_dev.p, dt->params_host.p, sizeof(double) * estep_mfma4_param_stride(dt->D) * K,
+                                 hipMemcpyHostToDevice, ctx->stream));
+    } else if (use_mfma) {
         host::build_estep_params_mfma(dt->d, dt->D, K, mixing, means, covs, dt->params_host.as<double>());
         HIP_CHECK(hipMemcpyAsync(dt->params_dev.p, dt->params_host.p, sizeof(double) * estep_mfma_param_stride(dt->D) * K,
                                  hipMemcpyHostToDevice, ctx->stream));
@@ -285,7 +295,8 @@ void run_estep(mlhip_data* dt, int K, const double* mixing, const double* means,
     a.ll_partials = dt->ll_partials.as<double>(); a.n_ll_partials = kMaxLlPartials;
     int grid = 0;
     ctx->timed("em_estep", [&] {
-        grid = use_mfma ? launch_em_estep_mfma(a, ctx->num_cus, ctx->stream) : launch_em_estep(a, ctx->stream);
+        grid = use_mfma4 ? launch_em_estep_mfma4(a, ctx->num_cus, ctx->stream)
+             : use_mfma ? launch_em_estep_mfma(a, ctx->num_cus, ctx->stream) : launch_em_estep(a, ctx->stream);
     });
     if (grid < 0) throw Unsupported("E-step kernel not instantiated for this dimension");
     HIP_CHECK(hipGetLastError());

@@ -42,6 +42,23 @@ __global__ __launch_bounds__(256) void mfma_kernel(double* out, double a, double
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma4_kernel(double* out, double a, double b)
+{
+    double acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+    double av = a + threadIdx.x * 1e-9, bv = b;
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 // waves 0-3: MFMA, waves 4-7: FMA (512-thread workgroup, 2 waves per SIMD)
 __global__ __launch_bounds__(512) void both_kernel(double* out, double a, double b)
 {
@@ -126,6 +143,12 @@ int main()
         float ms = time_ms([&] { hipLaunchKernelGGL(mfma_kernel<1>, dim3(blocks), dim3(256), 0, 0, out, 1.0000001, 1e-9); });
         const double flop = 2.0 * 16 * 16 * 4 * 1 * ITERS * 4.0 * blocks;
         printf("v_mfma_f64_16x16x4   1 wave/SIMD (1 acc, dependent chain): %7.3f ms  %7.2f TFLOP/s\n", ms, flop / ms * 1e-9);
+    }
+    for (int wps : {1, 2}) {
+        const int blocks = cus * wps;
+        float ms = time_ms([&] { hipLaunchKernelGGL(mfma4_kernel<8>, dim3(blocks), dim3(256), 0, 0, out, 1.0000001, 1e-9); });
+        const double flop = 2.0 * 4 * 4 * 4 * 4 * 8 * ITERS * 4.0 * blocks;   // 4 blocks of 4x4x4 per instruction
+        printf("v_mfma_f64_4x4x4_4b  %d waves/SIMD (8 acc): %7.3f ms  %7.2f TFLOP/s\n", wps, ms, flop / ms * 1e-9);
     }
     {
         const int blocks = cus;
