@@ -3,6 +3,7 @@
 #include "ML/Clustering.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <iterator>
 #include <limits>
 #include <numeric>
@@ -17,7 +18,7 @@ inline double squared_distance(const double* x, const double* c, Index d)
     double s = 0;
     for (Index j = 0; j < d; ++j) {
         const double t = x[j] - c[j];
-        s += t * t;
+        s = std::fma(t, t, s);   // the same fma chain as the device kernel (ml_amd/csrc/device/kmeans.hip)
     }
     return s;
 }

@@ -9,6 +9,7 @@
 #include <stdexcept>
 #include <typeinfo>
 
+#include "DeviceInit.hpp"
 #include "ML/Device.hpp"
 #include "ML/LinearAlgebra.hpp"
 #include "mlhip.h"
@@ -183,7 +184,7 @@ bool EM::fit(ConstMatrixRef data)
             // pass (strict '<', first minimum wins: ML/Clustering.cpp:77-88) on the GPU and accumulate the one-hot
             // M-step from labels -- no N x K matrix is materialised.
             MatrixXd centroids(number_dimensions, K);
-            closest->centroids_initialiser()->init(data, prng_, K, centroids);
+            Clustering::detail::init_centroids(*closest->centroids_initialiser(), data, prng_, K, centroids, ctx, dev.h);
             if (world > 1) {
                 if (rank != 0) centroids.setZero();
                 check(mlhip_ctx_allreduce(ctx, centroids.data(), static_cast<std::size_t>(centroids.size())));
@@ -204,7 +205,7 @@ bool EM::fit(ConstMatrixRef data)
         }
     } else {
         // Sensible guesses: initialiser's means, every covariance = sample covariance (ML/EM.cpp:127-135).
-        means_initialiser_->init(data, prng_, K, means_);
+        Clustering::detail::init_centroids(*means_initialiser_, data, prng_, K, means_, ctx, dev.h);
         if (world > 1) {
             if (rank != 0) means_.setZero();
             check(mlhip_ctx_allreduce(ctx, means_.data(), static_cast<std::size_t>(means_.size())));
