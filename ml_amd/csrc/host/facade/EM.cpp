@@ -110,7 +110,9 @@ const MatrixXd& EM::covariance(unsigned int k) const
 const MatrixXd& EM::responsibilities() const
 {
     if (responsibilities_on_device_ && device_data_) {
-        // Lazy device -> host copy of the N x K block (column-major, like the reference's member).
+        // Lazy device -> host copy of the N x K block (column-major, like the reference's member); the host matrix
+        // (N*K doubles, 5 GB at the headline size) is only allocated now.
+        responsibilities_.resize(static_cast<Index>(labels_.size()), number_components_);
         check(mlhip_em_responsibilities(device::context(), device_data_, number_components_, responsibilities_.data(),
                                         responsibilities_.rows()));
         responsibilities_on_device_ = false;
@@ -256,8 +258,8 @@ bool EM::fit(ConstMatrixRef data)
 
     unpack_covariances();
     process_covariances(number_dimensions);
-    // The responsibilities of the last E-step stay in HBM; responsibilities() fetches them on demand.
-    responsibilities_.resize(sample_size, K);
+    // The responsibilities of the last E-step stay in HBM; responsibilities() allocates and fetches them on demand.
+    responsibilities_.resize(0, 0);
     responsibilities_on_device_ = true;
     device_data_ = dev.release();
     return converged_;

@@ -90,6 +90,8 @@ struct mlhip_ctx {
     // scratch
     DevBuf small_dev;        // for all-reducing short host vectors through a device hook
     PinnedBuf small_host;
+    DevBuf up_stage[2];      // upload staging (kept across uploads: pinned allocations are slow)
+    PinnedBuf up_pin[2];
     // timing
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -220,17 +222,36 @@ mlhip_data* upload_common(mlhip_ctx* ctx, const double* x, bool on_device, uint3
         if (on_device) {
             launch_transpose_to_dim_major(x, ld, dt->d, n, dt->xt.as<double>(), dt->ldx, 0, ctx->stream);
         } else {
-            const uint64_t chunk = 1u << 20;
-            DevBuf stage;
-            stage.reserve(sizeof(double) * d * (n < chunk ? (n ? n : 1) : chunk));
-            for (uint64_t i0 = 0; i0 < n; i0 += chunk) {
-                const uint64_t c = (n - i0 < chunk) ? n - i0 : chunk;
-                HIP_CHECK(hipMemcpy2DAsync(stage.p, sizeof(double) * d, x + (int64_t)i0 * ld, sizeof(double) * ld,
-                                           sizeof(double) * d, c, hipMemcpyHostToDevice, ctx->stream));
-                launch_transpose_to_dim_major(stage.as<double>(), d, dt->d, c, dt->xt.as<double>(), dt->ldx, i0, ctx->stream);
-                ctx->sync();   // the staging buffer is reused
+            // Pageable host memory: the caller's block is packed into two pinned staging buffers by the CPU (this also
+            // removes the ld > d padding) while the previous chunk's H2D copy + transpose run on the stream. A direct
+            // hipMemcpy from pageable memory reaches only ~3 GB/s on this platform; pinned chunks go at PCIe rate.
+            const uint64_t chunk = 1u << 19;                       // samples per chunk (128 MB at d = 32)
+            const uint64_t cap = n < chunk ? (n ? n : 1) : chunk;
+            DevBuf* stage = ctx->up_stage;
+            PinnedBuf* pin = ctx->up_pin;
+            hipEvent_t done[2];
+            for (int b = 0; b < 2; ++b) {
+                stage[b].reserve(sizeof(double) * d * cap);
+                pin[b].reserve(sizeof(double) * d * cap);
+                HIP_CHECK(hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
             }
-            stage.release();
+            int b = 0;
+            for (uint64_t i0 = 0; i0 < n; i0 += chunk, b ^= 1) {
+                const uint64_t c = (n - i0 < chunk) ? n - i0 : chunk;
+                if (i0 >= 2 * chunk) HIP_CHECK(hipEventSynchronize(done[b]));   // staging pair b is free again
+                double* dst = pin[b].as<double>();
+                const double* src = x + (int64_t)i0 * ld;
+                if (ld == (int64_t)d) {
+                    std::memcpy(dst, src, sizeof(double) * d * c);
+                } else {
+                    for (uint64_t i = 0; i < c; ++i) std::memcpy(dst + i * d, src + (int64_t)i * ld, sizeof(double) * d);
+                }
+                HIP_CHECK(hipMemcpyAsync(stage[b].p, dst, sizeof(double) * d * c, hipMemcpyHostToDevice, ctx->stream));
+                launch_transpose_to_dim_major(stage[b].as<double>(), d, dt->d, c, dt->xt.as<double>(), dt->ldx, i0, ctx->stream);
+                HIP_CHECK(hipEventRecord(done[b], ctx->stream));
+            }
+            ctx->sync();
+            for (int k = 0; k < 2; ++k) (void)hipEventDestroy(done[k]);
         }
         finish_upload(dt);
     } catch (...) {
@@ -488,6 +509,7 @@ int mlhip_ctx_destroy(mlhip_ctx* ctx)
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
         ctx->small_dev.release();
         ctx->small_host.release();
+        for (int b = 0; b < 2; ++b) { ctx->up_stage[b].release(); ctx->up_pin[b].release(); }
         if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
         if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
