@@ -46,6 +46,10 @@ void process_covariance(int d, const double* cov, double* inverse, double* sqrt_
 }
 
 namespace {
+/// Threads used for the K independent per-component d x d factorizations (serial section of an EM iteration: every
+/// microsecond here is paid by all GPUs of a row-sharded job).
+constexpr int kHostThreads = 8;
+
 /// W = L^-1 (lower triangular, column-major d x d) and sum_j log L_jj for one covariance.
 double whitening_matrix(int d, const double* cov, std::vector<double>& L, std::vector<double>& W)
 {
@@ -93,7 +97,10 @@ void build_estep_params_mfma4(int d, int D, int K, const double* mixing, const d
     const int PS = estep_mfma4_param_stride(D);
     const int NB = estep_mfma4_block_count(D);
     const int Q = D / 4;
+#pragma omp parallel num_threads(kHostThreads) if (K >= 8)
+    {
     std::vector<double> L((size_t)d * d), W((size_t)d * d);
+#pragma omp for schedule(static)
     for (int k = 0; k < K; ++k) {
         double* rec = records + (size_t)k * PS;
         for (int i = 0; i < PS; ++i) rec[i] = 0.0;
@@ -108,6 +115,7 @@ void build_estep_params_mfma4(int d, int D, int K, const double* mixing, const d
                     }
         for (int j = 0; j < d; ++j) rec[NB * 16 + j] = means[(size_t)k * d + j];
         rec[NB * 16 + D] = std::log(mixing[k]) - log_det_half;
+    }
     }
 }
 
@@ -132,7 +140,10 @@ void finalize_mstep(int d, int K, const double* stats, const double* shift, doub
                     double* means, double* covariances)
 {
     const int F = stats_count(d);
+#pragma omp parallel num_threads(kHostThreads) if (K >= 8)
+    {
     std::vector<double> m(d);
+#pragma omp for schedule(static)
     for (int k = 0; k < K; ++k) {
         const double* s = stats + (size_t)k * F;
         const double s0 = s[stats_index(d, d)];
@@ -150,6 +161,7 @@ void finalize_mstep(int d, int K, const double* stats, const double* shift, doub
         static constexpr double epsilon = 1e-15;   // ML/EM.cpp:252
         for (int a = 0; a < d; ++a) cov[a * d + a] += epsilon;
         mixing[k] = s0 / n_global;                 // ML/EM.cpp:257
+    }
     }
 }
 

@@ -7,7 +7,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -167,6 +169,20 @@ namespace {
 using namespace mlhip;
 
 constexpr int kMaxLlPartials = 2048;
+
+/// MLHIP_TRACE=1: wall-clock microseconds of the host-visible phases of one EM iteration on stderr.
+struct PhaseTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    PhaseTrace() : on([] { const char* e = std::getenv("MLHIP_TRACE"); return e && e[0] == '1'; }()), t(std::chrono::steady_clock::now()) {}
+    void mark(const char* name)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[mlhip] %-22s %8.1f us\n", name, std::chrono::duration<double, std::micro>(now - t).count());
+        t = now;
+    }
+};
 
 void require(bool ok, const char* msg) { if (!ok) throw InvalidArgument(msg); }
 
@@ -631,10 +647,14 @@ int mlhip_em_step(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* mi
     return guarded([&] {
         check_em_args(ctx, data, K);
         require(mixing && means && covariances && log_likelihood && mixing_out && means_out && covariances_out, "null argument");
+        PhaseTrace tr;
         run_estep(data, (int)K, mixing, means, covariances);
+        tr.mark("params+launch E");
         run_mstats(data, (int)K, kFromLogResp, nullptr, 0, true);
+        tr.mark("M launch+sync+D2H");
         *log_likelihood = ll_from_stats(data, (int)K);
         finalize_out(data, (int)K, mixing_out, means_out, covariances_out);
+        tr.mark("closing arithmetic");
     });
 }
 
