@@ -170,8 +170,18 @@ __global__ __launch_bounds__(256) void em_reduce_kernel(const double* __restrict
         if (e < total) {
             const int k = e / F, f = e - k * F;
             const double* p = partials + (size_t)k * FP + f;
+            // same left-to-right order as a plain loop, but 16 loads are issued before the adds consume them
+            // (a dependent load->add chain over 256 partials is latency-bound: ~80 us).
             double s = 0.0;
-            for (int b = 0; b < n_blocks; ++b) s += p[(size_t)b * KP * FP];
+            int b = 0;
+            for (; b + 16 <= n_blocks; b += 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = p[(size_t)(b + u) * KP * FP];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s += v[u];
+            }
+            for (; b < n_blocks; ++b) s += p[(size_t)b * KP * FP];
             stats[e] = s;
         }
     } else {
