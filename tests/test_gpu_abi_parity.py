@@ -228,3 +228,40 @@ def test_bad_arguments(ctx):
     with pytest.raises(_lib.MlhipError):
         _lib.Data(ctx, np.zeros((10, 33)))   # d > 32 unsupported (yet)
     dt.close()
+
+
+@pytest.mark.parametrize("d,K", [(12, 7), (16, 16), (20, 5), (24, 9), (28, 3), (32, 64)])
+def test_estep_kernel_variants_agree(ctx, oracle, d, K, monkeypatch):
+    """The three E-step kernels that exist for d in 12..32 (4x4x4 MFMA = default, 16x16x4 MFMA, scalar-fed VALU) compute the
+    same log-likelihood / responsibilities / labels; the default one is also checked against the oracle."""
+    rng = np.random.default_rng(d * 100 + K)
+    n = 3000
+    means = 2.5 * rng.standard_normal((K, d))
+    X = np.ascontiguousarray(means[rng.integers(0, K, n)] + rng.standard_normal((n, d)))
+    mu0 = means + 0.3 * rng.standard_normal((K, d))
+    S0 = np.stack([np.cov(X.T) * rng.uniform(0.2, 0.6) + 0.1 * np.eye(d) for _ in range(K)])
+    pi0 = rng.dirichlet(np.ones(K) * 5)
+    out = {}
+    for variant in ("", "mfma16", "valu"):
+        if variant:
+            monkeypatch.setenv("MLHIP_ESTEP", variant)
+        else:
+            monkeypatch.delenv("MLHIP_ESTEP", raising=False)
+        dt = _data(ctx, X)
+        ll = dt.em_expectation(pi0, mu0, S0)
+        out[variant] = (ll, dt.em_responsibilities(K), dt.em_labels(K), dt.em_maximisation(K))
+        dt.close()
+    monkeypatch.delenv("MLHIP_ESTEP", raising=False)
+    em = oracle.EM(K)
+    em.set_parameters(mu0, S0, pi0)
+    em.expectation_step(X)
+    ll0, R0, lab0, m0 = out[""]
+    assert abs(ll0 - em.log_likelihood) <= 1e-12 * abs(em.log_likelihood)
+    assert np.max(np.abs(R0 - em.responsibilities)) < 1e-12
+    for variant in ("mfma16", "valu"):
+        ll, R, lab, m = out[variant]
+        assert abs(ll - ll0) <= 1e-13 * abs(ll0)
+        assert np.max(np.abs(R - R0)) < 1e-12
+        assert np.array_equal(lab, lab0)
+        for a, b in zip(m, m0):
+            assert np.max(np.abs(a - b)) <= 1e-11 * np.max(np.abs(b))
