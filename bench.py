@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--components", type=int, default=COMPONENTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=200_000)
+    ap.add_argument("--force-hook", action="store_true",
+                    help="(diagnostic) single rank, but with the torch.distributed/RCCL all-reduce hook installed")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -77,6 +79,9 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif args.force_hook:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29544", rank=0, world_size=1,
+                                device_id=torch.device("cuda", local_rank))
 
     n, d, K = args.n, args.dim, args.components
     lo, hi = mldist.shard_bounds(n, world, rank)
@@ -84,7 +89,7 @@ def main():
     X, _ = mix.sample(hi - lo, stream=rank)
 
     ctx = _lib.Context(local_rank)
-    if world > 1:
+    if world > 1 or args.force_hook:
         mldist.install_allreduce(ctx, world, rank)
     data = _lib.Data(ctx, X)
     del X
@@ -169,7 +174,7 @@ def main():
         print(json.dumps(out))
     data.close()
     ctx.close()
-    if world > 1:
+    if world > 1 or args.force_hook:
         dist.destroy_process_group()
 
 

@@ -8,7 +8,7 @@ Conventions kept from the reference:
   * `KMeans.labels` is a Python list (pybind11/stl.h conversion, clustering.cpp:173);
   * std::invalid_argument / std::domain_error surface as ValueError.
 Extensions (not in the reference surface): `EM.labels`, `EM.converged`, `EM.steps_done`, `KMeans.converged`,
-`KMeans.steps_done`, `FixedCentroids`.
+`KMeans.steps_done`, `KMeans.labels_array`, `FixedCentroids`.
 """
 import ctypes as C
 
@@ -331,6 +331,15 @@ class KMeans:
         out = np.empty(n, dtype=np.uint32)
         _check(_l.mlpp_kmeans_labels(self._h, _lib.u32ptr(out)))
         return out.tolist()
+
+    @property
+    def labels_array(self):
+        """Extension: the fitted labels as a numpy uint32 array (the reference surface converts to a Python list, which
+        costs seconds and gigabytes at N = 1e8)."""
+        _, n = self._dims()
+        out = np.empty(n, dtype=np.uint32)
+        _check(_l.mlpp_kmeans_labels(self._h, _lib.u32ptr(out)))
+        return out
 
     @property
     def inertia(self):

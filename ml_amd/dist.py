@@ -26,14 +26,26 @@ class _DeviceBuffer:
         self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
 
 
+_tensor_cache = {}   # (ptr, count) -> zero-copy tensor view of a library-owned device buffer (stable across iterations)
+_stream_cache = {}
+
+
 def allreduce_sum(ptr, count, on_device, stream, group=None):
     """In-place sum over ranks of `count` doubles at `ptr` (device or host memory)."""
     import torch
     import torch.distributed as dist
     if on_device:
-        ext = torch.cuda.ExternalStream(stream) if stream else torch.cuda.current_stream()
+        ext = _stream_cache.get(stream)
+        if ext is None:
+            ext = torch.cuda.ExternalStream(stream) if stream else torch.cuda.current_stream()
+            _stream_cache[stream] = ext
+        t = _tensor_cache.get((ptr, count))
         with torch.cuda.stream(ext):
-            t = torch.as_tensor(_DeviceBuffer(ptr, count), device="cuda")
+            if t is None:
+                t = torch.as_tensor(_DeviceBuffer(ptr, count), device="cuda")
+                if len(_tensor_cache) > 64:
+                    _tensor_cache.clear()
+                _tensor_cache[(ptr, count)] = t
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         ext.synchronize()
     else:
