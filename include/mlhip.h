@@ -116,6 +116,11 @@ int mlhip_em_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, uint32_t* labe
  * ML/EM.cpp:265-272). mean may be NULL. */
 int mlhip_sample_covariance(mlhip_ctx* ctx, mlhip_data* data, double* mean, double* covariance);
 
+/* X X^T (d x d, column-major) and X y (d) over ALL ranks' samples in one pass over the resident block: the dense
+ * contraction of LinearRegression::calculate_XXt_beta (ML/LinearRegression.cpp:213-215), the "next" row f4 of SURVEY.md
+ * section 8. `y` holds this rank's n_local target values. Runs on the statistics kernel (two weight rows: 1 and y). */
+int mlhip_xxt_xy(mlhip_ctx* ctx, mlhip_data* data, const double* y, double* xxt, double* xy);
+
 /* Host helpers, no GPU needed: the layout of the all-reduced sufficient statistics and the M-step closing
  * arithmetic applied to them (ML/EM.cpp:242, 250-257). Per component, F = (d+1)(d+2)/2 doubles: the packed lower
  * triangle (row-major: entry (a,b), a >= b, at a(a+1)/2 + b) of  sum_i r_ik xt_i xt_i^T  with

@@ -83,6 +83,10 @@ int mlpp_xAx_symmetric(const double* A, uint32_t rows, uint32_t cols, const doub
 int mlpp_xxT(const double* x, uint32_t n, double* dest /* n x n */);
 int mlpp_add_a_xxT(const double* x, uint32_t n, double* dest, uint32_t drows, uint32_t dcols, double a);
 
+/* ---- LinearRegression::calculate_XXt_beta (ML/LinearRegression.hpp:412): X is N x q row-major == q x N column-major ---- */
+int mlpp_calculate_XXt_beta(const double* X, uint64_t n, uint32_t q, const double* y, uint64_t ylen, const double* lambda,
+                            uint32_t lambda_len, double* XXt /* q x q */, double* beta /* q */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -275,6 +275,19 @@ class Data:
         return out
 
 
+def calculate_XXt_beta(X, y, lam):
+    """ml::LinearRegression::calculate_XXt_beta on an N x q float64 C-contiguous X: returns (XXt + diag(lam), beta)."""
+    if not (isinstance(X, np.ndarray) and X.dtype == np.float64 and X.ndim == 2 and X.flags.c_contiguous):
+        raise TypeError("X must be a C-contiguous float64 N x q numpy array")
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    lam = np.ascontiguousarray(lam, dtype=np.float64)
+    n, q = X.shape
+    XXt, beta = np.empty((q, q)), np.empty(q)
+    check(lib.mlpp_calculate_XXt_beta(dptr(X), C.c_uint64(n), q, dptr(y), C.c_uint64(y.size), dptr(lam), lam.size,
+                                      dptr(XXt), dptr(beta)))
+    return XXt, beta
+
+
 def process_covariance(cov):
     cov = np.ascontiguousarray(cov, dtype=np.float64)
     d = cov.shape[0]

@@ -757,6 +757,38 @@ int mlhip_sample_covariance(mlhip_ctx* ctx, mlhip_data* data, double* mean, doub
     });
 }
 
+int mlhip_xxt_xy(mlhip_ctx* ctx, mlhip_data* data, const double* y, double* xxt, double* xy)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, 2);
+        require(y && xxt && xy, "null argument");
+        ensure_em_workspace(data, 2);
+        data->have_estep = false;
+        // weight rows: [0] = 1 (valid samples), [1] = y; the statistics kernel then yields, about the shift s,
+        //   component 0: N, sum (x - s), sum (x - s)(x - s)^T      component 1: sum y, sum y (x - s)
+        double* w = data->lw.as<double>();
+        launch_fill_responsibilities(nullptr, data->n, 1, w, data->ldr, ctx->stream);
+        HIP_CHECK(hipMemsetAsync(w + data->ldr, 0, sizeof(double) * data->ldr, ctx->stream));
+        if (data->n)
+            HIP_CHECK(hipMemcpyAsync(w + data->ldr, y, sizeof(double) * data->n, hipMemcpyHostToDevice, ctx->stream));
+        run_mstats(data, 2, kFromResp, w, data->ldr, false);
+        const int d = data->d, F = stats_count(d);
+        const double* s0 = data->stats_host.as<double>();
+        const double* s1 = s0 + F;
+        const double* sh = data->shift.data();
+        const double n = s0[stats_index(d, d)], sum_y = s1[stats_index(d, d)];
+        for (int a = 0; a < d; ++a) {
+            xy[a] = s1[stats_index(d, a)] + sh[a] * sum_y;
+            for (int b = 0; b <= a; ++b) {
+                const double v = s0[stats_index(a, b)] + sh[a] * s0[stats_index(d, b)] + s0[stats_index(d, a)] * sh[b] +
+                                 n * sh[a] * sh[b];
+                xxt[(size_t)b * d + a] = v;
+                xxt[(size_t)a * d + b] = v;
+            }
+        }
+    });
+}
+
 int mlhip_em_statistics_count(uint32_t d, uint32_t* count_per_component)
 {
     return guarded([&] {

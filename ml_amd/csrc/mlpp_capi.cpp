@@ -12,6 +12,7 @@
 #include "ML/EM.hpp"
 #include "ML/KMeans.hpp"
 #include "ML/LinearAlgebra.hpp"
+#include "ML/LinearRegression.hpp"
 #include "mlhip.h"
 
 extern "C" void mlhip_set_last_error_(const char* msg);   // defined in mlhip_abi.cpp
@@ -186,6 +187,18 @@ int mlpp_add_a_xxT(const double* x, uint32_t n, double* dest, uint32_t drows, ui
         std::copy_n(dest, static_cast<std::size_t>(drows) * dcols, m.data());
         LinearAlgebra::add_a_xxT(v, m, a);
         std::copy_n(m.data(), m.size(), dest);
+    });
+}
+
+int mlpp_calculate_XXt_beta(const double* X, uint64_t n, uint32_t q, const double* y, uint64_t ylen, const double* lambda,
+                            uint32_t lambda_len, double* XXt, double* beta)
+{
+    return guarded([&] {
+        need(X); need(y); need(lambda); need(XXt); need(beta);
+        const VectorXd b = LinearRegression::calculate_XXt_beta(ConstMatrixRef(X, q, static_cast<Index>(n)),
+                                                                ConstVectorRef(y, static_cast<Index>(ylen)),
+                                                                MatrixRef(XXt, q, q, q), ConstVectorRef(lambda, lambda_len));
+        std::copy_n(b.data(), b.size(), beta);
     });
 }
 

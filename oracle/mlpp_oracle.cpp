@@ -94,6 +94,53 @@ void add_a_xxT(const double* x, std::size_t n, Mat& dest, const double a)
 }
 
 // =================================================================================================
+// ML/LinearRegression.cpp:201-230
+// =================================================================================================
+std::vector<double> calculate_XXt_beta(const DataView& X, const double* y, std::size_t ylen, Mat& XXt,
+                                       const double* lambda, std::size_t lambda_len)
+{
+    const std::size_t n = X.n, q = X.d;
+    double min_lambda = lambda_len ? lambda[0] : 0.0;
+    for (std::size_t i = 1; i < lambda_len; ++i) min_lambda = std::min(min_lambda, lambda[i]);
+    if (min_lambda < 0) throw std::domain_error("Ridge regularisation constant cannot be negative");          // :206-208
+    if (lambda_len != q) throw std::invalid_argument("Lambda vector must have the same size as the number of features");
+    if (n != ylen) throw std::invalid_argument("X matrix has different number of data points than Y has values");
+    if (n < q) throw std::invalid_argument("Not enough data points for regression");
+    std::vector<double> b(q, 0.0);                                      // :218  b = X * y  [eigen-order]
+    for (std::size_t i = 0; i < n; ++i)
+        for (std::size_t a = 0; a < q; ++a) b[a] += X.col(i)[a] * y[i];
+    XXt = Mat(q, q, 0.0);                                               // :220  XXt = X * X^T  [eigen-order]
+    for (std::size_t i = 0; i < n; ++i) {
+        const double* x = X.col(i);
+        for (std::size_t c = 0; c < q; ++c)
+            for (std::size_t a = 0; a < q; ++a) XXt(a, c) += x[a] * x[c];
+    }
+    if (min_lambda != 0)                                                // :221-225 `if (lambda.minCoeff())`: the ridge is
+        for (std::size_t i = 0; i < q; ++i) XXt(i, i) += lambda[i];     //   skipped altogether when its smallest entry is 0
+    // :228-229 xxt_decomp.compute(XXt); solve(b)  -- LDL^T; unpivoted here (the matrices used are positive definite)
+    Mat L(q, q, 0.0);
+    std::vector<double> D(q);
+    for (std::size_t j = 0; j < q; ++j) {
+        double dj = XXt(j, j);
+        for (std::size_t l = 0; l < j; ++l) dj -= L(j, l) * L(j, l) * D[l];
+        D[j] = dj;
+        L(j, j) = 1;
+        for (std::size_t i = j + 1; i < q; ++i) {
+            double t = XXt(i, j);
+            for (std::size_t l = 0; l < j; ++l) t -= L(i, l) * L(j, l) * D[l];
+            L(i, j) = t / dj;
+        }
+    }
+    std::vector<double> beta(b);
+    for (std::size_t i = 0; i < q; ++i)
+        for (std::size_t l = 0; l < i; ++l) beta[i] -= L(i, l) * beta[l];
+    for (std::size_t i = 0; i < q; ++i) beta[i] /= D[i];
+    for (std::size_t i = q; i-- > 0;)
+        for (std::size_t l = i + 1; l < q; ++l) beta[i] -= L(l, i) * beta[l];
+    return beta;
+}
+
+// =================================================================================================
 // ML/Clustering.cpp
 // =================================================================================================
 

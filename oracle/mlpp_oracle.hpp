@@ -37,6 +37,11 @@ double xAx_symmetric(const Mat& A, const double* x, std::size_t xlen);   // :8-3
 void xxT(const double* x, std::size_t n, Mat& dest);                     // :33-52
 void add_a_xxT(const double* x, std::size_t n, Mat& dest, double a);     // :54-73
 
+// ---- ML/LinearRegression.cpp (the dense helper that shares the covariance contraction: SURVEY section 8 row f4) ----
+/// :201-230. X is q x N (DataView), y has N entries; XXt receives X X^T + diag(lambda); returns beta.
+std::vector<double> calculate_XXt_beta(const DataView& X, const double* y, std::size_t ylen, Mat& XXt,
+                                       const double* lambda, std::size_t lambda_len);
+
 // ---- ML/Clustering.cpp ----------------------------------------------------------------------
 struct CentroidsInitialiser {
     virtual ~CentroidsInitialiser() = default;

@@ -70,6 +70,17 @@ int orc_add_a_xxT(const double* x, unsigned n, double* dest, unsigned drows, uns
     });
 }
 
+int orc_calculate_XXt_beta(const double* X, unsigned q, unsigned n, const double* y, unsigned ylen, const double* lambda,
+                           unsigned lambda_len, double* XXt, double* beta)
+{
+    return guarded([&] {
+        Mat m;
+        const auto b = calculate_XXt_beta(DataView{X, q, n, q}, y, ylen, m, lambda, lambda_len);
+        std::copy(m.a.begin(), m.a.end(), XXt);
+        std::copy(b.begin(), b.end(), beta);
+    });
+}
+
 // ---- initialisers (seeded std::default_random_engine, like a freshly seeded model) ----------------
 // kind: 0 Forgy, 1 RandomPartition, 2 KPP. seed_set==0 -> default-constructed engine.
 int orc_init_centroids(int kind, const double* x, unsigned d, unsigned n, unsigned ld, unsigned K,

@@ -81,6 +81,17 @@ def add_a_xxT(x, dest, a):
     return out
 
 
+def calculate_XXt_beta(X, y, lam):
+    """X: N x q (rows = data points), y: N, lam: q. Returns (XXt q x q, beta q)."""
+    X = _as_data(X)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    lam = np.ascontiguousarray(lam, dtype=np.float64)
+    n, q = X.shape
+    XXt, beta = np.empty((q, q)), np.empty(q)
+    _check(lib.orc_calculate_XXt_beta(_d(X), q, n, _d(y), y.size, _d(lam), lam.size, _d(XXt), _d(beta)))
+    return XXt, beta
+
+
 def init_centroids(kind, data, K, seed=None):
     """Returns K x d (row-major view of the d x K column-major result)."""
     data = _as_data(data)
