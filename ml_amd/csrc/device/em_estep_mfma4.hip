@@ -146,10 +146,14 @@ __global__ __launch_bounds__(256, 2) void em_estep_mfma4_kernel(const double* __
             const double q = reduce_scatter_groups(qs[0], qs[1], qs[2], qs[3]);   // lane (g, s) gets sample 16g + s
             const double lw = __builtin_fma(-0.5, q, coef);
             lw_out[(size_t)k * ldr + base + lane] = lw;
-            const double e = exp(-fabs(lw - m));
-            const bool up = lw > m;
-            ssum = up ? __builtin_fma(ssum, e, 1.0) : ssum + e;
-            m = up ? lw : m;
+            // exp(t) is exactly 0 in fp64 for t < -745.2: when that holds for the whole wave the update would add 0 to
+            // every ssum and leave every m unchanged, so it is skipped (bit-identical result, one exp saved).
+            if (!__all(lw - m < -746.0)) {
+                const double e = exp(-fabs(lw - m));
+                const bool up = lw > m;
+                ssum = up ? __builtin_fma(ssum, e, 1.0) : ssum + e;
+                m = up ? lw : m;
+            }
             // publish record k+1 in the other buffer: nobody reads it now (last read during k-1, before this
             // iteration's barrier), the next iteration's barrier makes it visible.
 #pragma unroll
