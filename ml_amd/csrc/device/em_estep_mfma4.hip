@@ -14,6 +14,8 @@
 // With j + 4b = sample-in-16 this is the B / D layout of the 16x16x4 kernel (lane & 15 = sample, lane >> 4 = k or row),
 // so the coordinates stay in VGPRs as xb[column quad][sample block], every accumulator is ONE double per lane
 // (acc[sample block][row quad]) and the |y|^2 reduce-scatter / log-domain epilogue are unchanged.
+#include <cstdlib>
+
 #include "device.hpp"
 
 namespace mlhip {
@@ -63,44 +65,48 @@ __device__ __forceinline__ double reduce_scatter_groups(double v0, double v1, do
     return t01 + t23;
 }
 
-template <int D>
-__global__ __launch_bounds__(256, 2) void em_estep_mfma4_kernel(const double* __restrict__ xt, size_t ldx, uint32_t n,
-                                                                 uint32_t n_groups, const double* __restrict__ params,
-                                                                 int K, double* __restrict__ lw_out, size_t ldr,
-                                                                 double* __restrict__ lse_out,
-                                                                 double* __restrict__ ll_partials)
+/// SB = 16-sample blocks per wave (4: 64 samples per wave, 4 waves per workgroup, 2 waves per SIMD; 2: 32 samples per
+/// wave, 8 waves per workgroup, half the coordinate/accumulator registers -> 4 waves per SIMD). A workgroup always
+/// covers 256 samples per component sweep, so the record staging traffic is the same.
+template <int D, int SB>
+__global__ __launch_bounds__(1024 / SB, 8 / SB) void em_estep_mfma4_kernel(
+    const double* __restrict__ xt, size_t ldx, uint32_t n, uint32_t n_groups, const double* __restrict__ params, int K,
+    double* __restrict__ lw_out, size_t ldr, double* __restrict__ lse_out, double* __restrict__ ll_partials)
 {
     using B = Blocks<D>;
     constexpr int Q = B::Q, NB = B::NB, PS = B::PS;
+    constexpr int NT = 1024 / SB, NWV = NT / 64;   // threads / waves per workgroup
+    constexpr int GS = 16 * SB;                    // samples per wave
     constexpr int W = 4;                           // LDS read-ahead window (blocks)
-    constexpr int NLD = (PS + 255) / 256;          // doubles of a record each thread moves to LDS
-    __shared__ double red[4];
-    __shared__ double recs[2][NLD * 256];          // the component record, staged once per workgroup, double-buffered
+    constexpr int NLD = (PS + NT - 1) / NT;        // doubles of a record each thread moves to LDS
+    __shared__ double red[NWV];
+    __shared__ double recs[2][NLD * NT];           // the component record, staged once per workgroup, double-buffered
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, s = lane & 15;
     const int aoff = g * 4 + (lane & 3);          // A operand: entry [k = lane>>4][i = lane&3] of a 16-double block
+    const bool owner = g < SB;                    // lane (g, s) owns sample 16g + s of the wave's group
     double ll_acc = 0.0;
 
-    // The 4 waves of a workgroup walk the components in lockstep (they share the staged record), each on its own
-    // 64-sample group: a workgroup iteration covers 4 consecutive groups (n_groups is a multiple of 4).
-    for (uint32_t grp = blockIdx.x * 4 + wave; grp < n_groups; grp += gridDim.x * 4) {
-        const uint32_t base = grp * 64;
+    // The waves of a workgroup walk the components in lockstep (they share the staged record), each on its own
+    // GS-sample group: a workgroup iteration covers NWV consecutive groups = 256 samples (n_pad is a multiple of 256).
+    for (uint32_t grp = blockIdx.x * NWV + wave; grp < n_groups; grp += gridDim.x * NWV) {
+        const uint32_t base = grp * GS;
         // coordinates in B-operand layout: xb[C][sb] = x[dim 4C + g][sample base + 16sb + s]
-        double xb[Q][4];
+        double xb[Q][SB];
 #pragma unroll
         for (int C = 0; C < Q; ++C)
 #pragma unroll
-            for (int sb = 0; sb < 4; ++sb) xb[C][sb] = xt[(size_t)(4 * C + g) * ldx + base + 16 * sb + s];
+            for (int sb = 0; sb < SB; ++sb) xb[C][sb] = xt[(size_t)(4 * C + g) * ldx + base + 16 * sb + s];
 
         double m = -__builtin_inf(), ssum = 0.0;
 
         // record 0 -> LDS buffer 0 (the barrier at the top of the component loop publishes it)
         double stage[NLD];
 #pragma unroll
-        for (int it = 0; it < NLD; ++it) stage[it] = params[min(tid + 256 * it, PS - 1)];
+        for (int it = 0; it < NLD; ++it) stage[it] = params[min(tid + NT * it, PS - 1)];
         __syncthreads();                            // everyone is done with the previous group's last record
 #pragma unroll
-        for (int it = 0; it < NLD; ++it) recs[0][tid + 256 * it] = stage[it];
+        for (int it = 0; it < NLD; ++it) recs[0][tid + NT * it] = stage[it];
 
         for (int k = 0; k < K; ++k) {
             const double* __restrict__ rec = recs[k & 1];
@@ -108,10 +114,10 @@ __global__ __launch_bounds__(256, 2) void em_estep_mfma4_kernel(const double* __
             // record k+1: global -> registers now (in flight during the MFMA phase), registers -> LDS at the end
             const double* __restrict__ nxt = params + (size_t)(k + 1 < K ? k + 1 : k) * PS;
 #pragma unroll
-            for (int it = 0; it < NLD; ++it) stage[it] = nxt[min(tid + 256 * it, PS - 1)];
+            for (int it = 0; it < NLD; ++it) stage[it] = nxt[min(tid + NT * it, PS - 1)];
 
             const double coef = rec[NB * 16 + D];
-            double aw[W], acc[4][Q], z[4];
+            double aw[W], acc[SB][Q], z[SB];
 #pragma unroll
             for (int t = 0; t < W && t < NB; ++t) aw[t] = rec[t * 16 + aoff];
             // Nested static loops (column quad C, then row quad R >= C): every index below is a compile-time constant
@@ -125,27 +131,41 @@ __global__ __launch_bounds__(256, 2) void em_estep_mfma4_kernel(const double* __
                     const double a = aw[t % W];
                     if (R == C) {
 #pragma unroll
-                        for (int sb = 0; sb < 4; ++sb) z[sb] = xb[C][sb] - mu;
+                        for (int sb = 0; sb < SB; ++sb) z[sb] = xb[C][sb] - mu;
                     }
                     if (t + W < NB) aw[t % W] = rec[(t + W) * 16 + aoff];   // refill the slot (LDS broadcast read)
 #pragma unroll
-                    for (int sb = 0; sb < 4; ++sb)
+                    for (int sb = 0; sb < SB; ++sb)
                         acc[sb][R] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, z[sb], C == 0 ? 0.0 : acc[sb][R], 0, 0, 0);
-                    // Pin the block order (column-quad major, the 4 sample blocks back to back); see em_estep_mfma.hip.
+                    // Pin the block order (column-quad major, the sample blocks back to back); see em_estep_mfma.hip.
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            double qs[4];
+            double qs[SB];
 #pragma unroll
-            for (int sb = 0; sb < 4; ++sb) {
+            for (int sb = 0; sb < SB; ++sb) {
                 double t2 = 0.0;
 #pragma unroll
                 for (int R = 0; R < Q; ++R) t2 = __builtin_fma(acc[sb][R], acc[sb][R], t2);
                 qs[sb] = t2;
             }
-            const double q = reduce_scatter_groups(qs[0], qs[1], qs[2], qs[3]);   // lane (g, s) gets sample 16g + s
+            double q;
+            if constexpr (SB == 4) {
+                q = reduce_scatter_groups(qs[0], qs[1], qs[2], qs[3]);   // lane (g, s) gets sample 16g + s
+            } else {
+                // two blocks: rows g, g^1 exchange so that even rows hold block 0 and odd rows block 1, then the two
+                // halves are summed; lanes (g, s) with g < 2 own sample 16g + s, g >= 2 hold duplicates.
+                double v0 = qs[0], v1 = qs[1];
+                const unsigned alo = __double2loint(v0), ahi = __double2hiint(v0), blo = __double2loint(v1), bhi = __double2hiint(v1);
+                const auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+                const auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+                v0 = __hiloint2double((int)hi[0], (int)lo[0]);
+                v1 = __hiloint2double((int)hi[1], (int)lo[1]);
+                const double t = v0 + v1;                  // even rows: block 0 over the pair, odd rows: block 1
+                q = t + __shfl_xor(t, 32, 64);
+            }
             const double lw = __builtin_fma(-0.5, q, coef);
-            lw_out[(size_t)k * ldr + base + lane] = lw;
+            if (owner) lw_out[(size_t)k * ldr + base + lane] = lw;
             // exp(t) is exactly 0 in fp64 for t < -745.2: when that holds for the whole wave the update would add 0 to
             // every ssum and leave every m unchanged, so it is skipped (bit-identical result, one exp saved).
             if (!__all(lw - m < -746.0)) {
@@ -157,30 +177,46 @@ __global__ __launch_bounds__(256, 2) void em_estep_mfma4_kernel(const double* __
             // publish record k+1 in the other buffer: nobody reads it now (last read during k-1, before this
             // iteration's barrier), the next iteration's barrier makes it visible.
 #pragma unroll
-            for (int it = 0; it < NLD; ++it) recs[(k + 1) & 1][tid + 256 * it] = stage[it];
+            for (int it = 0; it < NLD; ++it) recs[(k + 1) & 1][tid + NT * it] = stage[it];
         }
         const double lse = m + log(ssum);
-        lse_out[base + lane] = lse;
-        if (base + lane < n) ll_acc += lse;
+        if (owner) {
+            lse_out[base + lane] = lse;
+            if (base + lane < n) ll_acc += lse;
+        }
     }
     ll_acc = wave_sum(ll_acc);
     if (lane == 0) red[wave] = ll_acc;
     __syncthreads();
-    if (threadIdx.x == 0) ll_partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) t += red[w];
+        ll_partials[blockIdx.x] = t;
+    }
+}
+
+template <int D, int SB>
+int launch_sb(const EstepArgs& a, int num_cus, hipStream_t stream)
+{
+    constexpr int NT = 1024 / SB, NWV = NT / 64, GS = 16 * SB;
+    const uint32_t n_pad = (a.n + kSampleTile - 1) / kSampleTile * kSampleTile;
+    const uint32_t n_groups = n_pad / GS;
+    uint32_t grid = (n_groups + NWV - 1) / NWV;
+    const uint32_t cap = (uint32_t)num_cus * 2;          // 2 workgroups per CU, persistent
+    if (grid > cap) grid = cap;
+    if (grid > (uint32_t)a.n_ll_partials) grid = (uint32_t)a.n_ll_partials;
+    hipLaunchKernelGGL((em_estep_mfma4_kernel<D, SB>), dim3(grid), dim3(NT), 0, stream, a.xt, a.ldx, a.n, n_groups, a.params,
+                       a.K, a.lw, a.ldr, a.lse, a.ll_partials);
+    return (int)grid;
 }
 
 template <int D>
 int launch_t(const EstepArgs& a, int num_cus, hipStream_t stream)
 {
-    const uint32_t n_pad = (a.n + kSampleTile - 1) / kSampleTile * kSampleTile;
-    const uint32_t n_groups = n_pad / 64;
-    uint32_t grid = (n_groups + 3) / 4;
-    const uint32_t cap = (uint32_t)num_cus * 2;          // 2 workgroups (8 waves) per CU, persistent
-    if (grid > cap) grid = cap;
-    if (grid > (uint32_t)a.n_ll_partials) grid = (uint32_t)a.n_ll_partials;
-    hipLaunchKernelGGL(em_estep_mfma4_kernel<D>, dim3(grid), dim3(256), 0, stream, a.xt, a.ldx, a.n, n_groups, a.params, a.K,
-                       a.lw, a.ldr, a.lse, a.ll_partials);
-    return (int)grid;
+    // MLHIP_ESTEP_SB=2 selects the 32-samples-per-wave variant (A/B experiments); default 4.
+    static const int sb = [] { const char* e = std::getenv("MLHIP_ESTEP_SB"); return (e && e[0] == '2') ? 2 : 4; }();
+    return sb == 2 ? launch_sb<D, 2>(a, num_cus, stream) : launch_sb<D, 4>(a, num_cus, stream);
 }
 
 static_assert(Blocks<32>::NB == 36 && Blocks<12>::NB == 6, "block count");

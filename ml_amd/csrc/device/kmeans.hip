@@ -16,6 +16,8 @@
 // workgroups or GPUs contribute: the update step is bitwise reproducible run to run (floating-point atomics are not),
 // which the reference's own test relies on (same seed => same fit => inertia of 3 initialisations <= inertia of the
 // first, Tests/test_KMeans.cpp:75-79). A limb sum cannot overflow: 2^32 samples x 2^32 per limb < 2^64.
+#include <cstdlib>
+
 #include "device.hpp"
 
 namespace mlhip {
@@ -208,8 +210,15 @@ size_t kmeans_scratch_doubles(int d, int K, int num_cus)
     return (size_t)kmeans_grid(num_cus) * (2 + (size_t)K * (3 * d + 1));
 }
 
+bool kmeans_mfma_supported(int D, int K);
+int launch_kmeans_mfma(const KmeansArgs& a, int num_cus, hipStream_t stream);
+
 int launch_kmeans_assign(const KmeansArgs& a, int num_cus, hipStream_t stream)
 {
+    // Matrix-core search with exact recheck (kmeans_mfma.hip) where it applies; MLHIP_KMEANS=valu forces this file's kernel.
+    const char* e = std::getenv("MLHIP_KMEANS");
+    const bool force_valu = e && e[0] == 'v';
+    if (!force_valu && kmeans_mfma_supported(a.D, a.K)) return launch_kmeans_mfma(a, num_cus, stream);
     const size_t pstride = 2 + (size_t)a.K * (3 * a.d + 1);
     int grid = kmeans_grid(num_cus);
     const uint32_t blocks_needed = (a.n + BS - 1) / BS;

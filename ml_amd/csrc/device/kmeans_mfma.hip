@@ -1,0 +1,273 @@
+// K-means assignment on the gfx950 fp64 matrix cores with bit-exact labels -- replaces KMeans::assignment_step /
+// assign_label (reference ML/KMeans.cpp:153-178) and the sums of update_step (:180-192) for d = 4, 8, ..., 32.
+//
+// The reference's decision for a sample is  argmin_k fl(sum_j (x_j - c_kj)^2)  with strict '<' (first minimum wins).
+// That direct form has no matrix structure, but ranking the clusters does not need it:
+//     |x - c_k|^2 = |x|^2 - 2 s_k,      s_k = x . c_k - |c_k|^2 / 2        (larger score = nearer)
+// and S = C X is a GEMM. So, per 64-sample group of a wave:
+//   1. scores by v_mfma_f64_16x16x4_f64: A = 16 centroids x 4 dims (LDS), B = 4 dims x 16 samples (coordinates held in
+//      VGPRs in operand layout), accumulator initialised with -|c|^2/2; every lane tracks best, second-best and argbest
+//      over the 4 x (K/16) clusters it sees, the four lane groups are merged by shuffles;
+//   2. one lane per sample re-reads the sample's row and evaluates the EXACT direct-form distance to the winner with the
+//      same fma chain as the host point query (this is the min distance / inertia contribution that is stored);
+//   3. if best - second is not larger than E = 8 (d+2) 2^-53 (|x|^2 + max_k |c_k|^2) -- a bound on the rounding error of
+//      the two scores plus that of the direct form itself, with a factor 2 to spare -- the sample is AMBIGUOUS and the
+//      lane falls back to the full exact scan (strict '<', ascending k). Otherwise every other cluster is farther than
+//      the winner by more than all rounding involved, so the reference's comparison chain picks the same label.
+// The labels are therefore bit-exact and the stored distances bit-identical to the VALU kernel (kmeans.hip); only the
+// work of the N x K search moves to the matrix pipe (2d flop per pair instead of 3d, no per-cluster compare chain).
+//
+// Update statistics: exact fixed-point limb sums with integer atomics, exactly as in kmeans.hip.
+#include "device.hpp"
+
+namespace mlhip {
+namespace {
+
+typedef unsigned long long u64;
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int BSM = 512;   // threads per workgroup (8 waves; two workgroups per CU)
+
+__device__ __forceinline__ void split_limbs(double t, u64& w0, u64& w1, u64& w2)
+{
+    const double h2 = floor(t * 0x1p-64);
+    const double r = __builtin_fma(-h2, 0x1p64, t);
+    const double h1 = floor(r * 0x1p-32);
+    const double l = __builtin_fma(-h1, 0x1p32, r);
+    w2 = (u64)(long long)(int)h2;
+    w1 = (u64)(unsigned)h1;
+    w0 = (u64)(unsigned)l;
+}
+
+template <int D, bool USE_LDS>
+__global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
+    const double* __restrict__ xt, size_t ldx, uint32_t n, uint32_t n_pad, int d, const double* __restrict__ cent, int K,
+    const double* __restrict__ scale, uint32_t* __restrict__ labels, const uint32_t* __restrict__ old_labels,
+    int have_old, double* __restrict__ min_dist, int accumulate, double* __restrict__ partials, size_t pstride)
+{
+    constexpr int Q = D / 4;          // 4-dimension steps of the MFMA
+    constexpr int DS = D + 1;         // odd row stride of the centroid table: conflict-free A-operand reads
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int Kp = (K + 15) & ~15;
+    double* Cs = smem;                         // [Kp][DS] centroids (padding rows zero)
+    double* cn = Cs + (size_t)Kp * DS;         // [Kp]  -|c|^2/2, -inf for padding rows
+    double* cmax_slot = cn + Kp;               // [1]   max_k |c_k|^2
+    u64* acc_lds = reinterpret_cast<u64*>(cmax_slot + 1);   // [K][3d+1] when USE_LDS
+    __shared__ double red[2 * (BSM / 64)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, s = lane & 15;
+    const int W = 3 * d + 1;
+    double* my_part = partials + (size_t)blockIdx.x * pstride;
+    u64* my_words = reinterpret_cast<u64*>(my_part + 2);
+
+    // ---- workgroup prologue: centroid table, -|c|^2/2 (same ascending-j fma chain as everywhere), max |c|^2, accumulators
+    for (int e = tid; e < Kp * DS; e += BSM) {
+        const int k = e / DS, j = e - k * DS;
+        Cs[e] = (k < K && j < D) ? cent[(size_t)k * D + j] : 0.0;
+    }
+    if (accumulate) {
+        if (USE_LDS) { for (int e = tid; e < K * W; e += BSM) acc_lds[e] = 0; }
+        else         { for (int e = tid; e < K * W; e += BSM) my_words[e] = 0; }
+    }
+    __syncthreads();
+    for (int k = tid; k < Kp; k += BSM) {
+        double nn = 0.0;
+        for (int j = 0; j < D; ++j) nn = __builtin_fma(Cs[k * DS + j], Cs[k * DS + j], nn);
+        cn[k] = k < K ? -0.5 * nn : -__builtin_inf();
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double mx = 0.0;
+        for (int k = tid; k < K; k += 64) mx = fmax(mx, -2.0 * cn[k]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+        if (tid == 0) *cmax_slot = mx;
+    }
+    __syncthreads();
+    const double cmax2 = *cmax_slot;
+    const double err_unit = 8.0 * (D + 2) * 0x1p-53;
+
+    double inertia = 0.0, changed = 0.0;
+    const uint32_t n_groups = n_pad / 64;
+    for (uint32_t grp = blockIdx.x * (BSM / 64) + wave; grp < n_groups; grp += gridDim.x * (BSM / 64)) {
+        const uint32_t base = grp * 64;
+        // ---- phase 1: scores on the matrix cores. xb[q][sb] = x[dim 4q + g][sample base + 16 sb + s]
+        double xb[Q][4];
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int sb = 0; sb < 4; ++sb) xb[q][sb] = xt[(size_t)(4 * q + g) * ldx + base + 16 * sb + s];
+        double best[4], second[4];
+        int idx[4];
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) { best[sb] = -__builtin_inf(); second[sb] = -__builtin_inf(); idx[sb] = 0; }
+
+        for (int cb = 0; cb < Kp / 16; ++cb) {
+            double a[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) a[q] = Cs[(16 * cb + s) * DS + 4 * q + g];   // A[i = lane&15][k = lane>>4]
+            d4 init;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) init[r] = cn[16 * cb + g + 4 * r];           // D row = (lane>>4) + 4 r
+#pragma unroll
+            for (int sb = 0; sb < 4; ++sb) {
+                d4 acc = init;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], xb[q][sb], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double v = acc[r];
+                    second[sb] = fmax(second[sb], fmin(best[sb], v));
+                    idx[sb] = (v > best[sb]) ? 16 * cb + g + 4 * r : idx[sb];
+                    best[sb] = fmax(best[sb], v);
+                }
+            }
+        }
+        // merge the 4 lane groups (disjoint cluster subsets) of every sample block; lane (g, s) keeps sample 16 g + s
+        double my_best = 0.0, my_second = 0.0;
+        int my_idx = 0;
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+            double b = best[sb], sd = second[sb];
+            int ix = idx[sb];
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+                const double b2 = __shfl_xor(b, off, 64), s2 = __shfl_xor(sd, off, 64);
+                const int i2 = __shfl_xor(ix, off, 64);
+                // keep the smaller index on exactly equal scores so that all four lanes agree
+                const bool take2 = (b2 > b) || (b2 == b && i2 < ix);
+                sd = fmax(fmin(b, b2), fmax(sd, s2));
+                ix = take2 ? i2 : ix;
+                b = fmax(b, b2);
+            }
+            if (g == sb) { my_best = b; my_second = sd; my_idx = ix; }
+        }
+
+        // ---- phase 2: one lane per sample, exact arithmetic
+        const uint32_t i = base + lane;
+        if (i < n) {
+            double x[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) x[j] = xt[(size_t)j * ldx + i];
+            double xn = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) xn = __builtin_fma(x[j], x[j], xn);
+            uint32_t arg = (uint32_t)my_idx;
+            double dist = 0.0;
+            {
+                const double* c = Cs + (size_t)arg * DS;
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    const double t = x[j] - c[j];
+                    dist = __builtin_fma(t, t, dist);
+                }
+            }
+            const bool certain = (my_best - my_second) > err_unit * (xn + cmax2);   // false for NaN / inf as well
+            if (!certain) {
+                // ambiguous: the reference's own loop (ML/KMeans.cpp:155-163)
+                double bd = __builtin_inf();
+                uint32_t ba = 0;
+                for (int k = 0; k < K; ++k) {
+                    const double* c = Cs + (size_t)k * DS;
+                    double sdist = 0.0;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        const double t = x[j] - c[j];
+                        sdist = __builtin_fma(t, t, sdist);
+                    }
+                    if (sdist < bd) { bd = sdist; ba = (uint32_t)k; }
+                }
+                arg = ba;
+                dist = bd;
+            }
+            labels[i] = arg;
+            if (min_dist) min_dist[i] = dist;
+            inertia += dist;
+            changed += (!have_old || old_labels[i] != arg) ? 1.0 : 0.0;
+            if (accumulate) {
+                u64* row = (USE_LDS ? acc_lds : my_words) + (size_t)arg * W;
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    if (j < d) {
+                        u64 w0, w1, w2;
+                        split_limbs(x[j] * scale[j], w0, w1, w2);   // wave-uniform index: scalar load
+                        atomicAdd(row + 3 * j, w0);
+                        atomicAdd(row + 3 * j + 1, w1);
+                        atomicAdd(row + 3 * j + 2, w2);
+                    }
+                }
+                atomicAdd(row + 3 * d, (u64)1);
+            }
+        }
+    }
+    // block sums of inertia / changed (fixed order)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        inertia += __shfl_down(inertia, off, 64);
+        changed += __shfl_down(changed, off, 64);
+    }
+    constexpr int NWV = BSM / 64;
+    if (lane == 0) {
+        red[wave] = inertia;
+        red[NWV + wave] = changed;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < NWV; ++w) { a += red[w]; b += red[NWV + w]; }
+        my_part[0] = a;
+        my_part[1] = b;
+    }
+    if (accumulate && USE_LDS) {
+        for (int e = tid; e < K * W; e += BSM) my_words[e] = acc_lds[e];
+    }
+}
+
+template <int D>
+int launch_t(const KmeansArgs& a, int num_cus, size_t pstride, hipStream_t stream)
+{
+    const int Kp = (a.K + 15) & ~15;
+    const size_t table = sizeof(double) * ((size_t)Kp * (D + 1) + Kp + 1);
+    const size_t accb = sizeof(u64) * (size_t)a.K * (3 * a.d + 1);
+    const bool use_lds = table + accb <= 78 * 1024;        // two workgroups per CU
+    const size_t smem = table + (use_lds ? accb : 0);
+    const uint32_t n_pad = (a.n + kSampleTile - 1) / kSampleTile * kSampleTile;
+    int grid = num_cus * 2;
+    const uint32_t need = (n_pad / 64 + BSM / 64 - 1) / (BSM / 64);
+    if ((uint32_t)grid > need) grid = (int)(need ? need : 1);
+    if ((size_t)grid * pstride > a.partials_capacity) return -2;
+    if (use_lds)
+        hipLaunchKernelGGL((kmeans_mfma_kernel<D, true>), dim3(grid), dim3(BSM), smem, stream, a.xt, a.ldx, a.n, n_pad, a.d,
+                           a.centroids, a.K, a.scale, a.labels, a.old_labels, a.have_old, a.min_dist, a.accumulate, a.partials, pstride);
+    else
+        hipLaunchKernelGGL((kmeans_mfma_kernel<D, false>), dim3(grid), dim3(BSM), smem, stream, a.xt, a.ldx, a.n, n_pad, a.d,
+                           a.centroids, a.K, a.scale, a.labels, a.old_labels, a.have_old, a.min_dist, a.accumulate, a.partials, pstride);
+    return grid;
+}
+
+}  // namespace
+
+/// The matrix-core kernel handles D = 4, 8, ..., 32 when the centroid table fits LDS next to another workgroup.
+bool kmeans_mfma_supported(int D, int K)
+{
+    const int Kp = (K + 15) & ~15;
+    return D >= 4 && D <= 32 && D % 4 == 0 && sizeof(double) * ((size_t)Kp * (D + 1) + Kp + 1) <= 72 * 1024;
+}
+
+int launch_kmeans_mfma(const KmeansArgs& a, int num_cus, hipStream_t stream)
+{
+    const size_t pstride = 2 + (size_t)a.K * (3 * a.d + 1);
+    switch (a.D) {
+    case 4: return launch_t<4>(a, num_cus, pstride, stream);
+    case 8: return launch_t<8>(a, num_cus, pstride, stream);
+    case 12: return launch_t<12>(a, num_cus, pstride, stream);
+    case 16: return launch_t<16>(a, num_cus, pstride, stream);
+    case 20: return launch_t<20>(a, num_cus, pstride, stream);
+    case 24: return launch_t<24>(a, num_cus, pstride, stream);
+    case 28: return launch_t<28>(a, num_cus, pstride, stream);
+    case 32: return launch_t<32>(a, num_cus, pstride, stream);
+    default: return -1;
+    }
+}
+
+}  // namespace mlhip

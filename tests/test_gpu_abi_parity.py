@@ -265,3 +265,38 @@ def test_estep_kernel_variants_agree(ctx, oracle, d, K, monkeypatch):
         assert np.array_equal(lab, lab0)
         for a, b in zip(m, m0):
             assert np.max(np.abs(a - b)) <= 1e-11 * np.max(np.abs(b))
+
+
+@pytest.mark.parametrize("n,d,K", [(5000, 4, 3), (20000, 8, 256), (7001, 8, 17), (3000, 16, 40), (3000, 32, 64), (2000, 12, 1)])
+def test_kmeans_mfma_and_valu_kernels_agree_bitwise(ctx, oracle, n, d, K, monkeypatch):
+    """The matrix-core search (approximate scores + exact recheck / exact fallback) yields the same labels and the same
+    per-sample distances, bit for bit, as the direct-form VALU kernel and as the oracle's point query -- including on
+    data with exact ties (duplicated centroids, samples equidistant from two centroids)."""
+    rng = np.random.default_rng(n + d + K)
+    C = 2.0 * rng.standard_normal((K, d))
+    X = np.ascontiguousarray(C[rng.integers(0, K, n)] + rng.standard_normal((n, d)))
+    if K >= 3:
+        C[2] = C[0]                                   # duplicate centroid: exact tie for every sample near it
+        X[:50] = 0.5 * (C[0] + C[1])                  # exactly equidistant samples (up to rounding of the midpoint)
+        X[50:60] = C[1]                               # zero distance
+    res = {}
+    for variant in ("mfma", "valu"):
+        if variant == "valu":
+            monkeypatch.setenv("MLHIP_KMEANS", "valu")
+        else:
+            monkeypatch.delenv("MLHIP_KMEANS", raising=False)
+        dt = _data(ctx, X)
+        inertia, changed, counts, C1 = dt.kmeans_step(C)
+        res[variant] = (inertia, counts, C1, dt.kmeans_labels(), dt.min_squared_distances(C))
+        dt.close()
+    monkeypatch.delenv("MLHIP_KMEANS", raising=False)
+    a, b = res["mfma"], res["valu"]
+    assert np.array_equal(a[3], b[3])                 # labels
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    km = oracle.KMeans(K)
+    km.set_centroids(C, n)
+    km.assignment_step(X)
+    assert np.array_equal(a[3], km.labels)
+    step = max(1, n // 500)
+    ref = np.array([km.assign_label(X[i])[1] for i in range(0, n, step)])
+    assert np.array_equal(a[4][::step], ref)          # distances bit-identical to the oracle's fma chain
