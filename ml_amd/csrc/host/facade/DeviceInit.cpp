@@ -1,6 +1,8 @@
 #include "DeviceInit.hpp"
 
 #include <algorithm>
+#include <limits>
+#include <random>
 #include <typeinfo>
 #include <vector>
 
@@ -20,20 +22,44 @@ void init_centroids(const CentroidsInitialiser& initialiser, ConstMatrixRef data
         initialiser.init(data, prng, number_components, centroids);
         return;
     }
-    // K-means++ (ML/Clustering.cpp:39-59) with the distance passes on the device.
+    // K-means++ (ML/Clustering.cpp:39-59) with the distance passes on the device. The draw follows what
+    // std::discrete_distribution (libstdc++ bits/random.tcc, _M_initialize + operator()) computes for these weights -- the
+    // sequential sum, p_i = w_i / sum, sequential cumulative sums, first index whose cumulative probability is >= the
+    // canonical uniform draw, last one forced to 1 -- without materialising the two N-long probability vectors: the
+    // cumulative scan stops at the drawn index.
     const Index n = data.cols(), d = data.rows();
-    std::vector<double> weights(static_cast<std::size_t>(n), 1.0), latest;
+    const std::size_t count = static_cast<std::size_t>(n);
+    std::vector<double> weights(count, 1.0), latest;
     for (unsigned int chosen = 0; chosen < number_components; ++chosen) {
-        if (chosen > 0) {
+        double sum = 0.0;
+        if (chosen == 0) {
+            sum = static_cast<double>(count);     // == the sequential sum of `count` ones (exact below 2^53)
+        } else {
             // squared distance of every sample to the centroid chosen last; weights = running minimum
             std::vector<double>& target = chosen == 1 ? weights : latest;
-            target.resize(static_cast<std::size_t>(n));
+            target.resize(count);
             device::check(mlhip_min_squared_distances(ctx, device_data, 1, centroids.col(chosen - 1), target.data()));
-            if (chosen > 1)
-                for (std::size_t i = 0; i < weights.size(); ++i) weights[i] = std::min(weights[i], latest[i]);
+            if (chosen == 1) {
+                for (std::size_t i = 0; i < count; ++i) sum += weights[i];
+            } else {
+                for (std::size_t i = 0; i < count; ++i) {
+                    const double w = std::min(weights[i], latest[i]);
+                    weights[i] = w;
+                    sum += w;
+                }
+            }
         }
-        std::discrete_distribution<Index> draw(weights.begin(), weights.end());
-        std::copy_n(data.col(draw(prng)), d, centroids.col(chosen));
+        std::size_t pick = 0;
+        if (count >= 2) {
+            const double p = std::generate_canonical<double, std::numeric_limits<double>::digits>(prng);
+            double cumulative = 0.0;
+            pick = count - 1;
+            for (std::size_t i = 0; i + 1 < count; ++i) {
+                cumulative += weights[i] / sum;
+                if (cumulative >= p) { pick = i; break; }
+            }
+        }
+        std::copy_n(data.col(static_cast<Index>(pick)), d, centroids.col(chosen));
     }
 }
 

@@ -33,6 +33,12 @@ def main():
         t0 = time.perf_counter()
         labels = em.labels
         out[name]["labels_seconds"] = time.perf_counter() - t0
+        if name == "fixed":
+            t0 = time.perf_counter()
+            resp = em.responsibilities
+            out[name]["responsibilities_seconds"] = time.perf_counter() - t0
+            out[name]["responsibilities_gb"] = resp.nbytes / 1e9
+            del resp
         del em
     km = clustering.KMeans(256)
     X8 = np.ascontiguousarray(X[:, :8])
