@@ -1,5 +1,6 @@
 """ctypes binding of the C ABI (include/mlhip.h). Loads ml_amd/libmlhip.so; never falls back to anything else."""
 import ctypes as C
+import weakref
 import os
 
 import numpy as np
@@ -91,9 +92,12 @@ class Context:
         self._h = C.c_void_p()
         check(lib.mlhip_ctx_create(int(device_id), C.byref(self._h)))
         self._hook = None
+        self._blocks = weakref.WeakSet()      # live Data objects: they hold a pointer to this context
 
     def close(self):
         if getattr(self, "_h", None):
+            for block in list(self._blocks):  # a sample block must not outlive its context
+                block.close()
             lib.mlhip_ctx_destroy(self._h)
             self._h = None
 
@@ -166,11 +170,13 @@ class Data:
             check(lib.mlhip_data_upload_dev(ctx.handle, C.cast(C.c_void_p(device_ptr), c_dp), d, C.c_uint64(n),
                                             C.c_int64(d), C.byref(self._h)))
         self.n, self.d = n, d
+        ctx._blocks.add(self)
 
     def close(self):
         if getattr(self, "_h", None):
             lib.mlhip_data_free(self._h)
             self._h = None
+            self.ctx._blocks.discard(self)
 
     def __del__(self):
         self.close()

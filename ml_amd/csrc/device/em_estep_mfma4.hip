@@ -69,7 +69,7 @@ __device__ __forceinline__ double reduce_scatter_groups(double v0, double v1, do
 /// wave, 8 waves per workgroup, half the coordinate/accumulator registers -> 4 waves per SIMD). A workgroup always
 /// covers 256 samples per component sweep, so the record staging traffic is the same.
 template <int D, int SB>
-__global__ __launch_bounds__(1024 / SB, 8 / SB) void em_estep_mfma4_kernel(
+__global__ __launch_bounds__(1024 / SB, D <= 32 ? 8 / SB : 2) void em_estep_mfma4_kernel(
     const double* __restrict__ xt, size_t ldx, uint32_t n, uint32_t n_groups, const double* __restrict__ params, int K,
     double* __restrict__ lw_out, size_t ldr, double* __restrict__ lse_out, double* __restrict__ ll_partials)
 {
@@ -216,7 +216,12 @@ int launch_t(const EstepArgs& a, int num_cus, hipStream_t stream)
 {
     // MLHIP_ESTEP_SB=2 selects the 32-samples-per-wave variant (A/B experiments); default 4.
     static const int sb = [] { const char* e = std::getenv("MLHIP_ESTEP_SB"); return (e && e[0] == '2') ? 2 : 4; }();
-    return sb == 2 ? launch_sb<D, 2>(a, num_cus, stream) : launch_sb<D, 4>(a, num_cus, stream);
+    if constexpr (D > 32) {
+        // 2 sample blocks per wave: D coordinate + D accumulator doubles per lane pair do not fit otherwise
+        return launch_sb<D, 2>(a, num_cus, stream);
+    } else {
+        return sb == 2 ? launch_sb<D, 2>(a, num_cus, stream) : launch_sb<D, 4>(a, num_cus, stream);
+    }
 }
 
 static_assert(Blocks<32>::NB == 36 && Blocks<12>::NB == 6, "block count");
@@ -233,6 +238,10 @@ int launch_em_estep_mfma4(const EstepArgs& a, int num_cus, hipStream_t stream)
     case 24: return launch_t<24>(a, num_cus, stream);
     case 28: return launch_t<28>(a, num_cus, stream);
     case 32: return launch_t<32>(a, num_cus, stream);
+    case 40: return launch_t<40>(a, num_cus, stream);
+    case 48: return launch_t<48>(a, num_cus, stream);
+    case 56: return launch_t<56>(a, num_cus, stream);
+    case 64: return launch_t<64>(a, num_cus, stream);
     default: return -1;
     }
 }

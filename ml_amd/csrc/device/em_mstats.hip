@@ -66,12 +66,12 @@ __global__ __launch_bounds__(256, 2) void em_mstats_kernel(
     // unconditional (row indices clamped into the allocation, the value is discarded when staged) so that they are
     // issued back to back and nothing waits for them before the MFMA loop.
     const int sS = tid & (TS - 1), qS = __builtin_amdgcn_readfirstlane(tid / TS);
-    double xv[kMaxDim / 4], rv[RBW * 4], lv = 0.0;
+    double xv[kRegDim / 4], rv[RBW * 4], lv = 0.0;
 
     auto prefetch = [&](uint32_t tile) {
         const uint32_t i = tile * TS + sS;           // < n_pad: always inside the allocation
 #pragma unroll
-        for (int it = 0; it < kMaxDim / 4; ++it) xv[it] = xt[(size_t)min(qS + 4 * it, D - 1) * ldx + i];
+        for (int it = 0; it < kRegDim / 4; ++it) xv[it] = xt[(size_t)min(qS + 4 * it, D - 1) * ldx + i];
 #pragma unroll
         for (int it = 0; it < RBW * 4; ++it) rv[it] = lw[(size_t)min(rb0 * 16 + qS + 4 * it, K - 1) * ldr + i];
         if (EXP) lv = lse[i];
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void em_mstats_kernel(
             Rb[sS * RS + qS + 4 * it] = valid ? r : 0.0;
         }
 #pragma unroll
-        for (int it = 0; it < kMaxDim / 4; ++it) {
+        for (int it = 0; it < kRegDim / 4; ++it) {
             const int j = qS + 4 * it;
             if (j < d) Xb[sS * XS + j] = xv[it] - shift[j];   // wave-uniform index: scalar load
         }
@@ -228,9 +228,10 @@ Plan make_plan(int d, int K, int num_cus)
         // One 512-thread workgroup per CU; its 8 waves take the column blocks round-robin (wave w: w, w+8, ...), every
         // wave holds all (<= 4) row blocks of the group: RBW x CBW <= 20 accumulator tiles.
         p.RBW = p.RB >= 4 ? 4 : (p.RB >= 2 ? 2 : 1);
-        p.CBW = (p.CB + 7) / 8;   // <= 5 for d <= 32 (CB <= 36), so there is a single column group
+        // <= 5 blocks per wave: a single column group for d <= 32 (CB <= 36), ceil(CB / 40) groups of equal width above
+        p.n_cbg = (p.CB + 39) / 40;
+        p.CBW = (p.CB + 8 * p.n_cbg - 1) / (8 * p.n_cbg);
         p.n_rbg = (p.RB + p.RBW - 1) / p.RBW;
-        p.n_cbg = (p.CB + 8 * p.CBW - 1) / (8 * p.CBW);
         p.KP = p.n_rbg * p.RBW * 16;
         p.FP = p.n_cbg * 8 * p.CBW * 16;
         p.grid_x = num_cus / (p.n_rbg * p.n_cbg);

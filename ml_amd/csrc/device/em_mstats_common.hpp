@@ -8,7 +8,8 @@ namespace mstats {
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int TS = 64;            // samples per LDS tile
-constexpr int XS = kMaxDim + 3;   // LDS row stride of the sample tile in doubles: d+1 coordinates + zero slot, odd (35)
+constexpr int XS = kRegDim + 3;   // LDS row stride of the sample tile in doubles: d+1 coordinates + zero slot, odd (35)
+constexpr int XS_BIG = kMaxDim + 3;   // the same for 32 < d <= 64 (67)
 
 /// Column `col` of the packed lower triangle of xt xt^T -> its (row a, column b) pair; padding columns map to the
 /// zero slot `da` of the LDS row.

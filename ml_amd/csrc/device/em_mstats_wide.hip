@@ -18,7 +18,7 @@ namespace {
 
 constexpr int NW = 8;   // waves per workgroup
 
-template <int RBW, int CBW, bool EXP>
+template <int RBW, int CBW, bool EXP, int DM>
 __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
     const double* __restrict__ xt, size_t ldx, uint32_t n, int d, int D, const double* __restrict__ shift,
     const double* __restrict__ lw, size_t ldr, const double* __restrict__ lse, int K, int n_rbg, int CB_total,
@@ -26,7 +26,8 @@ __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int RS = RBW * 16 + 1;     // odd row stride of the responsibility tile
-    constexpr int NXV = kMaxDim / NW;    // x rows staged per thread (4)
+    constexpr int NXV = DM / NW;         // x rows staged per thread (4, or 8 for d > 32)
+    constexpr int XS = DM <= kRegDim ? mstats::XS : mstats::XS_BIG;
     constexpr int NRV = RBW * 16 / NW;   // responsibility rows staged per thread (2 * RBW)
     const int da = d + 1;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -45,8 +46,9 @@ __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
         offa[c] = a;
         offb[c] = b;
     }
-    // With CBW = ceil(CB / 8) column blocks per wave and a single column group, only a wave's LAST block can fall
-    // outside the matrix (wave-uniform); all others are unconditional, which keeps them in one basic block.
+    // With CBW = ceil(CB / 8) column blocks per wave and a single column group (d <= 32), only a wave's LAST block can
+    // fall outside the matrix (wave-uniform); all others are unconditional, which keeps them in one basic block. With
+    // several column groups (d > 32) earlier blocks of the last group may be outside too: they multiply the zero slot.
     const bool last_active = (cbg * CBW + CBW - 1) * NW + wave < CB_total;
 
     d4 acc[RBW][CBW];
@@ -144,16 +146,17 @@ __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
         }
 }
 
-template <int RBW, int CBW>
+template <int RBW, int CBW, int DM = kRegDim>
 void launch_t(const MstatsArgs& a, const Plan& p, int grid_x, hipStream_t stream)
 {
-    const size_t smem = 2 * sizeof(double) * ((size_t)TS * XS + (size_t)TS * (RBW * 16 + 1));   // double-buffered
+    constexpr int XSD = DM <= kRegDim ? XS : XS_BIG;
+    const size_t smem = 2 * sizeof(double) * ((size_t)TS * XSD + (size_t)TS * (RBW * 16 + 1));   // double-buffered
     const dim3 grid(grid_x, p.n_rbg * p.n_cbg);
     if (a.mode == kFromLogResp)
-        hipLaunchKernelGGL((em_mstats_wide_kernel<RBW, CBW, true>), grid, dim3(512), smem, stream, a.xt, a.ldx, a.n, a.d,
+        hipLaunchKernelGGL((em_mstats_wide_kernel<RBW, CBW, true, DM>), grid, dim3(512), smem, stream, a.xt, a.ldx, a.n, a.d,
                            padded_dim(a.d), a.shift, a.lw, a.ldr, a.lse, a.K, p.n_rbg, p.CB, a.partials, p.KP, p.FP);
     else
-        hipLaunchKernelGGL((em_mstats_wide_kernel<RBW, CBW, false>), grid, dim3(512), smem, stream, a.xt, a.ldx, a.n, a.d,
+        hipLaunchKernelGGL((em_mstats_wide_kernel<RBW, CBW, false, DM>), grid, dim3(512), smem, stream, a.xt, a.ldx, a.n, a.d,
                            padded_dim(a.d), a.shift, a.lw, a.ldr, a.lse, a.K, p.n_rbg, p.CB, a.partials, p.KP, p.FP);
 }
 
@@ -161,6 +164,16 @@ void launch_t(const MstatsArgs& a, const Plan& p, int grid_x, hipStream_t stream
 
 int launch_wide(const MstatsArgs& a, const Plan& p, int grid_x, hipStream_t stream)
 {
+    if (a.d > kRegDim) {
+        // 32 < d <= 64: 38..135 column blocks in 1..4 column groups of 8 waves x (3, 4 or 5) blocks
+#define MLHIP_BIG(R, C) \
+    if (p.RBW == R && p.CBW == C) { launch_t<R, C, kMaxDim>(a, p, grid_x, stream); } else
+        MLHIP_BIG(1, 3) MLHIP_BIG(1, 4) MLHIP_BIG(1, 5) MLHIP_BIG(2, 3) MLHIP_BIG(2, 4) MLHIP_BIG(2, 5)
+        MLHIP_BIG(4, 3) MLHIP_BIG(4, 4) MLHIP_BIG(4, 5)
+        { return -1; }
+#undef MLHIP_BIG
+        return grid_x;
+    }
 #define MLHIP_CASE(R, C) \
     if (p.RBW == R && p.CBW == C) { launch_t<R, C>(a, p, grid_x, stream); } else
     MLHIP_CASE(1, 1) MLHIP_CASE(1, 2) MLHIP_CASE(1, 3) MLHIP_CASE(1, 4) MLHIP_CASE(1, 5)

@@ -28,6 +28,8 @@ typedef unsigned long long u64;
 // 1024-thread workgroups: the workgroup-private LDS accumulators (K*(3d+1) words, 51 KB at K=256, d=8) would otherwise
 // cap the CU at 3 small workgroups = 3 waves per SIMD, too few to cover the dependent FMA chain of a distance.
 constexpr int BS = 1024;
+// 32 < d <= 64: the coordinates alone take 2d VGPRs, so the workgroup shrinks to 512 threads (256 VGPRs per lane).
+constexpr int BS_BIG = 512;
 
 /// t (|t| < 2^94, integer part only is kept) -> limbs: t = i2 * 2^64 + u1 * 2^32 + u0 (+ dropped fraction), u0,u1 in [0, 2^32).
 __device__ __forceinline__ void split_limbs(double t, u64& w0, u64& w1, u64& w2)
@@ -41,7 +43,7 @@ __device__ __forceinline__ void split_limbs(double t, u64& w0, u64& w1, u64& w2)
     w0 = (u64)(unsigned)l;                                   // truncates the fraction below one unit
 }
 
-template <int D, bool USE_LDS>
+template <int D, bool USE_LDS, int BS>
 __global__ __launch_bounds__(BS) void kmeans_assign_kernel(
     const double* __restrict__ xt, size_t ldx, uint32_t n, int d, const double* __restrict__ cent, int K,
     const double* __restrict__ scale, uint32_t* __restrict__ labels, const uint32_t* __restrict__ old_labels,
@@ -192,12 +194,13 @@ __global__ __launch_bounds__(256) void kmeans_reduce_kernel(const double* __rest
 template <int D>
 void launch_t(const KmeansArgs& a, int grid, int use_lds, size_t pstride, hipStream_t stream)
 {
+    constexpr int BSZ = D <= kRegDim ? BS : BS_BIG;
     const size_t smem = use_lds ? sizeof(u64) * (size_t)a.K * (3 * a.d + 1) : 0;
     if (use_lds)
-        hipLaunchKernelGGL((kmeans_assign_kernel<D, true>), dim3(grid), dim3(BS), smem, stream, a.xt, a.ldx, a.n, a.d,
+        hipLaunchKernelGGL((kmeans_assign_kernel<D, true, BSZ>), dim3(grid), dim3(BSZ), smem, stream, a.xt, a.ldx, a.n, a.d,
                            a.centroids, a.K, a.scale, a.labels, a.old_labels, a.have_old, a.min_dist, a.accumulate, a.partials, pstride);
     else
-        hipLaunchKernelGGL((kmeans_assign_kernel<D, false>), dim3(grid), dim3(BS), smem, stream, a.xt, a.ldx, a.n, a.d,
+        hipLaunchKernelGGL((kmeans_assign_kernel<D, false, BSZ>), dim3(grid), dim3(BSZ), smem, stream, a.xt, a.ldx, a.n, a.d,
                            a.centroids, a.K, a.scale, a.labels, a.old_labels, a.have_old, a.min_dist, a.accumulate, a.partials, pstride);
 }
 
@@ -221,7 +224,8 @@ int launch_kmeans_assign(const KmeansArgs& a, int num_cus, hipStream_t stream)
     if (!force_valu && kmeans_mfma_supported(a.D, a.K)) return launch_kmeans_mfma(a, num_cus, stream);
     const size_t pstride = 2 + (size_t)a.K * (3 * a.d + 1);
     int grid = kmeans_grid(num_cus);
-    const uint32_t blocks_needed = (a.n + BS - 1) / BS;
+    const uint32_t bs = a.D <= kRegDim ? BS : BS_BIG;
+    const uint32_t blocks_needed = (a.n + bs - 1) / bs;
     if ((uint32_t)grid > blocks_needed) grid = (int)(blocks_needed ? blocks_needed : 1);
     if ((size_t)grid * pstride > a.partials_capacity) return -2;
     const int use_lds = (size_t)a.K * (3 * a.d + 1) * sizeof(u64) <= 64 * 1024;
@@ -238,6 +242,10 @@ int launch_kmeans_assign(const KmeansArgs& a, int num_cus, hipStream_t stream)
     case 24: launch_t<24>(a, grid, use_lds, pstride, stream); break;
     case 28: launch_t<28>(a, grid, use_lds, pstride, stream); break;
     case 32: launch_t<32>(a, grid, use_lds, pstride, stream); break;
+    case 40: launch_t<40>(a, grid, use_lds, pstride, stream); break;
+    case 48: launch_t<48>(a, grid, use_lds, pstride, stream); break;
+    case 56: launch_t<56>(a, grid, use_lds, pstride, stream); break;
+    case 64: launch_t<64>(a, grid, use_lds, pstride, stream); break;
     default: return -1;
     }
     return grid;

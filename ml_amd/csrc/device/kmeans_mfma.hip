@@ -247,11 +247,11 @@ int launch_t(const KmeansArgs& a, int num_cus, size_t pstride, hipStream_t strea
 
 }  // namespace
 
-/// The matrix-core kernel handles D = 4, 8, ..., 32 when the centroid table fits LDS next to another workgroup.
+/// The matrix-core kernel handles D = 4, 8, ..., 32, 40, ..., 64 when the centroid table fits LDS next to another workgroup.
 bool kmeans_mfma_supported(int D, int K)
 {
     const int Kp = (K + 15) & ~15;
-    return D >= 4 && D <= 32 && D % 4 == 0 && sizeof(double) * ((size_t)Kp * (D + 1) + Kp + 1) <= 72 * 1024;
+    return D >= 4 && D <= kMaxDim && D % 4 == 0 && sizeof(double) * ((size_t)Kp * (D + 1) + Kp + 1) <= 72 * 1024;
 }
 
 int launch_kmeans_mfma(const KmeansArgs& a, int num_cus, hipStream_t stream)
@@ -266,6 +266,10 @@ int launch_kmeans_mfma(const KmeansArgs& a, int num_cus, hipStream_t stream)
     case 24: return launch_t<24>(a, num_cus, pstride, stream);
     case 28: return launch_t<28>(a, num_cus, pstride, stream);
     case 32: return launch_t<32>(a, num_cus, pstride, stream);
+    case 40: return launch_t<40>(a, num_cus, pstride, stream);
+    case 48: return launch_t<48>(a, num_cus, pstride, stream);
+    case 56: return launch_t<56>(a, num_cus, pstride, stream);
+    case 64: return launch_t<64>(a, num_cus, pstride, stream);
     default: return -1;
     }
 }

@@ -241,7 +241,7 @@ mlhip_data* upload_common(mlhip_ctx* ctx, const double* x, bool on_device, uint3
     require(ld >= (int64_t)d, "ld must be >= d");
     require(n < 0xffffff00ull, "shard too large (n must fit 32 bits, like the reference's unsigned int)");
     const int D = padded_dim((int)d);
-    if (D < 0) throw Unsupported("dimension d > 32 is not supported by the register-resident kernels yet");
+    if (D < 0) throw Unsupported("dimension d > 64 is not supported by the register-resident kernels yet");
     ctx->use();
     auto* dt = new mlhip_data;
     try {
@@ -349,10 +349,8 @@ void ensure_em_workspace(mlhip_data* dt, int K)
     dt->lse.reserve(sizeof(double) * dt->n_pad);
     dt->ll_partials.reserve(sizeof(double) * kMaxLlPartials);
     size_t ps = (size_t)estep_param_stride(dt->D) * K * sizeof(double);
-    if (estep_mfma_supported(dt->D)) {
-        ps = std::max(ps, (size_t)estep_mfma_param_stride(dt->D) * K * sizeof(double));
-        ps = std::max(ps, (size_t)estep_mfma4_param_stride(dt->D) * K * sizeof(double));
-    }
+    if (estep_mfma_supported(dt->D)) ps = std::max(ps, (size_t)estep_mfma_param_stride(dt->D) * K * sizeof(double));
+    if (estep_mfma4_supported(dt->D)) ps = std::max(ps, (size_t)estep_mfma4_param_stride(dt->D) * K * sizeof(double));
     dt->params_dev.reserve(ps);
     dt->params_host.reserve(ps);
     dt->partials.reserve(sizeof(double) * em_mstats_scratch_doubles(dt->d, K, ctx->num_cus));
@@ -366,13 +364,14 @@ void run_estep(mlhip_data* dt, int K, const double* mixing, const double* means,
 {
     mlhip_ctx* ctx = dt->ctx;
     ensure_em_workspace(dt, K);
-    // Matrix-core kernel for d in 12..32, scalar-fed VALU kernel below that (MLHIP_ESTEP=valu|mfma overrides, for A/B runs).
-    // d in 12..32: 4x4-block triangular matrix-core kernel (mfma4); MLHIP_ESTEP=mfma16 selects the 16x16x4 block-
-    // triangular one, MLHIP_ESTEP=valu the scalar-fed VALU kernel (the only one below d = 12).
-    bool use_mfma = estep_mfma_supported(dt->D), use_mfma4 = use_mfma;
-    if (const char* e = std::getenv("MLHIP_ESTEP")) {
-        if (std::strcmp(e, "valu") == 0) use_mfma = use_mfma4 = false;
-        if (std::strcmp(e, "mfma16") == 0) use_mfma4 = false;
+        // d in 12..64: 4x4-block triangular matrix-core kernel (mfma4). For d <= 32, MLHIP_ESTEP=mfma16 selects the 16x16x4
+    // block-triangular one and MLHIP_ESTEP=valu the scalar-fed VALU kernel (the only one below d = 12), for A/B runs.
+    bool use_mfma = estep_mfma_supported(dt->D), use_mfma4 = estep_mfma4_supported(dt->D);
+    if (dt->D <= kRegDim) {
+        if (const char* e = std::getenv("MLHIP_ESTEP")) {
+            if (std::strcmp(e, "valu") == 0) use_mfma = use_mfma4 = false;
+            if (std::strcmp(e, "mfma16") == 0) use_mfma4 = false;
+        }
     }
     if (use_mfma4) {
         host::build_estep_params_mfma4(dt->d, dt->D, K, mixing, means, covs, dt->params_host.as<double>());

@@ -226,7 +226,7 @@ def test_bad_arguments(ctx):
     with pytest.raises(TypeError):
         _lib.Data(ctx, np.zeros((10, 3), dtype=np.float32))
     with pytest.raises(_lib.MlhipError):
-        _lib.Data(ctx, np.zeros((10, 33)))   # d > 32 unsupported (yet)
+        _lib.Data(ctx, np.zeros((10, 65)))   # d > 64 unsupported (yet)
     dt.close()
 
 
@@ -267,7 +267,8 @@ def test_estep_kernel_variants_agree(ctx, oracle, d, K, monkeypatch):
             assert np.max(np.abs(a - b)) <= 1e-11 * np.max(np.abs(b))
 
 
-@pytest.mark.parametrize("n,d,K", [(5000, 4, 3), (20000, 8, 256), (7001, 8, 17), (3000, 16, 40), (3000, 32, 64), (2000, 12, 1)])
+@pytest.mark.parametrize("n,d,K", [(5000, 4, 3), (20000, 8, 256), (7001, 8, 17), (3000, 16, 40), (3000, 32, 64), (2000, 12, 1),
+                                   (3000, 40, 9), (2500, 64, 33), (3000, 50, 160)])
 def test_kmeans_mfma_and_valu_kernels_agree_bitwise(ctx, oracle, n, d, K, monkeypatch):
     """The matrix-core search (approximate scores + exact recheck / exact fallback) yields the same labels and the same
     per-sample distances, bit for bit, as the direct-form VALU kernel and as the oracle's point query -- including on

@@ -309,6 +309,39 @@ def test_converged_labels_bit_exact_d16_K16(oracle):
     assert np.max(np.abs(em.means.T - ref.means)) <= 1e-10 * np.max(np.abs(ref.means))
 
 
+@pytest.mark.parametrize("d,K,n", [(40, 6, 6000), (64, 8, 8000), (50, 3, 4000)])
+def test_fits_above_32_dimensions(oracle, d, K, n):
+    """32 < d <= 64 (4x4-block E-step with 2 sample blocks per wave, statistics in several column groups, K-means with the
+    large-d kernels): EM converge-run and K-means fit against the oracle -- labels exact, parameters within tolerance."""
+    from ml_amd import synth
+    cl = _clustering()
+    mix = synth.Mixture(d, K, seed=d)
+    X, _ = mix.sample(n)
+    start = mix.initial_means()
+    em, ref = cl.EM(K), oracle.EM(K)
+    em.set_means_initialiser(cl.FixedCentroids(start))
+    ref.set_means_initialiser(oracle.FIXED, start)
+    for m in (em, ref):
+        m.set_absolute_tolerance(1e-10)
+        m.set_relative_tolerance(1e-10)
+        m.set_maximum_steps(100)
+    assert em.fit(X) and ref.fit(X)
+    assert em.steps_done == ref.steps_done
+    assert np.array_equal(em.labels, ref.labels)
+    assert abs(em.log_likelihood - ref.log_likelihood) <= 1e-12 * abs(ref.log_likelihood)
+    assert np.max(np.abs(em.means.T - ref.means)) <= 1e-10 * np.max(np.abs(ref.means))
+    for k in range(K):
+        assert np.max(np.abs(em.covariance(k) - ref.covariances[k])) <= 1e-9 * np.max(np.abs(ref.covariances[k]))
+
+    km, kref = cl.KMeans(K), oracle.KMeans(K)
+    km.set_centroids_initialiser(cl.FixedCentroids(start))
+    kref.set_centroids_initialiser(oracle.FIXED, start)
+    assert km.fit(X) == kref.fit(X)
+    assert np.array_equal(km.labels_array, kref.labels)
+    assert abs(km.inertia - kref.inertia) <= 1e-13 * kref.inertia
+    assert np.max(np.abs(km.centroids - kref.centroids)) <= 1e-13 * np.max(np.abs(kref.centroids))
+
+
 def test_nccl_single_rank_hook_device_path():
     """The device-pointer all-reduce hook (torch.distributed 'nccl' == RCCL) with world_size 1: validates the zero-copy
     wrapping of the library's statistics buffer and the stream hand-off. Results must equal the hook-free run bit for bit."""
