@@ -49,6 +49,30 @@ def cpu_baseline(mix, d, K, n_cpu, iters):
     return sec_per_iter, n_cpu
 
 
+def cpu_baseline_all_cores(mix, d, K, n_per_thread, iters):
+    """Row-parallel variant of the same restatement on every host core this process may use: one oracle instance per
+    thread on its own sample shard (the E and M steps are sums over samples, so this is what an OpenMP `parallel for` over
+    the reference's sample loops would do; the K x d x d combine is negligible). The reference itself is single-threaded."""
+    import threading
+    from oracle import oracle_ctypes as orc
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    X, _ = mix.sample(n_per_thread * threads, stream=998)
+    cov0 = np.stack([np.cov(X[:n_per_thread].T)] * K)
+    models = []
+    for _ in range(threads):
+        em = orc.EM(K)
+        em.set_parameters(mix.initial_means(), cov0, np.full(K, 1.0 / K))
+        models.append(em)
+    shards = [np.ascontiguousarray(X[t * n_per_thread:(t + 1) * n_per_thread]) for t in range(threads)]
+    pool = [threading.Thread(target=models[t].time_iterations, args=(shards[t], iters)) for t in range(threads)]
+    t0 = time.perf_counter()
+    for th in pool:
+        th.start()
+    for th in pool:
+        th.join()
+    return (time.perf_counter() - t0) / iters, n_per_thread * threads, threads
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,6 +197,13 @@ def main():
                                              f"{n_cpu} samples (d={d}, K={K}), time scaled x{n / n_cpu:g} to N={n} "
                                              f"(cost is linear in N, ML/EM.cpp:205,245)",
                                    "seconds_per_iteration_on_sample": sec}
+            psec, pn, threads = cpu_baseline_all_cores(mix, d, K, max(1000, args.cpu_samples // 2), iters)
+            out["cpu_baseline_all_cores"] = {
+                "value": 1.0 / (psec * n / pn), "unit": "iterations/s", "cores": threads, "kind": "port",
+                "sample": f"{iters} EM iteration(s), row-parallel: {threads} threads x {pn // threads} samples each "
+                          f"(one oracle instance per thread), time scaled x{n / pn:g} to N={n}; the reference is "
+                          f"single-threaded, this is the all-cores bound for it",
+                "seconds_per_iteration_on_sample": psec}
         print(json.dumps(out))
     data.close()
     ctx.close()
