@@ -1,6 +1,10 @@
 #include "em_math.hpp"
 
+#include <sched.h>
+
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "../device/layout.hpp"
@@ -47,8 +51,33 @@ void process_covariance(int d, const double* cov, double* inverse, double* sqrt_
 
 namespace {
 /// Threads used for the K independent per-component d x d factorizations (serial section of an EM iteration: every
-/// microsecond here is paid by all GPUs of a row-sharded job).
-constexpr int kHostThreads = 8;
+/// microsecond here is paid by all GPUs of a row-sharded job). At most 8, and never more than this process's share of
+/// the host cores when several ranks run on one node (set_host_ranks): oversubscribed OpenMP teams spin against each other.
+std::atomic<int> g_host_threads{0};
+
+int resolve_host_threads(int local_ranks)
+{
+    if (const char* e = std::getenv("MLHIP_HOST_THREADS")) {
+        const int v = std::atoi(e);
+        if (v >= 1) return v > 64 ? 64 : v;
+    }
+    int cores = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) cores = CPU_COUNT(&set);
+    if (local_ranks < 1) local_ranks = 1;
+    int t = cores / local_ranks;
+    return t < 1 ? 1 : (t > 8 ? 8 : t);
+}
+
+int host_threads()
+{
+    int t = g_host_threads.load(std::memory_order_relaxed);
+    if (t == 0) {
+        t = resolve_host_threads(1);
+        g_host_threads.store(t, std::memory_order_relaxed);
+    }
+    return t;
+}
 
 /// W = L^-1 (lower triangular, column-major d x d) and sum_j log L_jj for one covariance.
 double whitening_matrix(int d, const double* cov, std::vector<double>& L, std::vector<double>& W)
@@ -97,7 +126,7 @@ void build_estep_params_mfma4(int d, int D, int K, const double* mixing, const d
     const int PS = estep_mfma4_param_stride(D);
     const int NB = estep_mfma4_block_count(D);
     const int Q = D / 4;
-#pragma omp parallel num_threads(kHostThreads) if (K >= 8)
+#pragma omp parallel num_threads(host_threads()) if (K >= 8)
     {
     std::vector<double> L((size_t)d * d), W((size_t)d * d);
 #pragma omp for schedule(static)
@@ -140,7 +169,7 @@ void finalize_mstep(int d, int K, const double* stats, const double* shift, doub
                     double* means, double* covariances)
 {
     const int F = stats_count(d);
-#pragma omp parallel num_threads(kHostThreads) if (K >= 8)
+#pragma omp parallel num_threads(host_threads()) if (K >= 8)
     {
     std::vector<double> m(d);
 #pragma omp for schedule(static)
@@ -164,6 +193,8 @@ void finalize_mstep(int d, int K, const double* stats, const double* shift, doub
     }
     }
 }
+
+void set_host_ranks(int local_ranks) { g_host_threads.store(resolve_host_threads(local_ranks), std::memory_order_relaxed); }
 
 }  // namespace host
 }  // namespace mlhip

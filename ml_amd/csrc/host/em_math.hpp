@@ -35,5 +35,9 @@ void build_estep_params_mfma4(int d, int D, int K, const double* mixing, const d
 void finalize_mstep(int d, int K, const double* stats, const double* shift, double n_global, double* mixing,
                     double* means, double* covariances);
 
+/// Tells the host-side math how many ranks share this node, so that the OpenMP teams of the per-component
+/// factorizations together stay within the host's cores (MLHIP_HOST_THREADS overrides the per-rank thread count).
+void set_host_ranks(int local_ranks);
+
 }  // namespace host
 }  // namespace mlhip

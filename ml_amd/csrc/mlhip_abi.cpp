@@ -617,6 +617,13 @@ int mlhip_ctx_set_allreduce(mlhip_ctx* ctx, mlhip_allreduce_fn fn, void* user, i
         ctx->reduce_on_device = on_device;
         ctx->world_size = fn ? world_size : 1;
         ctx->rank = fn ? rank : 0;
+        // ranks sharing this host: LOCAL_WORLD_SIZE when a launcher (torchrun) exports it, else the whole world
+        int local = ctx->world_size;
+        if (const char* e = std::getenv("LOCAL_WORLD_SIZE")) {
+            const int v = std::atoi(e);
+            if (v >= 1 && v <= ctx->world_size) local = v;
+        }
+        host::set_host_ranks(local);
     });
 }
 
