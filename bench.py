@@ -9,7 +9,11 @@ through the C ABI entry point mlhip_em_step on data already resident in HBM. The
 over the ranks (strong scaling: the job size is fixed), the only exchange is one all-reduce of the K*561+1
 sufficient statistics per iteration through torch.distributed (backend nccl == RCCL over xGMI).
 
-Prints ONE JSON line on rank 0 (see the fields below)."""
+Prints ONE JSON line on rank 0 (see the fields below).
+
+    python bench.py --workload kmeans [--gpus N ...]       second workload, same contract: K-means steps/sec at
+        N=100M, d=8, K=256 (BASELINE.json configs[4]); one step = mlhip_kmeans_step = assignment + exact update sums +
+        all-reduce of counts/sums + new centroids (ML/KMeans.cpp:82-108)."""
 import argparse
 import json
 import os
@@ -73,8 +77,90 @@ def cpu_baseline_all_cores(mix, d, K, n_per_thread, iters):
     return (time.perf_counter() - t0) / iters, n_per_thread * threads, threads
 
 
+def kmeans_workload(args, rank, local_rank, world, dist, torch):
+    """K-means steps/sec, N row-sharded over the ranks, centroids replicated, one all-reduce of [inertia, n_changed,
+    counts(K), sums(K*d)] per step."""
+    from ml_amd import _lib, synth
+    from ml_amd import dist as mldist
+    n = args.n if args.n != N_TOTAL else 100_000_000
+    d = args.dim if args.dim != DIM else 8
+    K = args.components if args.components != COMPONENTS else 256
+    lo, hi = mldist.shard_bounds(n, world, rank)
+    mix = synth.Mixture(d, K, seed=77, diagonal=True)
+    X = np.empty((hi - lo, d))
+    chunk = 12_500_000                                       # bounded temporaries: the block itself is 6.4 GB at N=100M
+    for c, a in enumerate(range(0, hi - lo, chunk)):
+        b = min(hi - lo, a + chunk)
+        X[a:b] = mix.sample(b - a, stream=1000 * rank + c)[0]
+    ctx = _lib.Context(local_rank)
+    if world > 1 or args.force_hook:
+        mldist.install_allreduce(ctx, world, rank)
+    data = _lib.Data(ctx, X)
+    del X
+    C = mix.means + 0.3 * np.random.default_rng(1).standard_normal((K, d))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    inertia = None
+    for _ in range(args.warmup):
+        inertia, _, _, C = data.kmeans_step(C)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        inertia, _, _, C = data.kmeans_step(C)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    for _ in range(3):
+        inertia, _, _, C = data.kmeans_step(C)
+    k_ms, _ = ctx.timing_get("kmeans_assign")
+    ctx.timing_enable(False)
+    if rank == 0:
+        n_local = hi - lo
+        flops = float(n_local) * K * 3 * d                  # SURVEY 8(d): N*K*3d (direct-form distances)
+        achieved = flops / (k_ms * 1e-3) / 1e12
+        out = {
+            "metric": "K-means steps/sec at N=100M d=8 K=256 (fp64)" if (n, d, K) == (100_000_000, 8, 256)
+                      else f"K-means steps/sec at N={n} d={d} K={K} (fp64; diagnostic shape)",
+            "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"K-means (Lloyd) N={n} d={d} K={K}, row-sharded over {world} GPU(s)", "N": n, "d": d,
+                       "K": K, "parallelism": f"dp{world}", "inertia": inertia},
+            "roofline": {"bound": "mfma", "kernel": "kmeans_assign", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "kernel_ms": {"kmeans_assign": k_ms},
+                         "hbm_algorithmic_gbs": n_local * (8.0 * d + 4) / (k_ms * 1e-3) / 1e9, "hbm_peak_gbs": HBM_PEAK_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle_ctypes as orc
+            n_cpu = min(n, 5 * args.cpu_samples)
+            Xc, _ = mix.sample(n_cpu, stream=999)
+            km = orc.KMeans(K)
+            km.set_centroids(C, n_cpu)
+            sec = km.time_steps(Xc, 1)
+            out["cpu_baseline"] = {"value": 1.0 / (sec * n / n_cpu), "unit": "steps/s", "cores": 1, "kind": "port",
+                                   "sample": f"1 K-means step of the single-threaded CPU restatement (oracle/) on {n_cpu} "
+                                             f"samples, time scaled x{n / n_cpu:g} to N={n} (cost is linear in N, "
+                                             f"ML/KMeans.cpp:173-177,187-191)",
+                                   "seconds_per_step_on_sample": sec}
+        print(json.dumps(out))
+    data.close()
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", choices=("em", "kmeans"), default="em")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
@@ -106,6 +192,12 @@ def main():
     elif args.force_hook:
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29544", rank=0, world_size=1,
                                 device_id=torch.device("cuda", local_rank))
+
+    if args.workload == "kmeans":
+        kmeans_workload(args, rank, local_rank, world, dist, torch)
+        if world > 1 or args.force_hook:
+            dist.destroy_process_group()
+        return
 
     n, d, K = args.n, args.dim, args.components
     lo, hi = mldist.shard_bounds(n, world, rank)

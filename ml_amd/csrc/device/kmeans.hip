@@ -150,6 +150,45 @@ __global__ __launch_bounds__(BS) void kmeans_assign_kernel(
     }
 }
 
+/// Update sums as a second sweep, for shapes whose K*(3d+1) accumulator words do not fit LDS next to the assignment
+/// kernel's own state: the clusters are cut into chunks of KC whose accumulators do fit; for every chunk the workgroup
+/// re-reads its samples' labels (and the coordinates of the samples that fall into the chunk) and adds the limbs with LDS
+/// integer atomics, then flushes the chunk to its partial block. Same exact sums as the fused path, a few extra passes
+/// over labels / X instead of global-memory atomics (which serialise on popular clusters: 28 ms vs 2.4 ms for the
+/// assignment itself at N=12.5M, d=16, K=256).
+constexpr int BSU = 1024;
+__global__ __launch_bounds__(BSU) void kmeans_update_kernel(
+    const double* __restrict__ xt, size_t ldx, uint32_t n, int d, const uint32_t* __restrict__ labels,
+    const double* __restrict__ scale, int K, int KC, double* __restrict__ partials, size_t pstride)
+{
+    extern __shared__ u64 acc_lds[];      // [KC][3d+1]
+    const int tid = threadIdx.x;
+    const int W = 3 * d + 1;
+    u64* my_words = reinterpret_cast<u64*>(partials + (size_t)blockIdx.x * pstride + 2);
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        const int kc = min(KC, K - k0);
+        for (int e = tid; e < kc * W; e += BSU) acc_lds[e] = 0;
+        __syncthreads();
+        for (uint32_t i = blockIdx.x * (uint32_t)BSU + tid; i < n; i += gridDim.x * (uint32_t)BSU) {
+            const uint32_t rel = labels[i] - (uint32_t)k0;
+            if (rel < (uint32_t)kc) {
+                u64* row = acc_lds + (size_t)rel * W;
+                for (int j = 0; j < d; ++j) {
+                    u64 w0, w1, w2;
+                    split_limbs(xt[(size_t)j * ldx + i] * scale[j], w0, w1, w2);
+                    atomicAdd(row + 3 * j, w0);
+                    atomicAdd(row + 3 * j + 1, w1);
+                    atomicAdd(row + 3 * j + 2, w2);
+                }
+                atomicAdd(row + 3 * d, (u64)1);
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < kc * W; e += BSU) my_words[(size_t)k0 * W + e] = acc_lds[e];
+        __syncthreads();
+    }
+}
+
 /// out = [inertia, n_changed, counts(K), sums(K*d)]: inertia / changed are fixed-order sums of the per-workgroup
 /// partials; counts and coordinate sums are exact integer sums of the limb words, converted to double once.
 __global__ __launch_bounds__(256) void kmeans_reduce_kernel(const double* __restrict__ partials, int n_blocks, size_t pstride,
@@ -213,22 +252,38 @@ size_t kmeans_scratch_doubles(int d, int K, int num_cus)
     return (size_t)kmeans_grid(num_cus) * (2 + (size_t)K * (3 * d + 1));
 }
 
+/// Separate update sweep (see kmeans_update_kernel) over the same `grid` partial blocks the assignment kernel used.
+void launch_kmeans_update(const KmeansArgs& a, int grid, size_t pstride, hipStream_t stream)
+{
+    const int W = 3 * a.d + 1;
+    const size_t budget = 72 * 1024;                          // two 1024-thread workgroups per CU
+    int KC = (int)(budget / (sizeof(u64) * W));
+    if (KC > a.K) KC = a.K;
+    if (KC < 1) KC = 1;
+    hipLaunchKernelGGL(kmeans_update_kernel, dim3(grid), dim3(BSU), sizeof(u64) * (size_t)KC * W, stream, a.xt, a.ldx, a.n, a.d,
+                       a.labels, a.scale, a.K, KC, a.partials, pstride);
+}
+
 bool kmeans_mfma_supported(int D, int K);
 int launch_kmeans_mfma(const KmeansArgs& a, int num_cus, hipStream_t stream);
 
-int launch_kmeans_assign(const KmeansArgs& a, int num_cus, hipStream_t stream)
+int launch_kmeans_assign(const KmeansArgs& a_in, int num_cus, hipStream_t stream)
 {
     // Matrix-core search with exact recheck (kmeans_mfma.hip) where it applies; MLHIP_KMEANS=valu forces this file's kernel.
     const char* e = std::getenv("MLHIP_KMEANS");
     const bool force_valu = e && e[0] == 'v';
-    if (!force_valu && kmeans_mfma_supported(a.D, a.K)) return launch_kmeans_mfma(a, num_cus, stream);
-    const size_t pstride = 2 + (size_t)a.K * (3 * a.d + 1);
+    if (!force_valu && kmeans_mfma_supported(a_in.D, a_in.K)) return launch_kmeans_mfma(a_in, num_cus, stream);
+    const size_t pstride = 2 + (size_t)a_in.K * (3 * a_in.d + 1);
     int grid = kmeans_grid(num_cus);
-    const uint32_t bs = a.D <= kRegDim ? BS : BS_BIG;
-    const uint32_t blocks_needed = (a.n + bs - 1) / bs;
+    const uint32_t bs = a_in.D <= kRegDim ? BS : BS_BIG;
+    const uint32_t blocks_needed = (a_in.n + bs - 1) / bs;
     if ((uint32_t)grid > blocks_needed) grid = (int)(blocks_needed ? blocks_needed : 1);
-    if ((size_t)grid * pstride > a.partials_capacity) return -2;
-    const int use_lds = (size_t)a.K * (3 * a.d + 1) * sizeof(u64) <= 64 * 1024;
+    if ((size_t)grid * pstride > a_in.partials_capacity) return -2;
+    // Accumulators that fit LDS are updated by the assignment kernel itself; otherwise by a separate sweep afterwards.
+    const bool fits = (size_t)a_in.K * (3 * a_in.d + 1) * sizeof(u64) <= 64 * 1024;
+    const int use_lds = fits ? 1 : 0;
+    KmeansArgs a = a_in;
+    if (!fits) a.accumulate = 0;
     switch (a.D) {
     case 1: launch_t<1>(a, grid, use_lds, pstride, stream); break;
     case 2: launch_t<2>(a, grid, use_lds, pstride, stream); break;
@@ -248,6 +303,7 @@ int launch_kmeans_assign(const KmeansArgs& a, int num_cus, hipStream_t stream)
     case 64: launch_t<64>(a, grid, use_lds, pstride, stream); break;
     default: return -1;
     }
+    if (a_in.accumulate && !fits) launch_kmeans_update(a_in, grid, pstride, stream);
     return grid;
 }
 

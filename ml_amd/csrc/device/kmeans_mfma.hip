@@ -21,6 +21,7 @@
 #include "device.hpp"
 
 namespace mlhip {
+void launch_kmeans_update(const KmeansArgs& a, int grid, size_t pstride, hipStream_t stream);   // kmeans.hip
 namespace {
 
 typedef unsigned long long u64;
@@ -231,6 +232,8 @@ int launch_t(const KmeansArgs& a, int num_cus, size_t pstride, hipStream_t strea
     const size_t accb = sizeof(u64) * (size_t)a.K * (3 * a.d + 1);
     const bool use_lds = table + accb <= 78 * 1024;        // two workgroups per CU
     const size_t smem = table + (use_lds ? accb : 0);
+    // Accumulators that do not fit next to the centroid table: assignment only here, the sums by a separate sweep.
+    const int accumulate_here = use_lds ? a.accumulate : 0;
     const uint32_t n_pad = (a.n + kSampleTile - 1) / kSampleTile * kSampleTile;
     int grid = num_cus * 2;
     const uint32_t need = (n_pad / 64 + BSM / 64 - 1) / (BSM / 64);
@@ -238,10 +241,11 @@ int launch_t(const KmeansArgs& a, int num_cus, size_t pstride, hipStream_t strea
     if ((size_t)grid * pstride > a.partials_capacity) return -2;
     if (use_lds)
         hipLaunchKernelGGL((kmeans_mfma_kernel<D, true>), dim3(grid), dim3(BSM), smem, stream, a.xt, a.ldx, a.n, n_pad, a.d,
-                           a.centroids, a.K, a.scale, a.labels, a.old_labels, a.have_old, a.min_dist, a.accumulate, a.partials, pstride);
+                           a.centroids, a.K, a.scale, a.labels, a.old_labels, a.have_old, a.min_dist, accumulate_here, a.partials, pstride);
     else
         hipLaunchKernelGGL((kmeans_mfma_kernel<D, false>), dim3(grid), dim3(BSM), smem, stream, a.xt, a.ldx, a.n, n_pad, a.d,
-                           a.centroids, a.K, a.scale, a.labels, a.old_labels, a.have_old, a.min_dist, a.accumulate, a.partials, pstride);
+                           a.centroids, a.K, a.scale, a.labels, a.old_labels, a.have_old, a.min_dist, accumulate_here, a.partials, pstride);
+    if (a.accumulate && !use_lds) launch_kmeans_update(a, grid, pstride, stream);
     return grid;
 }
 

@@ -76,6 +76,9 @@ def test_two_rank_statistics_allreduce_matches_single_rank_oracle(oracle):
     results = [q.get(timeout=120) for _ in procs]
     for p in procs:
         p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+            p.join()
     for r in results:
         assert r[1] is not "error", r[2]
     results.sort(key=lambda r: r[0])
@@ -143,6 +146,9 @@ def test_two_ranks_on_one_gpu_match_single_rank():
     results = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+            p.join()
     for r in results:
         assert r[1] != "error", r[2]
     results.sort(key=lambda r: r[0])

@@ -342,37 +342,64 @@ def test_fits_above_32_dimensions(oracle, d, K, n):
     assert np.max(np.abs(km.centroids - kref.centroids)) <= 1e-13 * np.max(np.abs(kref.centroids))
 
 
-def test_nccl_single_rank_hook_device_path():
-    """The device-pointer all-reduce hook (torch.distributed 'nccl' == RCCL) with world_size 1: validates the zero-copy
-    wrapping of the library's statistics buffer and the stream hand-off. Results must equal the hook-free run bit for bit."""
-    import torch
-    import torch.distributed as dist
-    from ml_amd import _lib, synth
-    from ml_amd import dist as mldist
-    if not torch.cuda.is_available():
-        pytest.skip("torch sees no GPU")
-    mix = synth.Mixture(8, 4, seed=2)
-    X, _ = mix.sample(5000)
-    pi0, mu0 = np.full(4, 0.25), mix.initial_means()
-    S0 = np.stack([np.cov(X.T)] * 4)
-    ctx = _lib.Context(0)
-    dt = _lib.Data(ctx, X)
-    base = dt.em_step(pi0, mu0, S0)
-    dt.close()
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1,
-                            device_id=torch.device("cuda", 0))
+def _nccl_worker(q):
     try:
+        import os
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import torch
+        import torch.distributed as dist
+        from ml_amd import _lib, synth
+        from ml_amd import dist as mldist
+        if not torch.cuda.is_available():
+            q.put(("skip", "torch sees no GPU"))
+            return
+        mix = synth.Mixture(8, 4, seed=2)
+        X, _ = mix.sample(5000)
+        pi0, mu0 = np.full(4, 0.25), mix.initial_means()
+        S0 = np.stack([np.cov(X.T)] * 4)
+        ctx = _lib.Context(0)
+        dt = _lib.Data(ctx, X)
+        base = dt.em_step(pi0, mu0, S0)
+        dt.close()
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
         mldist.install_allreduce(ctx, 1, 0)
         dt = _lib.Data(ctx, X)
         hooked = dt.em_step(pi0, mu0, S0)
         dt.close()
         ctx.set_allreduce(None, False, 1, 0)
-    finally:
+        q.put(("ok", base, hooked))
+        ctx.close()
         dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put(("error", traceback.format_exc()))
+
+
+def test_nccl_single_rank_hook_device_path():
+    """The device-pointer all-reduce hook (torch.distributed 'nccl' == RCCL) with world_size 1: validates the zero-copy
+    wrapping of the library's statistics buffer and the stream hand-off. Results must equal the hook-free run bit for bit.
+    Runs in a child process: the process group (and its teardown) never lives in the test runner itself."""
+    import torch.multiprocessing as mp
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    proc = mpctx.Process(target=_nccl_worker, args=(q,))
+    proc.start()
+    try:
+        res = q.get(timeout=300)
+    finally:
+        proc.join(timeout=30)
+        if proc.is_alive():      # result delivered (or timed out): never let a stuck teardown hold the suite
+            proc.kill()
+            proc.join()
+    if res[0] == "skip":
+        pytest.skip(res[1])
+    assert res[0] == "ok", res[1]
+    base, hooked = res[1], res[2]
     assert base[0] == hooked[0]
     for a, b in zip(base[1:], hooked[1:]):
         assert np.array_equal(a, b)
-    ctx.close()
 
 
 def test_kpp_on_device_equals_host_kpp(oracle):
