@@ -40,19 +40,24 @@ __device__ __forceinline__ void split_limbs(double t, u64& w0, u64& w1, u64& w2)
     w0 = (u64)(unsigned)l;
 }
 
-template <int D, bool USE_LDS>
+/// CHUNKED = false: the whole centroid table lives in LDS, waves run independently. CHUNKED = true (tables beyond the LDS
+/// budget, i.e. large K): the table is streamed through LDS in chunks of KC clusters; the 8 waves of a workgroup then
+/// walk their 64-sample groups in lockstep (two barriers per chunk), keep the running best / second / argbest in
+/// registers across chunks, and the exact recheck reads the winner's centroid from global memory (L2).
+template <int D, bool USE_LDS, bool CHUNKED>
 __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
     const double* __restrict__ xt, size_t ldx, uint32_t n, uint32_t n_pad, int d, const double* __restrict__ cent, int K,
     const double* __restrict__ scale, uint32_t* __restrict__ labels, const uint32_t* __restrict__ old_labels,
-    int have_old, double* __restrict__ min_dist, int accumulate, double* __restrict__ partials, size_t pstride)
+    int have_old, double* __restrict__ min_dist, int accumulate, double* __restrict__ partials, size_t pstride, int KC)
 {
     constexpr int Q = D / 4;          // 4-dimension steps of the MFMA
     constexpr int DS = D + 1;         // odd row stride of the centroid table: conflict-free A-operand reads
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int Kp = (K + 15) & ~15;
-    double* Cs = smem;                         // [Kp][DS] centroids (padding rows zero)
-    double* cn = Cs + (size_t)Kp * DS;         // [Kp]  -|c|^2/2, -inf for padding rows
-    double* cmax_slot = cn + Kp;               // [1]   max_k |c_k|^2
+    const int KT = CHUNKED ? KC : Kp;          // rows of the LDS table (a multiple of 16)
+    double* Cs = smem;                         // [KT][DS] centroids (padding rows zero)
+    double* cn = Cs + (size_t)KT * DS;         // [KT]  -|c|^2/2, -inf for padding rows
+    double* cmax_slot = cn + KT;               // [1]   max_k |c_k|^2
     u64* acc_lds = reinterpret_cast<u64*>(cmax_slot + 1);   // [K][3d+1] when USE_LDS
     __shared__ double red[2 * (BSM / 64)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -62,27 +67,45 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
     u64* my_words = reinterpret_cast<u64*>(my_part + 2);
 
     // ---- workgroup prologue: centroid table, -|c|^2/2 (same ascending-j fma chain as everywhere), max |c|^2, accumulators
-    for (int e = tid; e < Kp * DS; e += BSM) {
-        const int k = e / DS, j = e - k * DS;
-        Cs[e] = (k < K && j < D) ? cent[(size_t)k * D + j] : 0.0;
-    }
     if (accumulate) {
         if (USE_LDS) { for (int e = tid; e < K * W; e += BSM) acc_lds[e] = 0; }
         else         { for (int e = tid; e < K * W; e += BSM) my_words[e] = 0; }
     }
-    __syncthreads();
-    for (int k = tid; k < Kp; k += BSM) {
-        double nn = 0.0;
-        for (int j = 0; j < D; ++j) nn = __builtin_fma(Cs[k * DS + j], Cs[k * DS + j], nn);
-        cn[k] = k < K ? -0.5 * nn : -__builtin_inf();
-    }
-    __syncthreads();
-    if (tid < 64) {
+    if constexpr (!CHUNKED) {
+        for (int e = tid; e < Kp * DS; e += BSM) {
+            const int k = e / DS, j = e - k * DS;
+            Cs[e] = (k < K && j < D) ? cent[(size_t)k * D + j] : 0.0;
+        }
+        __syncthreads();
+        for (int k = tid; k < Kp; k += BSM) {
+            double nn = 0.0;
+            for (int j = 0; j < D; ++j) nn = __builtin_fma(Cs[k * DS + j], Cs[k * DS + j], nn);
+            cn[k] = k < K ? -0.5 * nn : -__builtin_inf();
+        }
+        __syncthreads();
+        if (tid < 64) {
+            double mx = 0.0;
+            for (int k = tid; k < K; k += 64) mx = fmax(mx, -2.0 * cn[k]);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+            if (tid == 0) *cmax_slot = mx;
+        }
+    } else {
         double mx = 0.0;
-        for (int k = tid; k < K; k += 64) mx = fmax(mx, -2.0 * cn[k]);
+        for (int k = tid; k < K; k += BSM) {
+            double nn = 0.0;
+            for (int j = 0; j < D; ++j) nn = __builtin_fma(cent[(size_t)k * D + j], cent[(size_t)k * D + j], nn);
+            mx = fmax(mx, nn);
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
-        if (tid == 0) *cmax_slot = mx;
+        if (lane == 0) red[wave] = mx;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < BSM / 64; ++w) t = fmax(t, red[w]);
+            *cmax_slot = t;
+        }
     }
     __syncthreads();
     const double cmax2 = *cmax_slot;
@@ -90,7 +113,15 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
 
     double inertia = 0.0, changed = 0.0;
     const uint32_t n_groups = n_pad / 64;
-    for (uint32_t grp = blockIdx.x * (BSM / 64) + wave; grp < n_groups; grp += gridDim.x * (BSM / 64)) {
+    const uint32_t per_sweep = gridDim.x * (BSM / 64);
+    const uint32_t n_sweeps = (n_groups + per_sweep - 1) / per_sweep;          // uniform over the workgroup
+    for (uint32_t sweep = 0; sweep < n_sweeps; ++sweep) {
+        uint32_t grp = sweep * per_sweep + blockIdx.x * (BSM / 64) + wave;
+        const bool active = grp < n_groups;
+        if (!active) {
+            if constexpr (!CHUNKED) break;     // independent waves: done
+            grp = n_groups - 1;                // lockstep: keep serving the barriers (and the table loads) on a valid group
+        }
         const uint32_t base = grp * 64;
         // ---- phase 1: scores on the matrix cores. xb[q][sb] = x[dim 4q + g][sample base + 16 sb + s]
         double xb[Q][4];
@@ -103,7 +134,23 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
 #pragma unroll
         for (int sb = 0; sb < 4; ++sb) { best[sb] = -__builtin_inf(); second[sb] = -__builtin_inf(); idx[sb] = 0; }
 
-        for (int cb = 0; cb < Kp / 16; ++cb) {
+        for (int k0 = 0; k0 < Kp; k0 += KT) {
+        const int rows = min(KT, Kp - k0);      // a multiple of 16
+        if constexpr (CHUNKED) {
+            __syncthreads();                    // every wave is done with the previous chunk
+            for (int e = tid; e < rows * DS; e += BSM) {
+                const int k = e / DS, j = e - k * DS;
+                Cs[e] = (k0 + k < K && j < D) ? cent[(size_t)(k0 + k) * D + j] : 0.0;
+            }
+            for (int k = tid; k < rows; k += BSM) {
+                double nn = 0.0;
+                if (k0 + k < K)
+                    for (int j = 0; j < D; ++j) nn = __builtin_fma(cent[(size_t)(k0 + k) * D + j], cent[(size_t)(k0 + k) * D + j], nn);
+                cn[k] = k0 + k < K ? -0.5 * nn : -__builtin_inf();
+            }
+            __syncthreads();
+        }
+        for (int cb = 0; cb < rows / 16; ++cb) {
             double a[Q];
 #pragma unroll
             for (int q = 0; q < Q; ++q) a[q] = Cs[(16 * cb + s) * DS + 4 * q + g];   // A[i = lane&15][k = lane>>4]
@@ -119,11 +166,12 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
                 for (int r = 0; r < 4; ++r) {
                     const double v = acc[r];
                     second[sb] = fmax(second[sb], fmin(best[sb], v));
-                    idx[sb] = (v > best[sb]) ? 16 * cb + g + 4 * r : idx[sb];
+                    idx[sb] = (v > best[sb]) ? k0 + 16 * cb + g + 4 * r : idx[sb];
                     best[sb] = fmax(best[sb], v);
                 }
             }
         }
+        }   // chunks
         // merge the 4 lane groups (disjoint cluster subsets) of every sample block; lane (g, s) keeps sample 16 g + s
         double my_best = 0.0, my_second = 0.0;
         int my_idx = 0;
@@ -146,7 +194,7 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
 
         // ---- phase 2: one lane per sample, exact arithmetic
         const uint32_t i = base + lane;
-        if (i < n) {
+        if (active && i < n) {
             double x[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) x[j] = xt[(size_t)j * ldx + i];
@@ -156,7 +204,7 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
             uint32_t arg = (uint32_t)my_idx;
             double dist = 0.0;
             {
-                const double* c = Cs + (size_t)arg * DS;
+                const double* c = CHUNKED ? cent + (size_t)arg * D : Cs + (size_t)arg * DS;
 #pragma unroll
                 for (int j = 0; j < D; ++j) {
                     const double t = x[j] - c[j];
@@ -169,7 +217,7 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
                 double bd = __builtin_inf();
                 uint32_t ba = 0;
                 for (int k = 0; k < K; ++k) {
-                    const double* c = Cs + (size_t)k * DS;
+                    const double* c = CHUNKED ? cent + (size_t)k * D : Cs + (size_t)k * DS;
                     double sdist = 0.0;
 #pragma unroll
                     for (int j = 0; j < D; ++j) {
@@ -230,8 +278,8 @@ int launch_t(const KmeansArgs& a, int num_cus, size_t pstride, hipStream_t strea
     const int Kp = (a.K + 15) & ~15;
     const size_t table = sizeof(double) * ((size_t)Kp * (D + 1) + Kp + 1);
     const size_t accb = sizeof(u64) * (size_t)a.K * (3 * a.d + 1);
-    const bool use_lds = table + accb <= 78 * 1024;        // two workgroups per CU
-    const size_t smem = table + (use_lds ? accb : 0);
+    const bool chunked = table > 72 * 1024;                 // table beyond the LDS budget of two workgroups per CU
+    const bool use_lds = !chunked && table + accb <= 78 * 1024;
     // Accumulators that do not fit next to the centroid table: assignment only here, the sums by a separate sweep.
     const int accumulate_here = use_lds ? a.accumulate : 0;
     const uint32_t n_pad = (a.n + kSampleTile - 1) / kSampleTile * kSampleTile;
@@ -239,23 +287,30 @@ int launch_t(const KmeansArgs& a, int num_cus, size_t pstride, hipStream_t strea
     const uint32_t need = (n_pad / 64 + BSM / 64 - 1) / (BSM / 64);
     if ((uint32_t)grid > need) grid = (int)(need ? need : 1);
     if ((size_t)grid * pstride > a.partials_capacity) return -2;
-    if (use_lds)
-        hipLaunchKernelGGL((kmeans_mfma_kernel<D, true>), dim3(grid), dim3(BSM), smem, stream, a.xt, a.ldx, a.n, n_pad, a.d,
-                           a.centroids, a.K, a.scale, a.labels, a.old_labels, a.have_old, a.min_dist, accumulate_here, a.partials, pstride);
-    else
-        hipLaunchKernelGGL((kmeans_mfma_kernel<D, false>), dim3(grid), dim3(BSM), smem, stream, a.xt, a.ldx, a.n, n_pad, a.d,
-                           a.centroids, a.K, a.scale, a.labels, a.old_labels, a.have_old, a.min_dist, accumulate_here, a.partials, pstride);
+#define MLHIP_KM_ARGS a.xt, a.ldx, a.n, n_pad, a.d, a.centroids, a.K, a.scale, a.labels, a.old_labels, a.have_old, a.min_dist, \
+                      accumulate_here, a.partials, pstride
+    if (chunked) {
+        int KC = (int)((36 * 1024) / (sizeof(double) * (D + 2))) & ~15;     // rows per chunk: ~36 KB of table
+        if (KC < 16) KC = 16;
+        const size_t smem = sizeof(double) * ((size_t)KC * (D + 1) + KC + 1);
+        hipLaunchKernelGGL((kmeans_mfma_kernel<D, false, true>), dim3(grid), dim3(BSM), smem, stream, MLHIP_KM_ARGS, KC);
+    } else if (use_lds) {
+        hipLaunchKernelGGL((kmeans_mfma_kernel<D, true, false>), dim3(grid), dim3(BSM), table + accb, stream, MLHIP_KM_ARGS, 0);
+    } else {
+        hipLaunchKernelGGL((kmeans_mfma_kernel<D, false, false>), dim3(grid), dim3(BSM), table, stream, MLHIP_KM_ARGS, 0);
+    }
+#undef MLHIP_KM_ARGS
     if (a.accumulate && !use_lds) launch_kmeans_update(a, grid, pstride, stream);
     return grid;
 }
 
 }  // namespace
 
-/// The matrix-core kernel handles D = 4, 8, ..., 32, 40, ..., 64 when the centroid table fits LDS next to another workgroup.
+/// The matrix-core kernel handles D = 4, 8, ..., 32, 40, ..., 64 and any K (tables beyond the LDS budget are streamed in chunks).
 bool kmeans_mfma_supported(int D, int K)
 {
-    const int Kp = (K + 15) & ~15;
-    return D >= 4 && D <= kMaxDim && D % 4 == 0 && sizeof(double) * ((size_t)Kp * (D + 1) + Kp + 1) <= 72 * 1024;
+    (void)K;
+    return D >= 4 && D <= kMaxDim && D % 4 == 0;
 }
 
 int launch_kmeans_mfma(const KmeansArgs& a, int num_cus, hipStream_t stream)
