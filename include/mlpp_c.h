@@ -1,4 +1,4 @@
-/* mlpp_c.h -- flat C handles over the C++ facade (include/ML/*.hpp), so that the Python surface
+/* mlpp_c.h -- flat C handles over the C++ facade (the headers under include/ML), so that the Python surface
  * ml_amd.cppyml.clustering (the mirror of the reference's pybind11 module, cppyml/clustering.cpp:75-185) is plain
  * ctypes and needs neither pybind11 nor Eigen. Every function returns 0 or an MLHIP_E_* code (see mlhip.h);
  * mlhip_last_error() holds the message. std::invalid_argument / std::domain_error map to MLHIP_E_INVALID_ARGUMENT /

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void em_reduce_kernel(const double* __restrict
 {
     const int total = K * F;
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x * 256 < total) {
+    if ((int)blockIdx.x * 256 < total) {
         if (e < total) {
             const int k = e / F, f = e - k * F;
             const double* p = partials + (size_t)k * FP + f;

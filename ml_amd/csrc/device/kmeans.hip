@@ -19,29 +19,16 @@
 #include <cstdlib>
 
 #include "device.hpp"
+#include "exact_sum.hpp"
 
 namespace mlhip {
 namespace {
-
-typedef unsigned long long u64;
 
 // 1024-thread workgroups: the workgroup-private LDS accumulators (K*(3d+1) words, 51 KB at K=256, d=8) would otherwise
 // cap the CU at 3 small workgroups = 3 waves per SIMD, too few to cover the dependent FMA chain of a distance.
 constexpr int BS = 1024;
 // 32 < d <= 64: the coordinates alone take 2d VGPRs, so the workgroup shrinks to 512 threads (256 VGPRs per lane).
 constexpr int BS_BIG = 512;
-
-/// t (|t| < 2^94, integer part only is kept) -> limbs: t = i2 * 2^64 + u1 * 2^32 + u0 (+ dropped fraction), u0,u1 in [0, 2^32).
-__device__ __forceinline__ void split_limbs(double t, u64& w0, u64& w1, u64& w2)
-{
-    const double h2 = floor(t * 0x1p-64);
-    const double r = __builtin_fma(-h2, 0x1p64, t);         // exact, in [0, 2^64)
-    const double h1 = floor(r * 0x1p-32);
-    const double l = __builtin_fma(-h1, 0x1p32, r);          // exact, in [0, 2^32)
-    w2 = (u64)(long long)(int)h2;                            // |h2| < 2^30
-    w1 = (u64)(unsigned)h1;
-    w0 = (u64)(unsigned)l;                                   // truncates the fraction below one unit
-}
 
 template <int D, bool USE_LDS, int BS>
 __global__ __launch_bounds__(BS) void kmeans_assign_kernel(

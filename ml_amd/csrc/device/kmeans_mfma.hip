@@ -19,26 +19,15 @@
 //
 // Update statistics: exact fixed-point limb sums with integer atomics, exactly as in kmeans.hip.
 #include "device.hpp"
+#include "exact_sum.hpp"
 
 namespace mlhip {
 void launch_kmeans_update(const KmeansArgs& a, int grid, size_t pstride, hipStream_t stream);   // kmeans.hip
 namespace {
 
-typedef unsigned long long u64;
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int BSM = 512;   // threads per workgroup (8 waves; two workgroups per CU)
-
-__device__ __forceinline__ void split_limbs(double t, u64& w0, u64& w1, u64& w2)
-{
-    const double h2 = floor(t * 0x1p-64);
-    const double r = __builtin_fma(-h2, 0x1p64, t);
-    const double h1 = floor(r * 0x1p-32);
-    const double l = __builtin_fma(-h1, 0x1p32, r);
-    w2 = (u64)(long long)(int)h2;
-    w1 = (u64)(unsigned)h1;
-    w0 = (u64)(unsigned)l;
-}
 
 /// CHUNKED = false: the whole centroid table lives in LDS, waves run independently. CHUNKED = true (tables beyond the LDS
 /// budget, i.e. large K): the table is streamed through LDS in chunks of KC clusters; the 8 waves of a workgroup then

@@ -181,7 +181,8 @@ bool EM::fit(ConstMatrixRef data)
     if (maximise_first_) {
         // Start from responsibilities, then one M-step (ML/EM.cpp:120-125).
         const auto* closest = dynamic_cast<const Clustering::ClosestCentroid*>(responsibilities_initialiser_.get());
-        if (closest && typeid(*responsibilities_initialiser_) == typeid(Clustering::ClosestCentroid)) {
+        const Clustering::ResponsibilitiesInitialiser& initialiser = *responsibilities_initialiser_;
+        if (closest && typeid(initialiser) == typeid(Clustering::ClosestCentroid)) {
             // Library ClosestCentroid: draw the centroids on the host exactly as it would, run the nearest-centroid
             // pass (strict '<', first minimum wins: ML/Clustering.cpp:77-88) on the GPU and accumulate the one-hot
             // M-step from labels -- no N x K matrix is materialised.
