@@ -150,6 +150,12 @@ struct mlhip_data {
     PinnedBuf params_host, stats_host;
     int n_ll = 0;
     bool have_estep = false;
+    // source of the last statistics pass (for the per-component refinement pass)
+    int stats_mode = 0;
+    const double* stats_resp = nullptr;
+    size_t stats_ld = 0;
+    DevBuf refine_shift, refine_stats;
+    uint64_t refined_components = 0;   // diagnostic counter
     // K-means workspace
     DevBuf km_labels[2], km_cent, km_partials, km_out, km_mind, km_scale;
     PinnedBuf km_host;
@@ -159,7 +165,8 @@ struct mlhip_data {
     ~mlhip_data()
     {
         for (DevBuf* b : {&xt, &shift_dev, &lw, &lse, &ll_partials, &params_dev, &partials, &stats_dev, &resp_dev,
-                          &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_partials, &km_out, &km_mind, &km_scale})
+                          &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_partials, &km_out, &km_mind, &km_scale,
+                          &refine_shift, &refine_stats})
             b->release();
         params_host.release(); stats_host.release(); km_host.release();
     }
@@ -419,6 +426,9 @@ void run_mstats(mlhip_data* dt, int K, int mode, const double* resp_dev, size_t 
     a.ll_partials = with_ll ? dt->ll_partials.as<double>() : nullptr;
     a.n_ll_partials = with_ll ? dt->n_ll : 0;
     a.stats = dt->stats_dev.as<double>();
+    dt->stats_mode = mode;
+    dt->stats_resp = a.lw;
+    dt->stats_ld = a.ldr;
     int rc = 0;
     ctx->timed("em_mstats", [&] { rc = launch_em_mstats(a, ctx->num_cus, ctx->stream); });
     if (rc <= 0) throw std::runtime_error("statistics kernel launch failed (plan/scratch)");
@@ -452,10 +462,88 @@ void check_em_args(mlhip_ctx* ctx, mlhip_data* dt, uint32_t K)
     ctx->use();
 }
 
+/// Ratio (mean offset from the shared shift)^2 / variance above which a component's covariance is recomputed about its
+/// own mean. The one-GEMM statistics share one shift (the global mean), so Sigma_k = M2'/S0 - m m^T cancels
+/// ~log10(ratio) digits: measured relative error ~3e-15 * ratio. 1e4 keeps every covariance within ~3e-11 of the
+/// two-pass form the reference uses (ML/EM.cpp:245-250). MLHIP_REFINE_RATIO overrides; <= 0 disables the refinement.
+double refine_ratio()
+{
+    static const double r = [] {
+        const char* e = std::getenv("MLHIP_REFINE_RATIO");
+        return (e && *e) ? std::atof(e) : 1e4;
+    }();
+    return r;
+}
+
+/// Second statistics pass for ONE component with the shift at that component's new mean (K = 1 launch of the same
+/// kernels on column k of the responsibilities of the last pass), all-reduced like the first; replaces covariance k
+/// (and adds the tiny mean correction). Tight clusters far from the global mean need it; the headline shapes never do.
+void refine_component(mlhip_data* dt, int k, double* mean_k, double* cov_k)
+{
+    mlhip_ctx* ctx = dt->ctx;
+    const int d = dt->d, F = stats_count(d);
+    dt->refine_shift.reserve(sizeof(double) * d);
+    dt->refine_stats.reserve(sizeof(double) * (F + 1));
+    HIP_CHECK(hipMemcpyAsync(dt->refine_shift.p, mean_k, sizeof(double) * d, hipMemcpyHostToDevice, ctx->stream));
+    MstatsArgs a{};
+    a.xt = dt->xt.as<double>(); a.ldx = dt->ldx; a.n = dt->n; a.d = d;
+    a.shift = dt->refine_shift.as<double>();
+    a.lw = dt->stats_resp + (size_t)k * dt->stats_ld; a.ldr = dt->stats_ld; a.lse = dt->lse.as<double>();
+    a.K = 1; a.mode = dt->stats_mode;
+    a.partials = dt->partials.as<double>(); a.partials_capacity = dt->partials.bytes / sizeof(double);
+    a.ll_partials = nullptr; a.n_ll_partials = 0;
+    a.stats = dt->refine_stats.as<double>();
+    int rc = 0;
+    ctx->timed("em_refine", [&] { rc = launch_em_mstats(a, ctx->num_cus, ctx->stream); });
+    if (rc <= 0) throw std::runtime_error("statistics kernel launch failed (refinement pass)");
+    launch_em_reduce(a, ctx->num_cus, rc, ctx->stream);
+    HIP_CHECK(hipGetLastError());
+    std::vector<double> s((size_t)F);
+    if (ctx->reduce_fn && ctx->reduce_on_device) {
+        if (ctx->reduce_fn(ctx->reduce_user, dt->refine_stats.as<double>(), (size_t)F, 1, ctx->stream) != 0)
+            throw std::runtime_error("all-reduce hook failed");
+    }
+    HIP_CHECK(hipMemcpyAsync(s.data(), dt->refine_stats.p, sizeof(double) * F, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+    if (ctx->reduce_fn && !ctx->reduce_on_device) {
+        if (ctx->reduce_fn(ctx->reduce_user, s.data(), (size_t)F, 0, ctx->stream) != 0) throw std::runtime_error("all-reduce hook failed");
+    }
+    const double s0 = s[stats_index(d, d)];
+    std::vector<double> m(d);
+    for (int a2 = 0; a2 < d; ++a2) m[a2] = s[stats_index(d, a2)] / s0;          // ~0: the shift is the mean already
+    for (int a2 = 0; a2 < d; ++a2)
+        for (int b = 0; b <= a2; ++b) {
+            const double v = (s[stats_index(a2, b)] - s[stats_index(d, a2)] * m[b]) / s0;
+            cov_k[b * d + a2] = v;
+            cov_k[a2 * d + b] = v;
+        }
+    for (int a2 = 0; a2 < d; ++a2) {
+        cov_k[a2 * d + a2] += 1e-15;                                            // ML/EM.cpp:252
+        mean_k[a2] += m[a2];
+    }
+    dt->refined_components += 1;
+}
+
 void finalize_out(mlhip_data* dt, int K, double* mixing_out, double* means_out, double* cov_out)
 {
-    host::finalize_mstep(dt->d, K, dt->stats_host.as<double>(), dt->shift.data(), (double)dt->n_global, mixing_out,
+    const int d = dt->d;
+    host::finalize_mstep(d, K, dt->stats_host.as<double>(), dt->shift.data(), (double)dt->n_global, mixing_out,
                          means_out, cov_out);
+    const double limit = refine_ratio();
+    if (!(limit > 0)) return;
+    // Every rank sees the same all-reduced statistics, hence flags the same components in the same order.
+    for (int k = 0; k < K; ++k) {
+        const double* mu = means_out + (size_t)k * d;
+        const double* cov = cov_out + (size_t)k * d * d;
+        if (!(mixing_out[k] > 0) || !std::isfinite(mixing_out[k])) continue;    // empty / broken component: as the reference
+        bool flag = false;
+        for (int a = 0; a < d && !flag; ++a) {
+            const double off = mu[a] - dt->shift[a], var = cov[a * d + a];
+            if (!std::isfinite(off) || !std::isfinite(var)) { flag = false; break; }   // NaN stays NaN (ML/EM.cpp:236)
+            flag = off * off > limit * var;                                      // also catches var <= 0 from cancellation
+        }
+        if (flag) refine_component(dt, k, means_out + (size_t)k * d, cov_out + (size_t)k * d * d);
+    }
 }
 
 void ensure_km_workspace(mlhip_data* dt, int K)

@@ -302,3 +302,34 @@ def test_kmeans_mfma_and_valu_kernels_agree_bitwise(ctx, oracle, n, d, K, monkey
     step = max(1, n // 500)
     ref = np.array([km.assign_label(X[i])[1] for i in range(0, n, step)])
     assert np.array_equal(a[4][::step], ref)          # distances bit-identical to the oracle's fma chain
+
+
+@pytest.mark.parametrize("sigma,tol", [(1.0, 1e-12), (1e-2, 1e-11), (1e-4, 1e-10), (1e-6, 1e-8)])
+def test_tight_clusters_far_from_the_global_mean(ctx, oracle, sigma, tol):
+    """Clusters whose width is tiny next to their distance from the global mean: the one-GEMM statistics (shared shift)
+    would cancel log10((spread/sigma)^2) digits of the covariances, so such components get a second pass about their own
+    mean. Parity with the reference's two-pass form holds down to the conditioning of the problem itself
+    (~1e-16 * spread / sigma); well-conditioned components are never refined."""
+    rng = np.random.default_rng(5)
+    d, K, n = 8, 4, 4000
+    means = 10.0 * rng.standard_normal((K, d))
+    comp = rng.integers(0, K, n)
+    X = np.ascontiguousarray(means[comp] + sigma * rng.standard_normal((n, d)))
+    mu0 = means + 0.1 * sigma * rng.standard_normal((K, d))
+    S0 = np.stack([np.eye(d) * sigma ** 2] * K)
+    pi0 = np.full(K, 1.0 / K)
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    dt = _data(ctx, X)
+    ll, pi1, mu1, S1 = dt.em_step(pi0, mu0, S0)
+    dt.close()
+    _, refinements = ctx.timing_get("em_refine")
+    ctx.timing_enable(False)
+    em = oracle.EM(K)
+    em.set_parameters(mu0, S0, pi0)
+    em.expectation_step(X)
+    em.maximisation_step(X)
+    assert abs(ll - em.log_likelihood) <= 1e-12 * abs(em.log_likelihood)
+    assert relerr(mu1, em.means) < 1e-13
+    assert relerr(S1, em.covariances) < tol
+    assert refinements == (0 if sigma == 1.0 else K)
