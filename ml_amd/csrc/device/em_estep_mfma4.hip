@@ -69,18 +69,19 @@ __device__ __forceinline__ double reduce_scatter_groups(double v0, double v1, do
 /// wave, 8 waves per workgroup, half the coordinate/accumulator registers -> 4 waves per SIMD). A workgroup always
 /// covers 256 samples per component sweep, so the record staging traffic is the same.
 template <int D, int SB>
-__global__ __launch_bounds__(1024 / SB, D <= 32 ? 8 / SB : 2) void em_estep_mfma4_kernel(
+__global__ __launch_bounds__(SB == 1 ? 512 : 1024 / SB, D <= 32 ? 8 / SB : 2) void em_estep_mfma4_kernel(
     const double* __restrict__ xt, size_t ldx, uint32_t n, uint32_t n_groups, const double* __restrict__ params, int K,
     double* __restrict__ lw_out, size_t ldr, double* __restrict__ lse_out, double* __restrict__ ll_partials)
 {
     using B = Blocks<D>;
     constexpr int Q = B::Q, NB = B::NB, PS = B::PS;
-    constexpr int NT = 1024 / SB, NWV = NT / 64;   // threads / waves per workgroup
+    constexpr int NT = SB == 1 ? 512 : 1024 / SB, NWV = NT / 64;   // threads / waves per workgroup
     constexpr int GS = 16 * SB;                    // samples per wave
     constexpr int W = 4;                           // LDS read-ahead window (blocks)
     constexpr int NLD = (PS + NT - 1) / NT;        // doubles of a record each thread moves to LDS
     __shared__ double red[NWV];
-    __shared__ double recs[2][NLD * NT];           // the component record, staged once per workgroup, double-buffered
+    extern __shared__ __attribute__((aligned(16))) double recs_dyn[];   // [2][NLD * NT]: the component record, staged
+    double (*recs)[NLD * NT] = reinterpret_cast<double (*)[NLD * NT]>(recs_dyn);   // once per workgroup, double-buffered
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, s = lane & 15;
     const int aoff = g * 4 + (lane & 3);          // A operand: entry [k = lane>>4][i = lane&3] of a 16-double block
@@ -150,7 +151,11 @@ __global__ __launch_bounds__(1024 / SB, D <= 32 ? 8 / SB : 2) void em_estep_mfma
                 qs[sb] = t2;
             }
             double q;
-            if constexpr (SB == 4) {
+            if constexpr (SB == 1) {
+                // one block: the four lane groups hold the four row residues of the same 16 samples
+                const double t = qs[0] + __shfl_xor(qs[0], 16, 64);
+                q = t + __shfl_xor(t, 32, 64);
+            } else if constexpr (SB == 4) {
                 q = reduce_scatter_groups(qs[0], qs[1], qs[2], qs[3]);   // lane (g, s) gets sample 16g + s
             } else {
                 // two blocks: rows g, g^1 exchange so that even rows hold block 0 and odd rows block 1, then the two
@@ -199,14 +204,16 @@ __global__ __launch_bounds__(1024 / SB, D <= 32 ? 8 / SB : 2) void em_estep_mfma
 template <int D, int SB>
 int launch_sb(const EstepArgs& a, int num_cus, hipStream_t stream)
 {
-    constexpr int NT = 1024 / SB, NWV = NT / 64, GS = 16 * SB;
+    constexpr int NT = SB == 1 ? 512 : 1024 / SB, NWV = NT / 64, GS = 16 * SB;
+    constexpr int NLD = (Blocks<D>::PS + NT - 1) / NT;
+    const size_t smem = sizeof(double) * 2 * NLD * NT;
     const uint32_t n_pad = (a.n + kSampleTile - 1) / kSampleTile * kSampleTile;
     const uint32_t n_groups = n_pad / GS;
     uint32_t grid = (n_groups + NWV - 1) / NWV;
     const uint32_t cap = (uint32_t)num_cus * 2;          // 2 workgroups per CU, persistent
     if (grid > cap) grid = cap;
     if (grid > (uint32_t)a.n_ll_partials) grid = (uint32_t)a.n_ll_partials;
-    hipLaunchKernelGGL((em_estep_mfma4_kernel<D, SB>), dim3(grid), dim3(NT), 0, stream, a.xt, a.ldx, a.n, n_groups, a.params,
+    hipLaunchKernelGGL((em_estep_mfma4_kernel<D, SB>), dim3(grid), dim3(NT), smem, stream, a.xt, a.ldx, a.n, n_groups, a.params,
                        a.K, a.lw, a.ldr, a.lse, a.ll_partials);
     return (int)grid;
 }
@@ -216,7 +223,9 @@ int launch_t(const EstepArgs& a, int num_cus, hipStream_t stream)
 {
     // MLHIP_ESTEP_SB=2 selects the 32-samples-per-wave variant (A/B experiments); default 4.
     static const int sb = [] { const char* e = std::getenv("MLHIP_ESTEP_SB"); return (e && e[0] == '2') ? 2 : 4; }();
-    if constexpr (D > 32) {
+    if constexpr (D > 64) {
+        return launch_sb<D, 1>(a, num_cus, stream);     // one sample block per wave (16 samples): 2D doubles per lane
+    } else if constexpr (D > 32) {
         // 2 sample blocks per wave: D coordinate + D accumulator doubles per lane pair do not fit otherwise
         return launch_sb<D, 2>(a, num_cus, stream);
     } else {
@@ -242,6 +251,14 @@ int launch_em_estep_mfma4(const EstepArgs& a, int num_cus, hipStream_t stream)
     case 48: return launch_t<48>(a, num_cus, stream);
     case 56: return launch_t<56>(a, num_cus, stream);
     case 64: return launch_t<64>(a, num_cus, stream);
+    case 72: return launch_t<72>(a, num_cus, stream);
+    case 80: return launch_t<80>(a, num_cus, stream);
+    case 88: return launch_t<88>(a, num_cus, stream);
+    case 96: return launch_t<96>(a, num_cus, stream);
+    case 104: return launch_t<104>(a, num_cus, stream);
+    case 112: return launch_t<112>(a, num_cus, stream);
+    case 120: return launch_t<120>(a, num_cus, stream);
+    case 128: return launch_t<128>(a, num_cus, stream);
     default: return -1;
     }
 }

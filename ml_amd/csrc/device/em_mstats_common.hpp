@@ -9,7 +9,9 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int TS = 64;            // samples per LDS tile
 constexpr int XS = kRegDim + 3;   // LDS row stride of the sample tile in doubles: d+1 coordinates + zero slot, odd (35)
-constexpr int XS_BIG = kMaxDim + 3;   // the same for 32 < d <= 64 (67)
+constexpr int XS_MID = kMidDim + 3;   // the same for 32 < d <= 64 (67)
+constexpr int XS_BIG = kMaxDim + 3;   // and for 64 < d <= 128 (131)
+template <int DM> constexpr int tile_stride() { return DM <= kRegDim ? XS : (DM <= kMidDim ? XS_MID : XS_BIG); }
 
 /// Column `col` of the packed lower triangle of xt xt^T -> its (row a, column b) pair; padding columns map to the
 /// zero slot `da` of the LDS row.

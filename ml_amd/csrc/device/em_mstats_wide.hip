@@ -26,8 +26,9 @@ __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int RS = RBW * 16 + 1;     // odd row stride of the responsibility tile
-    constexpr int NXV = DM / NW;         // x rows staged per thread (4, or 8 for d > 32)
-    constexpr int XS = DM <= kRegDim ? mstats::XS : mstats::XS_BIG;
+    constexpr int NXV = DM / NW;         // x rows staged per thread (4; 8 for d > 32; 16 for d > 64)
+    constexpr int XS = tile_stride<DM>();
+    constexpr bool DOUBLE_BUF = DM <= kMidDim;   // two (x~, R) tiles of 64 samples do not fit LDS above d = 64
     constexpr int NRV = RBW * 16 / NW;   // responsibility rows staged per thread (2 * RBW)
     const int da = d + 1;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -92,7 +93,8 @@ __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
     constexpr int tile_doubles = TS * XS + TS * RS;
     int buf = 0;
     if (blockIdx.x < n_tiles) prefetch(blockIdx.x);
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, buf ^= DOUBLE_BUF ? 1 : 0) {
+        if constexpr (!DOUBLE_BUF) __syncthreads();   // single tile buffer: everyone is done reading the previous tile
         double* Xb = smem + buf * tile_doubles;
         double* Rb = Xb + TS * XS;
         stage(Xb, Rb, tile);
@@ -149,8 +151,8 @@ __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
 template <int RBW, int CBW, int DM = kRegDim>
 void launch_t(const MstatsArgs& a, const Plan& p, int grid_x, hipStream_t stream)
 {
-    constexpr int XSD = DM <= kRegDim ? XS : XS_BIG;
-    const size_t smem = 2 * sizeof(double) * ((size_t)TS * XSD + (size_t)TS * (RBW * 16 + 1));   // double-buffered
+    constexpr int XSD = tile_stride<DM>();
+    const size_t smem = (DM <= kMidDim ? 2 : 1) * sizeof(double) * ((size_t)TS * XSD + (size_t)TS * (RBW * 16 + 1));
     const dim3 grid(grid_x, p.n_rbg * p.n_cbg);
     if (a.mode == kFromLogResp)
         hipLaunchKernelGGL((em_mstats_wide_kernel<RBW, CBW, true, DM>), grid, dim3(512), smem, stream, a.xt, a.ldx, a.n, a.d,
@@ -165,9 +167,11 @@ void launch_t(const MstatsArgs& a, const Plan& p, int grid_x, hipStream_t stream
 int launch_wide(const MstatsArgs& a, const Plan& p, int grid_x, hipStream_t stream)
 {
     if (a.d > kRegDim) {
-        // 32 < d <= 64: 38..135 column blocks in 1..4 column groups of 8 waves x (3, 4 or 5) blocks
+        // 32 < d <= 128: 38..525 column blocks in column groups of 8 waves x (3, 4 or 5) blocks
 #define MLHIP_BIG(R, C) \
-    if (p.RBW == R && p.CBW == C) { launch_t<R, C, kMaxDim>(a, p, grid_x, stream); } else
+    if (p.RBW == R && p.CBW == C) { \
+        if (a.d <= kMidDim) launch_t<R, C, kMidDim>(a, p, grid_x, stream); else launch_t<R, C, kMaxDim>(a, p, grid_x, stream); \
+    } else
         MLHIP_BIG(1, 3) MLHIP_BIG(1, 4) MLHIP_BIG(1, 5) MLHIP_BIG(2, 3) MLHIP_BIG(2, 4) MLHIP_BIG(2, 5)
         MLHIP_BIG(4, 3) MLHIP_BIG(4, 4) MLHIP_BIG(4, 5)
         { return -1; }

@@ -259,7 +259,8 @@ int launch_kmeans_assign(const KmeansArgs& a_in, int num_cus, hipStream_t stream
     // Matrix-core search with exact recheck (kmeans_mfma.hip) where it applies; MLHIP_KMEANS=valu forces this file's kernel.
     const char* e = std::getenv("MLHIP_KMEANS");
     const bool force_valu = e && e[0] == 'v';
-    if (!force_valu && kmeans_mfma_supported(a_in.D, a_in.K)) return launch_kmeans_mfma(a_in, num_cus, stream);
+    // (above d = 64 only the matrix-core kernel exists)
+    if ((!force_valu || a_in.D > kMidDim) && kmeans_mfma_supported(a_in.D, a_in.K)) return launch_kmeans_mfma(a_in, num_cus, stream);
     const size_t pstride = 2 + (size_t)a_in.K * (3 * a_in.d + 1);
     int grid = kmeans_grid(num_cus);
     const uint32_t bs = a_in.D <= kRegDim ? BS : BS_BIG;

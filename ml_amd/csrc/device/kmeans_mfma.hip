@@ -29,6 +29,26 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int BSM = 512;   // threads per workgroup (8 waves; two workgroups per CU)
 
+/// One sample's coordinates for the exact phase: registers up to d = 64, re-read from memory (L1/L2) above.
+template <int D> struct SampleRow {
+    static constexpr bool kInRegs = D <= kMidDim;
+    double x[kInRegs ? D : 1];
+    const double* p;
+    size_t ld;
+    __device__ __forceinline__ SampleRow(const double* xt, size_t ldx, uint32_t i) : p(xt + i), ld(ldx)
+    {
+        if constexpr (kInRegs) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) x[j] = p[(size_t)j * ld];
+        }
+    }
+    __device__ __forceinline__ double operator()(int j) const
+    {
+        if constexpr (kInRegs) return x[j];
+        else return p[(size_t)j * ld];
+    }
+};
+
 /// CHUNKED = false: the whole centroid table lives in LDS, waves run independently. CHUNKED = true (tables beyond the LDS
 /// budget, i.e. large K): the table is streamed through LDS in chunks of KC clusters; the 8 waves of a workgroup then
 /// walk their 64-sample groups in lockstep (two barriers per chunk), keep the running best / second / argbest in
@@ -40,6 +60,11 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
     int have_old, double* __restrict__ min_dist, int accumulate, double* __restrict__ partials, size_t pstride, int KC)
 {
     constexpr int Q = D / 4;          // 4-dimension steps of the MFMA
+    constexpr int NSB = D <= kMidDim ? 4 : 2;   // 16-sample blocks per wave: the coordinates take Q * NSB doubles per lane
+    constexpr int GS = 16 * NSB;      // samples per wave group
+    // exact phase: fully unrolled on register-resident coordinates up to d = 64; above, rolled loops that re-read the
+    // sample (unrolling would let the compiler hoist all D loads back into registers)
+    constexpr int kExactUnroll = D <= kMidDim ? D : 2;
     constexpr int DS = D + 1;         // odd row stride of the centroid table: conflict-free A-operand reads
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int Kp = (K + 15) & ~15;
@@ -101,7 +126,7 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
     const double err_unit = 8.0 * (D + 2) * 0x1p-53;
 
     double inertia = 0.0, changed = 0.0;
-    const uint32_t n_groups = n_pad / 64;
+    const uint32_t n_groups = n_pad / GS;
     const uint32_t per_sweep = gridDim.x * (BSM / 64);
     const uint32_t n_sweeps = (n_groups + per_sweep - 1) / per_sweep;          // uniform over the workgroup
     for (uint32_t sweep = 0; sweep < n_sweeps; ++sweep) {
@@ -111,17 +136,17 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
             if constexpr (!CHUNKED) break;     // independent waves: done
             grp = n_groups - 1;                // lockstep: keep serving the barriers (and the table loads) on a valid group
         }
-        const uint32_t base = grp * 64;
+        const uint32_t base = grp * GS;
         // ---- phase 1: scores on the matrix cores. xb[q][sb] = x[dim 4q + g][sample base + 16 sb + s]
-        double xb[Q][4];
+        double xb[Q][NSB];
 #pragma unroll
         for (int q = 0; q < Q; ++q)
 #pragma unroll
-            for (int sb = 0; sb < 4; ++sb) xb[q][sb] = xt[(size_t)(4 * q + g) * ldx + base + 16 * sb + s];
-        double best[4], second[4];
-        int idx[4];
+            for (int sb = 0; sb < NSB; ++sb) xb[q][sb] = xt[(size_t)(4 * q + g) * ldx + base + 16 * sb + s];
+        double best[NSB], second[NSB];
+        int idx[NSB];
 #pragma unroll
-        for (int sb = 0; sb < 4; ++sb) { best[sb] = -__builtin_inf(); second[sb] = -__builtin_inf(); idx[sb] = 0; }
+        for (int sb = 0; sb < NSB; ++sb) { best[sb] = -__builtin_inf(); second[sb] = -__builtin_inf(); idx[sb] = 0; }
 
         for (int k0 = 0; k0 < Kp; k0 += KT) {
         const int rows = min(KT, Kp - k0);      // a multiple of 16
@@ -140,20 +165,36 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
             __syncthreads();
         }
         for (int cb = 0; cb < rows / 16; ++cb) {
-            double a[Q];
-#pragma unroll
-            for (int q = 0; q < Q; ++q) a[q] = Cs[(16 * cb + s) * DS + 4 * q + g];   // A[i = lane&15][k = lane>>4]
             d4 init;
 #pragma unroll
             for (int r = 0; r < 4; ++r) init[r] = cn[16 * cb + g + 4 * r];           // D row = (lane>>4) + 4 r
+            d4 acc[NSB];
+            if constexpr (D <= kMidDim) {
+                double a[Q];
 #pragma unroll
-            for (int sb = 0; sb < 4; ++sb) {
-                d4 acc = init;
+                for (int q = 0; q < Q; ++q) a[q] = Cs[(16 * cb + s) * DS + 4 * q + g];   // A[i = lane&15][k = lane>>4]
 #pragma unroll
-                for (int q = 0; q < Q; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], xb[q][sb], acc, 0, 0, 0);
+                for (int sb = 0; sb < NSB; ++sb) {
+                    acc[sb] = init;
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) acc[sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], xb[q][sb], acc[sb], 0, 0, 0);
+                }
+            } else {
+                // large d: the A operands are read step by step (Q of them would not fit next to the coordinates)
+#pragma unroll
+                for (int sb = 0; sb < NSB; ++sb) acc[sb] = init;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const double aq = Cs[(16 * cb + s) * DS + 4 * q + g];
+#pragma unroll
+                    for (int sb = 0; sb < NSB; ++sb) acc[sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, xb[q][sb], acc[sb], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int sb = 0; sb < NSB; ++sb) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double v = acc[r];
+                    const double v = acc[sb][r];
                     second[sb] = fmax(second[sb], fmin(best[sb], v));
                     idx[sb] = (v > best[sb]) ? k0 + 16 * cb + g + 4 * r : idx[sb];
                     best[sb] = fmax(best[sb], v);
@@ -165,7 +206,7 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
         double my_best = 0.0, my_second = 0.0;
         int my_idx = 0;
 #pragma unroll
-        for (int sb = 0; sb < 4; ++sb) {
+        for (int sb = 0; sb < NSB; ++sb) {
             double b = best[sb], sd = second[sb];
             int ix = idx[sb];
 #pragma unroll
@@ -183,20 +224,18 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
 
         // ---- phase 2: one lane per sample, exact arithmetic
         const uint32_t i = base + lane;
-        if (active && i < n) {
-            double x[D];
-#pragma unroll
-            for (int j = 0; j < D; ++j) x[j] = xt[(size_t)j * ldx + i];
+        if (active && lane < GS && i < n) {
+            const SampleRow<D> x(xt, ldx, i);
             double xn = 0.0;
-#pragma unroll
-            for (int j = 0; j < D; ++j) xn = __builtin_fma(x[j], x[j], xn);
+#pragma unroll kExactUnroll
+            for (int j = 0; j < D; ++j) { const double v = x(j); xn = __builtin_fma(v, v, xn); }
             uint32_t arg = (uint32_t)my_idx;
             double dist = 0.0;
             {
                 const double* c = CHUNKED ? cent + (size_t)arg * D : Cs + (size_t)arg * DS;
-#pragma unroll
+#pragma unroll kExactUnroll
                 for (int j = 0; j < D; ++j) {
-                    const double t = x[j] - c[j];
+                    const double t = x(j) - c[j];
                     dist = __builtin_fma(t, t, dist);
                 }
             }
@@ -208,9 +247,9 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
                 for (int k = 0; k < K; ++k) {
                     const double* c = CHUNKED ? cent + (size_t)k * D : Cs + (size_t)k * DS;
                     double sdist = 0.0;
-#pragma unroll
+#pragma unroll kExactUnroll
                     for (int j = 0; j < D; ++j) {
-                        const double t = x[j] - c[j];
+                        const double t = x(j) - c[j];
                         sdist = __builtin_fma(t, t, sdist);
                     }
                     if (sdist < bd) { bd = sdist; ba = (uint32_t)k; }
@@ -224,11 +263,11 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
             changed += (!have_old || old_labels[i] != arg) ? 1.0 : 0.0;
             if (accumulate) {
                 u64* row = (USE_LDS ? acc_lds : my_words) + (size_t)arg * W;
-#pragma unroll
+#pragma unroll kExactUnroll
                 for (int j = 0; j < D; ++j) {
                     if (j < d) {
                         u64 w0, w1, w2;
-                        split_limbs(x[j] * scale[j], w0, w1, w2);   // wave-uniform index: scalar load
+                        split_limbs(x(j) * scale[j], w0, w1, w2);   // wave-uniform index: scalar load
                         atomicAdd(row + 3 * j, w0);
                         atomicAdd(row + 3 * j + 1, w1);
                         atomicAdd(row + 3 * j + 2, w2);
@@ -273,7 +312,8 @@ int launch_t(const KmeansArgs& a, int num_cus, size_t pstride, hipStream_t strea
     const int accumulate_here = use_lds ? a.accumulate : 0;
     const uint32_t n_pad = (a.n + kSampleTile - 1) / kSampleTile * kSampleTile;
     int grid = num_cus * 2;
-    const uint32_t need = (n_pad / 64 + BSM / 64 - 1) / (BSM / 64);
+    const uint32_t groups = n_pad / (D <= kMidDim ? 64 : 32);
+    const uint32_t need = (groups + BSM / 64 - 1) / (BSM / 64);
     if ((uint32_t)grid > need) grid = (int)(need ? need : 1);
     if ((size_t)grid * pstride > a.partials_capacity) return -2;
 #define MLHIP_KM_ARGS a.xt, a.ldx, a.n, n_pad, a.d, a.centroids, a.K, a.scale, a.labels, a.old_labels, a.have_old, a.min_dist, \
@@ -295,7 +335,7 @@ int launch_t(const KmeansArgs& a, int num_cus, size_t pstride, hipStream_t strea
 
 }  // namespace
 
-/// The matrix-core kernel handles D = 4, 8, ..., 32, 40, ..., 64 and any K (tables beyond the LDS budget are streamed in chunks).
+/// The matrix-core kernel handles D = 4, 8, ..., 32, 40, ..., 128 and any K (tables beyond the LDS budget are streamed in chunks).
 bool kmeans_mfma_supported(int D, int K)
 {
     (void)K;
@@ -318,6 +358,14 @@ int launch_kmeans_mfma(const KmeansArgs& a, int num_cus, hipStream_t stream)
     case 48: return launch_t<48>(a, num_cus, pstride, stream);
     case 56: return launch_t<56>(a, num_cus, pstride, stream);
     case 64: return launch_t<64>(a, num_cus, pstride, stream);
+    case 72: return launch_t<72>(a, num_cus, pstride, stream);
+    case 80: return launch_t<80>(a, num_cus, pstride, stream);
+    case 88: return launch_t<88>(a, num_cus, pstride, stream);
+    case 96: return launch_t<96>(a, num_cus, pstride, stream);
+    case 104: return launch_t<104>(a, num_cus, pstride, stream);
+    case 112: return launch_t<112>(a, num_cus, pstride, stream);
+    case 120: return launch_t<120>(a, num_cus, pstride, stream);
+    case 128: return launch_t<128>(a, num_cus, pstride, stream);
     default: return -1;
     }
 }

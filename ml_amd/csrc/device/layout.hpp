@@ -9,14 +9,17 @@ namespace mlhip {
 constexpr int kSampleTile = 256;  // N is padded to a multiple of this in HBM
 
 /// Largest dimension the kernels are instantiated for. Up to kRegDim every kernel variant exists (the headline shapes);
-/// above it only the 4x4-block matrix-core E-step, the wide statistics kernel and the K-means kernels with smaller workgroups.
-constexpr int kMaxDim = 64;
+/// above it only the 4x4-block matrix-core E-step, the wide statistics kernel and the matrix-core K-means kernel, with
+/// fewer samples per wave in each tier (kRegDim < d <= kMidDim, kMidDim < d <= kMaxDim): a wave keeps its samples'
+/// coordinates in registers.
+constexpr int kMaxDim = 128;
+constexpr int kMidDim = 64;
 constexpr int kRegDim = 32;
 
 /// Dimension the kernels are instantiated for: d is padded with zero coordinates up to this.
 inline int padded_dim(int d)
 {
-    static const int sizes[] = {1, 2, 3, 4, 6, 8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64};
+    static const int sizes[] = {1, 2, 3, 4, 6, 8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64, 72, 80, 88, 96, 104, 112, 120, 128};
     for (int s : sizes)
         if (d <= s) return s;
     return -1;
@@ -35,7 +38,7 @@ inline int estep_mfma_slab_count(int D) { return D <= 16 ? estep_mfma_slabs_of(D
 inline int estep_mfma_param_stride(int D) { return estep_mfma_slab_count(D) * 64 + D + 1; }
 inline bool estep_mfma_supported(int D) { return D >= 12 && D <= 32 && D % 4 == 0; }
 
-/// 4x4-block E-step (v_mfma_f64_4x4x4_4b_f64; dimensions 12..64, multiples of 4): W is cut into 4x4 blocks (R, C); only
+/// 4x4-block E-step (v_mfma_f64_4x4x4_4b_f64; dimensions 12..128, multiples of 4): W is cut into 4x4 blocks (R, C); only
 /// blocks on or below the diagonal exist, ordered by column quad C, then row quad R. Record of one component,
 /// estep_mfma4_param_stride(D) doubles: [ block t: 16 doubles, entry [k][i] = W[4R + i][4C + k] | mean(D) | coef ].
 inline bool estep_mfma4_supported(int D) { return D >= 12 && D <= kMaxDim && D % 4 == 0; }

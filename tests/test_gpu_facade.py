@@ -309,9 +309,9 @@ def test_converged_labels_bit_exact_d16_K16(oracle):
     assert np.max(np.abs(em.means.T - ref.means)) <= 1e-10 * np.max(np.abs(ref.means))
 
 
-@pytest.mark.parametrize("d,K,n", [(40, 6, 6000), (64, 8, 8000), (50, 3, 4000)])
+@pytest.mark.parametrize("d,K,n", [(40, 6, 6000), (64, 8, 8000), (50, 3, 4000), (100, 4, 6000), (128, 3, 5000)])
 def test_fits_above_32_dimensions(oracle, d, K, n):
-    """32 < d <= 64 (4x4-block E-step with 2 sample blocks per wave, statistics in several column groups, K-means with the
+    """32 < d <= 128 (4x4-block E-step with 2 sample blocks per wave, statistics in several column groups, K-means with the
     large-d kernels): EM converge-run and K-means fit against the oracle -- labels exact, parameters within tolerance."""
     from ml_amd import synth
     cl = _clustering()

@@ -1,4 +1,4 @@
-"""Seeded random sweep over shapes (d = 1..64, K = 1..70, ragged N) comparing one E+M iteration, labels, sample covariance and
+"""Seeded random sweep over shapes (d = 1..128, K = 1..70, ragged N) comparing one E+M iteration, labels, sample covariance and
 one K-means step of the HIP path against the CPU oracle -- exercises every kernel variant (padded dimensions, VALU / MFMA E-step,
 narrow / wide statistics kernels, K not a multiple of 16, tiles with a ragged tail). Needs a GPU: `pytest -m gpu`."""
 import numpy as np
@@ -14,7 +14,7 @@ def relerr(a, b):
 def _cases():
     rng = np.random.default_rng(20241003)
     cases = []
-    for d in list(range(1, 33)) + [8, 16, 32, 32] + [33, 36, 40, 41, 47, 48, 50, 56, 57, 63, 64, 64]:
+    for d in list(range(1, 33)) + [8, 16, 32, 32] + [33, 36, 40, 41, 47, 48, 50, 56, 57, 63, 64, 64] + [65, 72, 77, 88, 96, 100, 120, 127, 128]:
         K = int(rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 31, 33, 48, 64, 70]))
         n = int(rng.integers(max(8 * K, 70), 2600))
         cases.append((d, K, n, int(rng.integers(1 << 30))))
