@@ -176,44 +176,57 @@ __global__ __launch_bounds__(BSU) void kmeans_update_kernel(
     }
 }
 
-/// out = [inertia, n_changed, counts(K), sums(K*d)]: inertia / changed are fixed-order sums of the per-workgroup
-/// partials; counts and coordinate sums are exact integer sums of the limb words, converted to double once.
+/// out = [inertia, n_changed, counts(K), sums(K*d)]: one wave per output element, the lanes stride over the per-workgroup
+/// partials. inertia / changed: lane-strided partial sums combined by a shuffle tree (a fixed order for a given number of
+/// partials); counts and coordinate sums: exact integer sums of the limb words (order-free), converted to double once.
 __global__ __launch_bounds__(256) void kmeans_reduce_kernel(const double* __restrict__ partials, int n_blocks, size_t pstride,
                                                              int K, int d, int accumulate, const double* __restrict__ scale,
                                                              double* __restrict__ out)
 {
     const int W = 3 * d + 1;
     const int total = 2 + (accumulate ? K * (d + 1) : 0);
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);        // wave-uniform
     if (e >= total) return;
     if (e < 2) {
-        double s = 0.0;
-        for (int b = 0; b < n_blocks; ++b) s += partials[(size_t)b * pstride + e];
-        out[e] = s;
+        double v = 0.0;
+        for (int b = lane; b < n_blocks; b += 64) v += partials[(size_t)b * pstride + e];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) out[e] = v;
         return;
     }
     const int k = (e - 2) / (d + 1), j = (e - 2) - k * (d + 1);
     const u64* words = reinterpret_cast<const u64*>(partials + 2) + (size_t)k * W;
     const size_t wstride = pstride;   // doubles and words are both 8 bytes
+    auto wave_sum = [](u64 v) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        return v;
+    };
     if (j == d) {
         u64 c = 0;
-        for (int b = 0; b < n_blocks; ++b) c += words[(size_t)b * wstride + 3 * d];
-        out[2 + k] = (double)c;
+        for (int b = lane; b < n_blocks; b += 64) c += words[(size_t)b * wstride + 3 * d];
+        c = wave_sum(c);
+        if (lane == 0) out[2 + k] = (double)c;
     } else {
         u64 w0 = 0, w1 = 0, w2 = 0;
-        for (int b = 0; b < n_blocks; ++b) {
+        for (int b = lane; b < n_blocks; b += 64) {
             const u64* p = words + (size_t)b * wstride + 3 * j;
             w0 += p[0];
             w1 += p[1];
             w2 += p[2];
         }
-        // value = (w2 * 2^64 + w1 * 2^32 + w0) / scale; propagate carries so that the top word carries the sign and the
-        // lower words are < 2^32, then combine from the small end (at most ~1.5 ulp from the exact sum, deterministic).
-        w1 += w0 >> 32;  w0 &= 0xffffffffull;
-        const long long top = (long long)w2 + (long long)(w1 >> 32);
-        w1 &= 0xffffffffull;
-        const double v = __builtin_fma((double)top, 0x1p64, __builtin_fma((double)w1, 0x1p32, (double)w0));
-        out[2 + K + (size_t)k * d + j] = v / scale[j];
+        w0 = wave_sum(w0); w1 = wave_sum(w1); w2 = wave_sum(w2);
+        if (lane == 0) {
+            // value = (w2 * 2^64 + w1 * 2^32 + w0) / scale; propagate carries so that the top word carries the sign and
+            // the lower words are < 2^32, then combine from the small end (at most ~1.5 ulp from the exact sum).
+            w1 += w0 >> 32;  w0 &= 0xffffffffull;
+            const long long top = (long long)w2 + (long long)(w1 >> 32);
+            w1 &= 0xffffffffull;
+            const double v = __builtin_fma((double)top, 0x1p64, __builtin_fma((double)w1, 0x1p32, (double)w0));
+            out[2 + K + (size_t)k * d + j] = v / scale[j];
+        }
     }
 }
 
@@ -299,7 +312,7 @@ void launch_kmeans_reduce(const KmeansArgs& a, int n_partials, hipStream_t strea
 {
     const size_t pstride = 2 + (size_t)a.K * (3 * a.d + 1);
     const int total = 2 + (a.accumulate ? a.K * (a.d + 1) : 0);
-    hipLaunchKernelGGL(kmeans_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, a.partials, n_partials, pstride,
+    hipLaunchKernelGGL(kmeans_reduce_kernel, dim3((total + 3) / 4), dim3(256), 0, stream, a.partials, n_partials, pstride,
                        a.K, a.d, a.accumulate, a.scale, a.out);
 }
 

@@ -3,6 +3,7 @@
 #   gpurun -- 'bash tools/profile_round.sh r01_v5'
 # 1. bench.py (default size, with the CPU baseline)                         -> gpurun_out/<tag>_bench.json
 # 2. rocprofv3 --kernel-trace --stats of the same command (no CPU baseline) -> gpurun_out/<tag>_bench_kernel_stats.csv
+# 4. K-means workload (bench.py --workload kmeans): bench line + kernel stats  -> gpurun_out/<tag>_kmeans_*
 # 3. separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ busy counters)       -> gpurun_out/<tag>_pmc_{fetch,write,sq}.csv
 # Copy what should be judged into profiles/ afterwards (tools/summarise_profiles.py does it and rebuilds traffic.json).
 set -e -o pipefail
@@ -22,5 +23,11 @@ for pass in fetch:FETCH_SIZE write:WRITE_SIZE "sq:SQ_WAVE_CYCLES SQ_BUSY_CYCLES 
     find "$O/${TAG}_pmc_$name" -name '*counter_collection.csv' -exec cp {} "$O/${TAG}_pmc_$name.csv" \;
     echo "[profile] pmc $name done"
 done
+# second workload: K-means config E on one GPU (bench line + kernel trace)
+python3 "$R/bench.py" --workload kmeans --steps 10 --warmup 2 > "$O/${TAG}_kmeans_bench.json" 2> "$O/${TAG}_kmeans_bench.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_kmstats" -- python3 "$R/bench.py" --workload kmeans --steps 5 --warmup 1 --no-cpu-baseline > "$O/${TAG}_kmstats.txt" 2>&1
+find "$O/${TAG}_kmstats" -name '*kernel_stats.csv' -exec cp {} "$O/${TAG}_kmeans_kernel_stats.csv" \;
+echo "[profile] kmeans done"
+rm -rf "$O/${TAG}_kmstats"
 rm -rf "$O/${TAG}_stats" "$O/${TAG}"_pmc_fetch "$O/${TAG}"_pmc_write "$O/${TAG}"_pmc_sq
 ls -la "$O" | grep "$TAG"

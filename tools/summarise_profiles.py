@@ -34,8 +34,9 @@ def condense(path):
 def main():
     tag = sys.argv[1]
     src, dst = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-    for name in ("bench.json", "bench_kernel_stats.csv"):
-        shutil.copy(os.path.join(src, f"{tag}_{name}"), os.path.join(dst, f"{tag}_{name}"))
+    for name in ("bench.json", "bench_kernel_stats.csv", "kmeans_bench.json", "kmeans_kernel_stats.csv"):
+        if os.path.exists(os.path.join(src, f"{tag}_{name}")):
+            shutil.copy(os.path.join(src, f"{tag}_{name}"), os.path.join(dst, f"{tag}_{name}"))
     summary = {}
     for p in ("fetch", "write", "sq"):
         c = condense(os.path.join(src, f"{tag}_pmc_{p}.csv"))
