@@ -29,6 +29,20 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int BSM = 512;   // threads per workgroup (8 waves; two workgroups per CU)
 
+/// second = max(second, min(best, v)); best = max(best, v) as three bare v_min_f64 / v_max_f64. Written as machine
+/// instructions because fmin / fmax on values the compiler cannot prove to be non-signalling (matrix-core results,
+/// loop-carried registers) cost an extra canonicalising v_max_f64 each -- 1.5 extra VALU operations per score in a loop
+/// whose VALU work is on the critical path. `order` (the argbest select, computed from v by a compiler-visible compare)
+/// is only an ordering dependency: the compare is the first reader of the matrix-core result, so the wait states the
+/// hardware needs between v_mfma and a VALU read have been inserted by the compiler before this point.
+__device__ __forceinline__ void track_top2(double& best, double& second, double v, int order)
+{
+    double t;
+    asm("v_min_f64 %2, %0, %3\n\tv_max_f64 %1, %1, %2\n\tv_max_f64 %0, %0, %3"
+        : "+v"(best), "+v"(second), "=&v"(t)
+        : "v"(v), "v"(order));
+}
+
 /// One sample's coordinates for the exact phase: registers up to d = 64, re-read from memory (L1/L2) above.
 template <int D> struct SampleRow {
     static constexpr bool kInRegs = D <= kMidDim;
@@ -195,9 +209,8 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const double v = acc[sb][r];
-                    second[sb] = fmax(second[sb], fmin(best[sb], v));
                     idx[sb] = (v > best[sb]) ? k0 + 16 * cb + g + 4 * r : idx[sb];
-                    best[sb] = fmax(best[sb], v);
+                    track_top2(best[sb], second[sb], v, idx[sb]);
                 }
             }
         }
