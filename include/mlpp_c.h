@@ -87,6 +87,11 @@ int mlpp_add_a_xxT(const double* x, uint32_t n, double* dest, uint32_t drows, ui
 int mlpp_calculate_XXt_beta(const double* X, uint64_t n, uint32_t q, const double* y, uint64_t ylen, const double* lambda,
                             uint32_t lambda_len, double* XXt /* q x q */, double* beta /* q */);
 
+/* ---- device context of the facade (include/ML/Device.hpp): the process-wide mlhip_ctx the model classes run on. A
+ * row-sharded job installs its all-reduce hook on it (mlhip_ctx_set_allreduce) before calling fit() on every rank. ---- */
+int mlpp_device_context(struct mlhip_ctx** out);          /* ml::device::context(): created on first use, not owned by the caller */
+int mlpp_device_set_context(struct mlhip_ctx* ctx);       /* ml::device::set_context(); NULL restores the default */
+
 #ifdef __cplusplus
 }
 #endif

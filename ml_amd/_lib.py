@@ -92,13 +92,25 @@ class Context:
         self._h = C.c_void_p()
         check(lib.mlhip_ctx_create(int(device_id), C.byref(self._h)))
         self._hook = None
+        self._owned = True
         self._blocks = weakref.WeakSet()      # live Data objects: they hold a pointer to this context
+
+    @classmethod
+    def borrow(cls, handle):
+        """Wraps a context owned by someone else (the C++ facade's process-wide one): close() leaves it alive."""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p(handle) if not isinstance(handle, C.c_void_p) else handle
+        self._hook = None
+        self._owned = False
+        self._blocks = weakref.WeakSet()
+        return self
 
     def close(self):
         if getattr(self, "_h", None):
             for block in list(self._blocks):  # a sample block must not outlive its context
                 block.close()
-            lib.mlhip_ctx_destroy(self._h)
+            if self._owned:
+                lib.mlhip_ctx_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -9,6 +9,7 @@
 #include <string>
 
 #include "ML/Clustering.hpp"
+#include "ML/Device.hpp"
 #include "ML/EM.hpp"
 #include "ML/KMeans.hpp"
 #include "ML/LinearAlgebra.hpp"
@@ -200,6 +201,16 @@ int mlpp_calculate_XXt_beta(const double* X, uint64_t n, uint32_t q, const doubl
                                                                 MatrixRef(XXt, q, q, q), ConstVectorRef(lambda, lambda_len));
         std::copy_n(b.data(), b.size(), beta);
     });
+}
+
+int mlpp_device_context(mlhip_ctx** out)
+{
+    return guarded([&] { need(out); *out = device::context(); });
+}
+
+int mlpp_device_set_context(mlhip_ctx* ctx)
+{
+    return guarded([&] { device::set_context(ctx); });
 }
 
 }  // extern "C"

@@ -182,3 +182,97 @@ def test_two_ranks_on_one_gpu_match_single_rank():
     assert np.max(np.abs(C1 - a[13])) <= 1e-14 * np.max(np.abs(C1))
     data.close()
     ctx.close()
+
+
+# ---- the same through the drop-in classes: every rank calls EM.fit / KMeans.fit on its shard ------------------------
+
+def _facade_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        import torch.distributed as dist
+        from ml_amd import cppyml, synth
+        from ml_amd import dist as mldist
+        from ml_amd.cppyml import clustering as cl
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        mldist.install_allreduce(cppyml.device_context(), world, rank, on_device=False)
+        d, K, n = 6, 4, 5003
+        mix = synth.Mixture(d, K, seed=8)
+        X, _ = mix.sample(n)
+        lo, hi = mldist.shard_bounds(n, world, rank)
+        shard = np.ascontiguousarray(X[lo:hi])
+        out = {}
+        for name, init in (("fixed", cl.FixedCentroids(mix.initial_means())), ("forgy", cl.Forgy())):
+            em = cl.EM(K)
+            em.set_means_initialiser(init)
+            em.set_absolute_tolerance(1e-10)
+            em.set_relative_tolerance(1e-10)
+            em.set_maximum_steps(200)
+            em.set_seed(5)
+            conv = em.fit(shard)
+            out[name] = (conv, em.steps_done, em.log_likelihood, em.means.copy(), em.mixing_probabilities.copy(),
+                         np.stack([em.covariance(k) for k in range(K)]), np.asarray(em.labels))
+        km = cl.KMeans(K)
+        km.set_centroids_initialiser(cl.FixedCentroids(mix.initial_means()))
+        conv = km.fit(shard)
+        out["kmeans"] = (conv, km.steps_done, km.inertia, km.centroids.copy(), np.asarray(km.labels_array))
+        q.put((rank, lo, hi, out))
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), str(e)))
+
+
+@pytest.mark.gpu
+def test_facade_fit_row_sharded_over_two_ranks():
+    """cppyml.clustering.EM / KMeans fitted by 2 processes on row shards (hook installed on the facade's context) ==
+    the single-process fit on the whole data; rank 0's initial means are what every rank starts from."""
+    import torch.multiprocessing as mp
+    from ml_amd import synth
+    from ml_amd.cppyml import clustering as cl
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = _free_port()
+    procs = [mpctx.Process(target=_facade_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+            p.join()
+    for r in results:
+        assert r[1] != "error", r[2]
+    results.sort(key=lambda r: r[0])
+    a, b = results[0][3], results[1][3]
+    for name in ("fixed", "forgy"):
+        assert a[name][0] and b[name][0] and a[name][1] == b[name][1]
+        for i in (2, 3, 4, 5):                                           # replicated: bit-identical on both ranks
+            assert np.array_equal(np.asarray(a[name][i]), np.asarray(b[name][i])), (name, i)
+    assert a["kmeans"][0] == b["kmeans"][0] and a["kmeans"][1] == b["kmeans"][1] and a["kmeans"][2] == b["kmeans"][2]
+    assert np.array_equal(a["kmeans"][3], b["kmeans"][3])
+
+    d, K, n = 6, 4, 5003
+    mix = synth.Mixture(d, K, seed=8)
+    X, _ = mix.sample(n)
+    em = cl.EM(K)
+    em.set_means_initialiser(cl.FixedCentroids(mix.initial_means()))
+    em.set_absolute_tolerance(1e-10)
+    em.set_relative_tolerance(1e-10)
+    em.set_maximum_steps(200)
+    assert em.fit(X)
+    conv, steps, ll, means, pis, covs, _ = a["fixed"]
+    assert steps == em.steps_done
+    assert abs(ll - em.log_likelihood) <= 1e-12 * abs(ll)
+    assert np.max(np.abs(means - em.means)) <= 1e-10 * np.max(np.abs(means))
+    assert np.max(np.abs(pis - em.mixing_probabilities)) <= 1e-11
+    for k in range(K):
+        assert np.max(np.abs(covs[k] - em.covariance(k))) <= 1e-9 * np.max(np.abs(covs[k]))
+    assert np.array_equal(np.concatenate([a["fixed"][6], b["fixed"][6]]), np.asarray(em.labels))
+    km = cl.KMeans(K)
+    km.set_centroids_initialiser(cl.FixedCentroids(mix.initial_means()))
+    assert km.fit(X) == a["kmeans"][0]
+    assert km.steps_done == a["kmeans"][1]
+    assert abs(km.inertia - a["kmeans"][2]) <= 1e-13 * km.inertia
+    assert np.max(np.abs(km.centroids - a["kmeans"][3])) <= 1e-13 * np.max(np.abs(km.centroids))
+    assert np.array_equal(np.concatenate([a["kmeans"][4], b["kmeans"][4]]), np.asarray(km.labels_array))
