@@ -1,6 +1,7 @@
 #include "DeviceInit.hpp"
 
 #include <algorithm>
+#include <iterator>
 #include <limits>
 #include <random>
 #include <typeinfo>
@@ -13,12 +14,188 @@ namespace ml {
 namespace Clustering {
 namespace detail {
 
+namespace {
+
+/// Index range [0, n) as a forward range without storage, for std::sample (selection sampling walks it once).
+struct IndexIterator {
+    using iterator_category = std::forward_iterator_tag;
+    using value_type = Index;
+    using difference_type = std::ptrdiff_t;
+    using pointer = const Index*;
+    using reference = Index;
+    Index i = 0;
+    Index operator*() const { return i; }
+    IndexIterator& operator++() { ++i; return *this; }
+    IndexIterator operator++(int) { IndexIterator t = *this; ++i; return t; }
+    bool operator==(const IndexIterator& o) const { return i == o.i; }
+    bool operator!=(const IndexIterator& o) const { return i != o.i; }
+};
+
+/// Row-sharded job: where this rank's rows sit in the whole (rank-ordered) sample.
+struct Shard {
+    int world = 1, rank = 0;
+    Index lo = 0, hi = 0, n_global = 0;
+};
+
+Shard locate_shard(mlhip_ctx* ctx, Index n_local)
+{
+    Shard s;
+    device::check(mlhip_ctx_world(ctx, &s.world, &s.rank));
+    std::vector<double> counts(static_cast<std::size_t>(s.world), 0.0);
+    counts[static_cast<std::size_t>(s.rank)] = static_cast<double>(n_local);
+    device::check(mlhip_ctx_allreduce(ctx, counts.data(), counts.size()));
+    for (int r = 0; r < s.world; ++r) {
+        if (r == s.rank) s.lo = s.n_global;
+        s.n_global += static_cast<Index>(counts[static_cast<std::size_t>(r)]);
+    }
+    s.hi = s.lo + n_local;
+    return s;
+}
+
+/// Every rank ends with rank `owner`'s values (sum with zeros elsewhere; exact up to the sign of a zero).
+void broadcast_from(mlhip_ctx* ctx, int owner, int rank, double* v, std::size_t count)
+{
+    if (rank != owner) std::fill_n(v, count, 0.0);
+    device::check(mlhip_ctx_allreduce(ctx, v, count));
+}
+
+/// Sums a d x K block across ranks (through a contiguous copy: a MatrixRef may be strided).
+void allreduce_matrix(mlhip_ctx* ctx, MatrixRef m)
+{
+    const Index d = m.rows(), K = m.cols();
+    std::vector<double> flat(static_cast<std::size_t>(d) * static_cast<std::size_t>(K));
+    for (Index k = 0; k < K; ++k) std::copy_n(m.col(k), d, flat.data() + static_cast<std::size_t>(k) * d);
+    device::check(mlhip_ctx_allreduce(ctx, flat.data(), flat.size()));
+    for (Index k = 0; k < K; ++k) std::copy_n(flat.data() + static_cast<std::size_t>(k) * d, d, m.col(k));
+}
+
+/// Forgy on the whole sample (ML/Clustering.cpp:16-25): every rank performs the same selection sampling over the global
+/// index range with its own (identically seeded) engine, so all agree on the K rows; the owners contribute them.
+void forgy_sharded(const Shard& sh, ConstMatrixRef data, std::default_random_engine& prng, unsigned int K, MatrixRef centroids,
+                   mlhip_ctx* ctx)
+{
+    std::vector<Index> chosen;
+    std::sample(IndexIterator{0}, IndexIterator{sh.n_global}, std::back_inserter(chosen), K, prng);
+    centroids.setZero();
+    for (unsigned int k = 0; k < K && k < chosen.size(); ++k)
+        if (chosen[k] >= sh.lo && chosen[k] < sh.hi) std::copy_n(data.col(chosen[k] - sh.lo), data.rows(), centroids.col(k));
+    allreduce_matrix(ctx, centroids);
+}
+
+/// RandomPartition on the whole sample (ML/Clustering.cpp:27-37): the per-row cluster draws are a function of the engine
+/// alone, so every rank replays all of them and keeps its own rows'; the running means are order dependent, so the
+/// ranks update the shared state one after the other, in row order.
+void random_partition_sharded(const Shard& sh, ConstMatrixRef data, std::default_random_engine& prng, unsigned int K,
+                              MatrixRef centroids, mlhip_ctx* ctx)
+{
+    const Index d = data.rows(), n_local = data.cols();
+    std::uniform_int_distribution<unsigned int> pick(0, K - 1);
+    std::vector<unsigned int> mine(static_cast<std::size_t>(n_local));
+    for (Index i = 0; i < sh.n_global; ++i) {
+        const unsigned int k = pick(prng);
+        if (i >= sh.lo && i < sh.hi) mine[static_cast<std::size_t>(i - sh.lo)] = k;
+    }
+    std::vector<double> state(static_cast<std::size_t>(d) * K + K, 0.0);   // [centroids d x K | sizes K]
+    for (int r = 0; r < sh.world; ++r) {
+        if (r == sh.rank) {
+            double* sizes = state.data() + static_cast<std::size_t>(d) * K;
+            for (Index i = 0; i < n_local; ++i) {
+                const unsigned int k = mine[static_cast<std::size_t>(i)];
+                const double count = (sizes[k] += 1.0);
+                double* c = state.data() + static_cast<std::size_t>(d) * k;
+                const double* x = data.col(i);
+                for (Index j = 0; j < d; ++j) c[j] += (x[j] - c[j]) / count;
+            }
+        }
+        broadcast_from(ctx, r, sh.rank, state.data(), state.size());
+    }
+    for (unsigned int k = 0; k < K; ++k) std::copy_n(state.data() + static_cast<std::size_t>(d) * k, d, centroids.col(k));
+}
+
+/// K-means++ on the whole sample (ML/Clustering.cpp:39-59) with the draw of std::discrete_distribution reproduced over the
+/// rank-ordered rows: the weight sum and the cumulative probabilities are sequential floating-point sums, so the ranks
+/// take turns in row order, each continuing from its predecessor's carry (K rounds x world short hops); the distance
+/// passes run on every rank's device block at once.
+void kpp_sharded(const Shard& sh, ConstMatrixRef data, std::default_random_engine& prng, unsigned int K, MatrixRef centroids,
+                 mlhip_ctx* ctx, mlhip_data* device_data)
+{
+    const Index d = data.rows();
+    const std::size_t count = static_cast<std::size_t>(data.cols());
+    std::vector<double> weights(count, 1.0), latest;
+    std::vector<double> pick(static_cast<std::size_t>(d));
+    for (unsigned int chosen = 0; chosen < K; ++chosen) {
+        if (chosen > 0) {
+            std::vector<double>& target = chosen == 1 ? weights : latest;
+            target.resize(count);
+            device::check(mlhip_min_squared_distances(ctx, device_data, 1, centroids.col(chosen - 1), target.data()));
+            if (chosen > 1)
+                for (std::size_t i = 0; i < count; ++i) weights[i] = std::min(weights[i], latest[i]);
+        }
+        // sum = ((0 + w_0) + w_1) + ... over all rows in order
+        double sum = 0.0;
+        for (int r = 0; r < sh.world; ++r) {
+            if (r == sh.rank)
+                for (std::size_t i = 0; i < count; ++i) sum += weights[i];
+            broadcast_from(ctx, r, sh.rank, &sum, 1);
+        }
+        std::fill(pick.begin(), pick.end(), 0.0);
+        if (sh.n_global >= 2) {
+            const double p = std::generate_canonical<double, std::numeric_limits<double>::digits>(prng);
+            double carry[2] = {0.0, 0.0};              // [cumulative probability so far, found flag]
+            for (int r = 0; r < sh.world; ++r) {
+                if (r == sh.rank && carry[1] == 0.0) {
+                    double cumulative = carry[0];
+                    for (std::size_t i = 0; i < count; ++i) {
+                        if (sh.lo + static_cast<Index>(i) == sh.n_global - 1) {   // the last probability is forced to 1
+                            carry[1] = 1.0;
+                            std::copy_n(data.col(static_cast<Index>(i)), d, pick.data());
+                            break;
+                        }
+                        cumulative += weights[i] / sum;
+                        if (cumulative >= p) {
+                            carry[1] = 1.0;
+                            std::copy_n(data.col(static_cast<Index>(i)), d, pick.data());
+                            break;
+                        }
+                    }
+                    carry[0] = cumulative;
+                }
+                broadcast_from(ctx, r, sh.rank, carry, 2);
+            }
+        } else if (sh.lo == 0 && count > 0) {
+            std::copy_n(data.col(0), d, pick.data());   // fewer than two weights: index 0, no draw (bits/random.tcc)
+        }
+        device::check(mlhip_ctx_allreduce(ctx, pick.data(), pick.size()));   // only the owner's copy is non-zero
+        std::copy_n(pick.data(), d, centroids.col(chosen));
+    }
+}
+
+}  // namespace
+
 void init_centroids(const CentroidsInitialiser& initialiser, ConstMatrixRef data, std::default_random_engine& prng,
                     const unsigned int number_components, MatrixRef centroids, mlhip_ctx* ctx, mlhip_data* device_data)
 {
-    int world = 1;
-    if (ctx) device::check(mlhip_ctx_world(ctx, &world, nullptr));
-    if (!ctx || !device_data || world != 1 || typeid(initialiser) != typeid(KPP)) {
+    int world = 1, rank = 0;
+    if (ctx) device::check(mlhip_ctx_world(ctx, &world, &rank));
+    if (world > 1) {
+        // Row-sharded job: the library initialisers reproduce what a single process would draw on the whole sample
+        // (same seed => same centroids, whatever the number of ranks); anything else runs on rank 0's shard and is
+        // handed to the others.
+        const Shard sh = locate_shard(ctx, data.cols());
+        if (typeid(initialiser) == typeid(Forgy)) {
+            forgy_sharded(sh, data, prng, number_components, centroids, ctx);
+        } else if (typeid(initialiser) == typeid(RandomPartition)) {
+            random_partition_sharded(sh, data, prng, number_components, centroids, ctx);
+        } else if (typeid(initialiser) == typeid(KPP) && device_data) {
+            kpp_sharded(sh, data, prng, number_components, centroids, ctx, device_data);
+        } else {
+            initialiser.init(data, prng, number_components, centroids);
+            if (rank != 0) centroids.setZero();
+            allreduce_matrix(ctx, centroids);
+        }
+        return;
+    }
+    if (!ctx || !device_data || typeid(initialiser) != typeid(KPP)) {
         initialiser.init(data, prng, number_components, centroids);
         return;
     }

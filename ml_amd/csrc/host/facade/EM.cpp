@@ -188,10 +188,6 @@ bool EM::fit(ConstMatrixRef data)
             // M-step from labels -- no N x K matrix is materialised.
             MatrixXd centroids(number_dimensions, K);
             Clustering::detail::init_centroids(*closest->centroids_initialiser(), data, prng_, K, centroids, ctx, dev.h);
-            if (world > 1) {
-                if (rank != 0) centroids.setZero();
-                check(mlhip_ctx_allreduce(ctx, centroids.data(), static_cast<std::size_t>(centroids.size())));
-            }
             double inertia = 0;
             uint64_t changed = 0;
             check(mlhip_kmeans_assign(ctx, dev.h, K, centroids.data(), &inertia, &changed));
@@ -208,11 +204,7 @@ bool EM::fit(ConstMatrixRef data)
         }
     } else {
         // Sensible guesses: initialiser's means, every covariance = sample covariance (ML/EM.cpp:127-135).
-        Clustering::detail::init_centroids(*means_initialiser_, data, prng_, K, means_, ctx, dev.h);
-        if (world > 1) {
-            if (rank != 0) means_.setZero();
-            check(mlhip_ctx_allreduce(ctx, means_.data(), static_cast<std::size_t>(means_.size())));
-        }
+        Clustering::detail::init_centroids(*means_initialiser_, data, prng_, K, means_, ctx, dev.h);   // identical on all ranks
         std::vector<double> sample_covariance(dd);
         check(mlhip_sample_covariance(ctx, dev.h, nullptr, sample_covariance.data()));
         for (unsigned int k = 0; k < K; ++k) std::copy_n(sample_covariance.data(), dd, cov_flat.data() + dd * k);

@@ -180,11 +180,7 @@ bool KMeans::fit_once(ConstMatrixRef data, mlhip_data* device_data)
     mlhip_ctx* ctx = device::context();
     int world = 1, rank = 0;
     check(mlhip_ctx_world(ctx, &world, &rank));
-    detail::init_centroids(*centroids_initialiser_, data, prng_, K, centroids_, ctx, device_data);
-    if (world > 1) {
-        if (rank != 0) centroids_.setZero();
-        check(mlhip_ctx_allreduce(ctx, centroids_.data(), static_cast<std::size_t>(centroids_.size())));
-    }
+    detail::init_centroids(*centroids_initialiser_, data, prng_, K, centroids_, ctx, device_data);   // identical on all ranks
 
     MatrixXd updated(number_dimensions, K);
     for (unsigned int step = 0; step < maximum_steps_; ++step) {

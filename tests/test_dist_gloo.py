@@ -201,7 +201,8 @@ def _facade_worker(rank, world, port, q):
         lo, hi = mldist.shard_bounds(n, world, rank)
         shard = np.ascontiguousarray(X[lo:hi])
         out = {}
-        for name, init in (("fixed", cl.FixedCentroids(mix.initial_means())), ("forgy", cl.Forgy())):
+        for name, init in (("fixed", cl.FixedCentroids(mix.initial_means())), ("forgy", cl.Forgy()), ("kpp", cl.KPP()),
+                           ("random_partition", cl.RandomPartition())):
             em = cl.EM(K)
             em.set_means_initialiser(init)
             em.set_absolute_tolerance(1e-10)
@@ -215,6 +216,12 @@ def _facade_worker(rank, world, port, q):
         km.set_centroids_initialiser(cl.FixedCentroids(mix.initial_means()))
         conv = km.fit(shard)
         out["kmeans"] = (conv, km.steps_done, km.inertia, km.centroids.copy(), np.asarray(km.labels_array))
+        km = cl.KMeans(K)
+        km.set_centroids_initialiser(cl.KPP())
+        km.set_seed(11)
+        km.set_number_initialisations(3)
+        conv = km.fit(shard)
+        out["kmeans_kpp"] = (conv, km.steps_done, km.inertia, km.centroids.copy(), np.asarray(km.labels_array))
         q.put((rank, lo, hi, out))
         dist.destroy_process_group()
     except Exception as e:  # pragma: no cover
@@ -245,8 +252,8 @@ def test_facade_fit_row_sharded_over_two_ranks():
         assert r[1] != "error", r[2]
     results.sort(key=lambda r: r[0])
     a, b = results[0][3], results[1][3]
-    for name in ("fixed", "forgy"):
-        assert a[name][0] and b[name][0] and a[name][1] == b[name][1]
+    for name in ("fixed", "forgy", "kpp", "random_partition"):
+        assert a[name][0] == b[name][0] and a[name][1] == b[name][1]
         for i in (2, 3, 4, 5):                                           # replicated: bit-identical on both ranks
             assert np.array_equal(np.asarray(a[name][i]), np.asarray(b[name][i])), (name, i)
     assert a["kmeans"][0] == b["kmeans"][0] and a["kmeans"][1] == b["kmeans"][1] and a["kmeans"][2] == b["kmeans"][2]
@@ -255,20 +262,34 @@ def test_facade_fit_row_sharded_over_two_ranks():
     d, K, n = 6, 4, 5003
     mix = synth.Mixture(d, K, seed=8)
     X, _ = mix.sample(n)
-    em = cl.EM(K)
-    em.set_means_initialiser(cl.FixedCentroids(mix.initial_means()))
-    em.set_absolute_tolerance(1e-10)
-    em.set_relative_tolerance(1e-10)
-    em.set_maximum_steps(200)
-    assert em.fit(X)
-    conv, steps, ll, means, pis, covs, _ = a["fixed"]
-    assert steps == em.steps_done
-    assert abs(ll - em.log_likelihood) <= 1e-12 * abs(ll)
-    assert np.max(np.abs(means - em.means)) <= 1e-10 * np.max(np.abs(means))
-    assert np.max(np.abs(pis - em.mixing_probabilities)) <= 1e-11
-    for k in range(K):
-        assert np.max(np.abs(covs[k] - em.covariance(k))) <= 1e-9 * np.max(np.abs(covs[k]))
-    assert np.array_equal(np.concatenate([a["fixed"][6], b["fixed"][6]]), np.asarray(em.labels))
+    # the library initialisers draw, on the shards, exactly what one process draws on the whole sample (same seed)
+    for name, init in (("fixed", cl.FixedCentroids(mix.initial_means())), ("forgy", cl.Forgy()), ("kpp", cl.KPP()),
+                       ("random_partition", cl.RandomPartition())):
+        em = cl.EM(K)
+        em.set_means_initialiser(init)
+        em.set_absolute_tolerance(1e-10)
+        em.set_relative_tolerance(1e-10)
+        em.set_maximum_steps(200)
+        em.set_seed(5)
+        conv1 = em.fit(X)
+        conv, steps, ll, means, pis, covs, _ = a[name]
+        assert conv == conv1 and steps == em.steps_done, name
+        assert abs(ll - em.log_likelihood) <= 1e-12 * abs(ll), name
+        assert np.max(np.abs(means - em.means)) <= 1e-10 * np.max(np.abs(means)), name
+        assert np.max(np.abs(pis - em.mixing_probabilities)) <= 1e-11, name
+        for k in range(K):
+            assert np.max(np.abs(covs[k] - em.covariance(k))) <= 1e-9 * np.max(np.abs(covs[k])), name
+        if conv:
+            assert np.array_equal(np.concatenate([a[name][6], b[name][6]]), np.asarray(em.labels)), name
+    km = cl.KMeans(K)
+    km.set_centroids_initialiser(cl.KPP())
+    km.set_seed(11)
+    km.set_number_initialisations(3)
+    assert km.fit(X) == a["kmeans_kpp"][0]
+    assert km.steps_done == a["kmeans_kpp"][1]
+    assert abs(km.inertia - a["kmeans_kpp"][2]) <= 1e-13 * km.inertia
+    assert np.max(np.abs(km.centroids - a["kmeans_kpp"][3])) <= 1e-13 * np.max(np.abs(km.centroids))
+    assert np.array_equal(np.concatenate([a["kmeans_kpp"][4], b["kmeans_kpp"][4]]), np.asarray(km.labels_array))
     km = cl.KMeans(K)
     km.set_centroids_initialiser(cl.FixedCentroids(mix.initial_means()))
     assert km.fit(X) == a["kmeans"][0]
