@@ -18,6 +18,9 @@ def _cases():
         K = int(rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 31, 33, 48, 64, 70]))
         n = int(rng.integers(max(8 * K, 70), 2600))
         cases.append((d, K, n, int(rng.integers(1 << 30))))
+    # many components; tiny samples (fewer rows than a tile, a wave, or the padded dimension)
+    for d, K, n in ((5, 200, 3000), (16, 130, 2100), (32, 257, 2600), (3, 2, 5), (16, 3, 17), (40, 2, 9), (8, 1, 2)):
+        cases.append((d, K, n, int(rng.integers(1 << 30))))
     return cases
 
 
