@@ -235,6 +235,16 @@ Plan make_plan(int d, int K, int num_cus)
         p.KP = p.n_rbg * p.RBW * 16;
         p.FP = p.n_cbg * 8 * p.CBW * 16;
         p.grid_x = num_cus / (p.n_rbg * p.n_cbg);
+    } else if (p.CB <= 4 && !force_narrow) {
+        // d <= 9: independent waves, each with all column blocks and up to 4 row blocks (em_mstats_small.hip)
+        p.small = true;
+        p.RBW = p.RB >= 3 ? 4 : (p.RB >= 2 ? 2 : 1);
+        p.CBW = p.CB;
+        p.n_rbg = (p.RB + p.RBW - 1) / p.RBW;
+        p.n_cbg = 1;
+        p.KP = p.n_rbg * p.RBW * 16;
+        p.FP = p.CB * 16;
+        p.grid_x = 2 * num_cus / p.n_rbg;
     } else {
         // Few column blocks (small d): 256-thread workgroups, 4 waves split the column blocks, two workgroups per CU.
         const int cb_per_wave = (p.CB + 3) / 4;
@@ -266,6 +276,7 @@ int launch_em_mstats(const MstatsArgs& a, int num_cus, hipStream_t stream)
     if ((uint32_t)grid_x > n_tiles) grid_x = (int)(n_tiles ? n_tiles : 1);
     if ((size_t)grid_x * p.KP * p.FP > a.partials_capacity) return -2;
     if (p.wide) return launch_wide(a, p, grid_x, stream);
+    if (p.small) return launch_small(a, p, grid_x, stream);
 
 #define MLHIP_CASE(R, C) \
     if (p.RBW == R && p.CBW == C) { launch_t<R, C>(a, p, grid_x, stream); } else

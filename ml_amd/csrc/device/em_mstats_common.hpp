@@ -28,6 +28,7 @@ __device__ __forceinline__ void feature_pair(int col, int F, int da, int& a, int
 /// Decomposition of the statistics GEMM over workgroups / waves.
 struct Plan {
     bool wide;          // em_mstats_wide.hip (512 threads, waves split the column blocks) or em_mstats.hip (256 threads)
+    bool small;         // em_mstats_small.hip (d <= 9: every wave on its own tile stream, all column blocks)
     int RBW, CBW;       // per-wave register blocking (16-row blocks x 16-column blocks)
     int RB, CB;         // total 16-blocks
     int n_rbg, n_cbg;   // grid.y decomposition
@@ -37,6 +38,7 @@ struct Plan {
 Plan make_plan(int d, int K, int num_cus);
 
 int launch_wide(const MstatsArgs& a, const Plan& p, int grid_x, hipStream_t stream);
+int launch_small(const MstatsArgs& a, const Plan& p, int grid_x, hipStream_t stream);
 
 }  // namespace mstats
 }  // namespace mlhip
