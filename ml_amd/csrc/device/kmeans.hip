@@ -138,41 +138,51 @@ __global__ __launch_bounds__(BS) void kmeans_assign_kernel(
 }
 
 /// Update sums as a second sweep, for shapes whose K*(3d+1) accumulator words do not fit LDS next to the assignment
-/// kernel's own state: the clusters are cut into chunks of KC whose accumulators do fit; for every chunk the workgroup
-/// re-reads its samples' labels (and the coordinates of the samples that fall into the chunk) and adds the limbs with LDS
-/// integer atomics, then flushes the chunk to its partial block. Same exact sums as the fused path, a few extra passes
-/// over labels / X instead of global-memory atomics (which serialise on popular clusters: 28 ms vs 2.4 ms for the
-/// assignment itself at N=12.5M, d=16, K=256).
+/// kernel's own state. The accumulators are cut into chunks that do fit -- by DIMENSION first: a chunk holds the limbs of
+/// DC dimensions for all clusters, so every pass reads its DC rows of X densely (all lanes active, coalesced; X is read
+/// exactly once over all passes) plus the labels; only when even one dimension of all K clusters is too much (K > ~3000)
+/// are the clusters chunked as well (KC < K: lanes outside the chunk idle). Same exact limb sums as the fused path
+/// (ds_add_u64), flushed per chunk into the workgroup's partial block -- instead of global-memory atomics, which serialise
+/// on popular clusters (N=12.5M, d=16, K=256: 25 ms; this sweep: 0.7 ms on top of the 2.2 ms assignment).
 constexpr int BSU = 1024;
 __global__ __launch_bounds__(BSU) void kmeans_update_kernel(
     const double* __restrict__ xt, size_t ldx, uint32_t n, int d, const uint32_t* __restrict__ labels,
-    const double* __restrict__ scale, int K, int KC, double* __restrict__ partials, size_t pstride)
+    const double* __restrict__ scale, int K, int KC, int DC, double* __restrict__ partials, size_t pstride)
 {
-    extern __shared__ u64 acc_lds[];      // [KC][3d+1]
+    extern __shared__ u64 acc_lds[];      // [KC][3*DC + 1]
     const int tid = threadIdx.x;
-    const int W = 3 * d + 1;
+    const int W = 3 * d + 1;              // words per cluster in the partial block
+    const int WC = 3 * DC + 1;            // words per cluster in LDS (last one: the count, used by the first dim chunk)
     u64* my_words = reinterpret_cast<u64*>(partials + (size_t)blockIdx.x * pstride + 2);
     for (int k0 = 0; k0 < K; k0 += KC) {
         const int kc = min(KC, K - k0);
-        for (int e = tid; e < kc * W; e += BSU) acc_lds[e] = 0;
-        __syncthreads();
-        for (uint32_t i = blockIdx.x * (uint32_t)BSU + tid; i < n; i += gridDim.x * (uint32_t)BSU) {
-            const uint32_t rel = labels[i] - (uint32_t)k0;
-            if (rel < (uint32_t)kc) {
-                u64* row = acc_lds + (size_t)rel * W;
-                for (int j = 0; j < d; ++j) {
-                    u64 w0, w1, w2;
-                    split_limbs(xt[(size_t)j * ldx + i] * scale[j], w0, w1, w2);
-                    atomicAdd(row + 3 * j, w0);
-                    atomicAdd(row + 3 * j + 1, w1);
-                    atomicAdd(row + 3 * j + 2, w2);
+        for (int j0 = 0; j0 < d; j0 += DC) {
+            const int dc = min(DC, d - j0);
+            for (int e = tid; e < kc * WC; e += BSU) acc_lds[e] = 0;
+            __syncthreads();
+            for (uint32_t i = blockIdx.x * (uint32_t)BSU + tid; i < n; i += gridDim.x * (uint32_t)BSU) {
+                const uint32_t rel = labels[i] - (uint32_t)k0;
+                if (rel < (uint32_t)kc) {
+                    u64* row = acc_lds + (size_t)rel * WC;
+                    for (int j = 0; j < dc; ++j) {
+                        u64 w0, w1, w2;
+                        split_limbs(xt[(size_t)(j0 + j) * ldx + i] * scale[j0 + j], w0, w1, w2);
+                        atomicAdd(row + 3 * j, w0);
+                        atomicAdd(row + 3 * j + 1, w1);
+                        atomicAdd(row + 3 * j + 2, w2);
+                    }
+                    if (j0 == 0) atomicAdd(row + 3 * DC, (u64)1);
                 }
-                atomicAdd(row + 3 * d, (u64)1);
             }
+            __syncthreads();
+            for (int e = tid; e < kc * 3 * dc; e += BSU) {
+                const int k = e / (3 * dc), w = e - k * 3 * dc;
+                my_words[(size_t)(k0 + k) * W + 3 * j0 + w] = acc_lds[(size_t)k * WC + w];
+            }
+            if (j0 == 0)
+                for (int k = tid; k < kc; k += BSU) my_words[(size_t)(k0 + k) * W + 3 * d] = acc_lds[(size_t)k * WC + 3 * DC];
+            __syncthreads();
         }
-        __syncthreads();
-        for (int e = tid; e < kc * W; e += BSU) my_words[(size_t)k0 * W + e] = acc_lds[e];
-        __syncthreads();
     }
 }
 
@@ -255,13 +265,18 @@ size_t kmeans_scratch_doubles(int d, int K, int num_cus)
 /// Separate update sweep (see kmeans_update_kernel) over the same `grid` partial blocks the assignment kernel used.
 void launch_kmeans_update(const KmeansArgs& a, int grid, size_t pstride, hipStream_t stream)
 {
-    const int W = 3 * a.d + 1;
-    const size_t budget = 72 * 1024;                          // two 1024-thread workgroups per CU
-    int KC = (int)(budget / (sizeof(u64) * W));
-    if (KC > a.K) KC = a.K;
-    if (KC < 1) KC = 1;
-    hipLaunchKernelGGL(kmeans_update_kernel, dim3(grid), dim3(BSU), sizeof(u64) * (size_t)KC * W, stream, a.xt, a.ldx, a.n, a.d,
-                       a.labels, a.scale, a.K, KC, a.partials, pstride);
+    const size_t budget = 72 * 1024 / sizeof(u64);           // words; two 1024-thread workgroups per CU
+    // as many whole dimensions of all K clusters as fit; if not even one does, chunk the clusters too
+    const size_t per_cluster = budget / (size_t)a.K;          // words available per cluster when all K are resident
+    int KC = a.K, DC = per_cluster >= 4 ? (int)((per_cluster - 1) / 3) : 0;
+    if (DC > a.d) DC = a.d;
+    if (DC < 1) {
+        DC = 1;
+        KC = (int)(budget / 4);
+        if (KC < 1) KC = 1;
+    }
+    hipLaunchKernelGGL(kmeans_update_kernel, dim3(grid), dim3(BSU), sizeof(u64) * (size_t)KC * (3 * DC + 1), stream, a.xt, a.ldx,
+                       a.n, a.d, a.labels, a.scale, a.K, KC, DC, a.partials, pstride);
 }
 
 bool kmeans_mfma_supported(int D, int K);
