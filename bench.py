@@ -53,13 +53,34 @@ def cpu_baseline(mix, d, K, n_cpu, iters):
     return sec_per_iter, n_cpu
 
 
+def usable_cores():
+    """Host cores this process can really use: the affinity mask, capped by the cgroup CPU quota of the container."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:      # cgroup v1
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0:
+                cores = min(cores, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return cores
+
+
 def cpu_baseline_all_cores(mix, d, K, n_per_thread, iters):
     """Row-parallel variant of the same restatement on every host core this process may use: one oracle instance per
     thread on its own sample shard (the E and M steps are sums over samples, so this is what an OpenMP `parallel for` over
     the reference's sample loops would do; the K x d x d combine is negligible). The reference itself is single-threaded."""
     import threading
     from oracle import oracle_ctypes as orc
-    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = usable_cores()
     X, _ = mix.sample(n_per_thread * threads, stream=998)
     cov0 = np.stack([np.cov(X[:n_per_thread].T)] * K)
     models = []
