@@ -46,6 +46,23 @@ struct MstatsArgs {
     const double* ll_partials; int n_ll_partials;            // summed into stats[K*F] (may be null/0)
     double* stats;                                           // out: device, K*F + 1 doubles
 };
+/// Fused E-step + statistics for small shapes (em_fused_small.hip): params are the estep_param_stride(D) records.
+struct FusedArgs {
+    const double* xt; size_t ldx; uint32_t n; int d;
+    const double* shift; const double* params; int K;
+    double* lse;                                             // out: per-sample log-sum-exp
+    double* partials; size_t partials_capacity;              // scratch: [grid][KP][FP]
+    double* ll_partials; int n_ll_partials;                  // out: per-workgroup log-likelihood sums (grid of them)
+};
+namespace mstats {
+bool em_fused_supported(int d, int K);
+int em_fused_partial_rows(int K);
+int em_fused_partial_cols(int d);
+int launch_em_fused_small(const FusedArgs& a, int num_cus, hipStream_t stream);
+}
+/// Fixed-order combination of `n_partials` blocks [KP][FP] (and of the log-likelihood partials) into stats[K*F (+1)].
+void launch_em_reduce_blocks(const double* partials, int n_partials, int KP, int FP, int K, int F, const double* ll_partials,
+                             int n_ll, double* stats, hipStream_t stream);
 /// resp[k*ldr + i] = (labels[i] == k), or 1 everywhere when labels == nullptr; columns n..n_pad-1 are zeroed.
 void launch_fill_responsibilities(const uint32_t* labels, uint32_t n, int K, double* resp, size_t ldr, hipStream_t stream);
 /// Doubles of scratch the statistics kernel needs for (d, K).

@@ -265,7 +265,12 @@ Plan make_plan(int d, int K, int num_cus)
 size_t em_mstats_scratch_doubles(int d, int K, int num_cus)
 {
     const Plan p = make_plan(d, K, num_cus);
-    return (size_t)p.grid_x * p.KP * p.FP;
+    size_t need = (size_t)p.grid_x * p.KP * p.FP;
+    if (mstats::em_fused_supported(d, K)) {   // the fused small-shape kernel runs up to 3 workgroups per CU
+        const size_t fused = (size_t)3 * num_cus * mstats::em_fused_partial_rows(K) * mstats::em_fused_partial_cols(d);
+        if (fused > need) need = fused;
+    }
+    return need;
 }
 
 int launch_em_mstats(const MstatsArgs& a, int num_cus, hipStream_t stream)
@@ -303,6 +308,14 @@ void launch_em_reduce(const MstatsArgs& a, int num_cus, int grid_x, hipStream_t 
     const int red_blocks = (total + 255) / 256 + 1;
     hipLaunchKernelGGL(em_reduce_kernel, dim3(red_blocks), dim3(256), 0, stream, a.partials, grid_x, p.KP, p.FP, a.K, F,
                        a.ll_partials, a.n_ll_partials, a.stats);
+}
+
+void launch_em_reduce_blocks(const double* partials, int n_partials, int KP, int FP, int K, int F, const double* ll_partials,
+                             int n_ll, double* stats, hipStream_t stream)
+{
+    const int red_blocks = (K * F + 255) / 256 + 1;
+    hipLaunchKernelGGL(em_reduce_kernel, dim3(red_blocks), dim3(256), 0, stream, partials, n_partials, KP, FP, K, F, ll_partials,
+                       n_ll, stats);
 }
 
 void launch_ll_reduce(const double* ll_partials, int n_ll, double* out, hipStream_t stream)

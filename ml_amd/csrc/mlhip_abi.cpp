@@ -150,6 +150,8 @@ struct mlhip_data {
     PinnedBuf params_host, stats_host;
     int n_ll = 0;
     bool have_estep = false;
+    bool lw_valid = false;        // false after a fused step: lw is rebuilt from params_dev on demand (ensure_lw)
+    int estep_variant = 0;        // record layout currently in params_dev: 0 = valu, 1 = mfma16, 2 = mfma4
     // source of the last statistics pass (for the per-component refinement pass)
     int stats_mode = 0;
     const double* stats_resp = nullptr;
@@ -367,11 +369,12 @@ void ensure_em_workspace(mlhip_data* dt, int K)
     dt->em_K = K;
 }
 
-void run_estep(mlhip_data* dt, int K, const double* mixing, const double* means, const double* covs)
+/// Builds the per-component records for the E-step kernel that fits (d, env) and uploads them to params_dev.
+void prepare_estep(mlhip_data* dt, int K, const double* mixing, const double* means, const double* covs)
 {
     mlhip_ctx* ctx = dt->ctx;
     ensure_em_workspace(dt, K);
-        // d in 12..64: 4x4-block triangular matrix-core kernel (mfma4). For d <= 32, MLHIP_ESTEP=mfma16 selects the 16x16x4
+    // d in 12..128: 4x4-block triangular matrix-core kernel (mfma4). For d <= 32, MLHIP_ESTEP=mfma16 selects the 16x16x4
     // block-triangular one and MLHIP_ESTEP=valu the scalar-fed VALU kernel (the only one below d = 12), for A/B runs.
     bool use_mfma = estep_mfma_supported(dt->D), use_mfma4 = estep_mfma4_supported(dt->D);
     if (dt->D <= kRegDim) {
@@ -393,6 +396,13 @@ void run_estep(mlhip_data* dt, int K, const double* mixing, const double* means,
         HIP_CHECK(hipMemcpyAsync(dt->params_dev.p, dt->params_host.p, sizeof(double) * estep_param_stride(dt->D) * K,
                                  hipMemcpyHostToDevice, ctx->stream));
     }
+    dt->estep_variant = use_mfma4 ? 2 : (use_mfma ? 1 : 0);
+}
+
+/// E-step kernel on the records in params_dev: fills lw, lse and the log-likelihood partials.
+void launch_estep(mlhip_data* dt, int K)
+{
+    mlhip_ctx* ctx = dt->ctx;
     EstepArgs a{};
     a.xt = dt->xt.as<double>(); a.ldx = dt->ldx; a.n = dt->n; a.D = dt->D;
     a.params = dt->params_dev.as<double>(); a.K = K;
@@ -400,13 +410,75 @@ void run_estep(mlhip_data* dt, int K, const double* mixing, const double* means,
     a.ll_partials = dt->ll_partials.as<double>(); a.n_ll_partials = kMaxLlPartials;
     int grid = 0;
     ctx->timed("em_estep", [&] {
-        grid = use_mfma4 ? launch_em_estep_mfma4(a, ctx->num_cus, ctx->stream)
-             : use_mfma ? launch_em_estep_mfma(a, ctx->num_cus, ctx->stream) : launch_em_estep(a, ctx->stream);
+        grid = dt->estep_variant == 2 ? launch_em_estep_mfma4(a, ctx->num_cus, ctx->stream)
+             : dt->estep_variant == 1 ? launch_em_estep_mfma(a, ctx->num_cus, ctx->stream) : launch_em_estep(a, ctx->stream);
     });
     if (grid < 0) throw Unsupported("E-step kernel not instantiated for this dimension");
     HIP_CHECK(hipGetLastError());
     dt->n_ll = grid;
     dt->have_estep = true;
+    dt->lw_valid = true;
+}
+
+void run_estep(mlhip_data* dt, int K, const double* mixing, const double* means, const double* covs)
+{
+    prepare_estep(dt, K, mixing, means, covs);
+    launch_estep(dt, K);
+}
+
+/// After a fused step only lse exists on the device; whoever needs the log-responsibility block (labels,
+/// responsibilities, a separate M-step, the refinement pass) gets it rebuilt from the same parameter records.
+void ensure_lw(mlhip_data* dt, int K)
+{
+    if (dt->have_estep && !dt->lw_valid) launch_estep(dt, K);
+}
+
+/// All-reduces the reduced statistics buffer [K*F stats, ll_sum] and leaves it in stats_host.
+void collect_stats(mlhip_data* dt, int K)
+{
+    mlhip_ctx* ctx = dt->ctx;
+    const size_t count = (size_t)K * stats_count(dt->d) + 1;
+    if (ctx->reduce_fn && ctx->reduce_on_device) {
+        if (ctx->reduce_fn(ctx->reduce_user, dt->stats_dev.as<double>(), count, 1, ctx->stream) != 0)
+            throw std::runtime_error("all-reduce hook failed");
+    }
+    HIP_CHECK(hipMemcpyAsync(dt->stats_host.p, dt->stats_dev.p, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+    if (ctx->reduce_fn && !ctx->reduce_on_device) {
+        if (ctx->reduce_fn(ctx->reduce_user, dt->stats_host.as<double>(), count, 0, ctx->stream) != 0)
+            throw std::runtime_error("all-reduce hook failed");
+    }
+}
+
+/// One EM iteration's device work in a single kernel where the shape allows (d <= 6, K <= 32 or d <= 4, K <= 64: em_fused_small.hip): no
+/// N x K block in HBM. MLHIP_FUSED=0 keeps the two-kernel path. Returns false when the shape is not covered.
+bool run_fused_step(mlhip_data* dt, int K, const double* mixing, const double* means, const double* covs)
+{
+    const char* env = std::getenv("MLHIP_FUSED");
+    if ((env && env[0] == '0') || !mstats::em_fused_supported(dt->d, K)) return false;
+    mlhip_ctx* ctx = dt->ctx;
+    prepare_estep(dt, K, mixing, means, covs);
+    if (dt->estep_variant != 0) return false;            // (cannot happen for d <= 8; the fused kernel reads VALU records)
+    FusedArgs a{};
+    a.xt = dt->xt.as<double>(); a.ldx = dt->ldx; a.n = dt->n; a.d = dt->d;
+    a.shift = dt->shift_dev.as<double>(); a.params = dt->params_dev.as<double>(); a.K = K;
+    a.lse = dt->lse.as<double>();
+    a.partials = dt->partials.as<double>(); a.partials_capacity = dt->partials.bytes / sizeof(double);
+    a.ll_partials = dt->ll_partials.as<double>(); a.n_ll_partials = kMaxLlPartials;
+    int grid = 0;
+    ctx->timed("em_fused", [&] { grid = mstats::launch_em_fused_small(a, ctx->num_cus, ctx->stream); });
+    if (grid <= 0) throw std::runtime_error("fused EM kernel launch failed");
+    launch_em_reduce_blocks(a.partials, grid, mstats::em_fused_partial_rows(K), mstats::em_fused_partial_cols(dt->d), K,
+                            stats_count(dt->d), a.ll_partials, grid, dt->stats_dev.as<double>(), ctx->stream);
+    HIP_CHECK(hipGetLastError());
+    dt->n_ll = grid;
+    dt->have_estep = true;
+    dt->lw_valid = false;
+    dt->stats_mode = kFromLogResp;
+    dt->stats_resp = dt->lw.as<double>();
+    dt->stats_ld = dt->ldr;
+    collect_stats(dt, K);
+    return true;
 }
 
 /// Runs the statistics kernel on log-responsibilities (mode kFromLogResp: the E-step's lw/lse) or on plain
@@ -434,17 +506,7 @@ void run_mstats(mlhip_data* dt, int K, int mode, const double* resp_dev, size_t 
     if (rc <= 0) throw std::runtime_error("statistics kernel launch failed (plan/scratch)");
     launch_em_reduce(a, ctx->num_cus, rc, ctx->stream);
     HIP_CHECK(hipGetLastError());
-    const size_t count = (size_t)K * stats_count(dt->d) + 1;
-    if (ctx->reduce_fn && ctx->reduce_on_device) {
-        if (ctx->reduce_fn(ctx->reduce_user, dt->stats_dev.as<double>(), count, 1, ctx->stream) != 0)
-            throw std::runtime_error("all-reduce hook failed");
-    }
-    HIP_CHECK(hipMemcpyAsync(dt->stats_host.p, dt->stats_dev.p, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
-    ctx->sync();
-    if (ctx->reduce_fn && !ctx->reduce_on_device) {
-        if (ctx->reduce_fn(ctx->reduce_user, dt->stats_host.as<double>(), count, 0, ctx->stream) != 0)
-            throw std::runtime_error("all-reduce hook failed");
-    }
+    collect_stats(dt, K);
 }
 
 double ll_from_stats(const mlhip_data* dt, int K)
@@ -482,6 +544,7 @@ void refine_component(mlhip_data* dt, int k, double* mean_k, double* cov_k)
 {
     mlhip_ctx* ctx = dt->ctx;
     const int d = dt->d, F = stats_count(d);
+    if (dt->stats_mode == kFromLogResp) ensure_lw(dt, dt->em_K);   // after a fused step the block is not in HBM yet
     dt->refine_shift.reserve(sizeof(double) * d);
     dt->refine_stats.reserve(sizeof(double) * (F + 1));
     HIP_CHECK(hipMemcpyAsync(dt->refine_shift.p, mean_k, sizeof(double) * d, hipMemcpyHostToDevice, ctx->stream));
@@ -791,6 +854,7 @@ int mlhip_em_maximisation(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, double* 
         check_em_args(ctx, data, K);
         require(mixing_out && means_out && covariances_out, "null argument");
         require(data->have_estep && data->em_K == (int)K, "no E-step results on the device for this K");
+        ensure_lw(data, (int)K);
         run_mstats(data, (int)K, kFromLogResp, nullptr, 0, true);
         finalize_out(data, (int)K, mixing_out, means_out, covariances_out);
     });
@@ -804,10 +868,14 @@ int mlhip_em_step(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* mi
         check_em_args(ctx, data, K);
         require(mixing && means && covariances && log_likelihood && mixing_out && means_out && covariances_out, "null argument");
         PhaseTrace tr;
-        run_estep(data, (int)K, mixing, means, covariances);
-        tr.mark("params+launch E");
-        run_mstats(data, (int)K, kFromLogResp, nullptr, 0, true);
-        tr.mark("M launch+sync+D2H");
+        if (run_fused_step(data, (int)K, mixing, means, covariances)) {
+            tr.mark("fused E+M launch+sync+D2H");
+        } else {
+            run_estep(data, (int)K, mixing, means, covariances);
+            tr.mark("params+launch E");
+            run_mstats(data, (int)K, kFromLogResp, nullptr, 0, true);
+            tr.mark("M launch+sync+D2H");
+        }
         *log_likelihood = ll_from_stats(data, (int)K);
         finalize_out(data, (int)K, mixing_out, means_out, covariances_out);
         tr.mark("closing arithmetic");
@@ -856,6 +924,7 @@ int mlhip_em_responsibilities(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, doub
         require(resp, "null argument");
         require(ldr >= (int64_t)data->n, "ldr must be >= n_local");
         require(data->have_estep && data->em_K == (int)K, "no E-step results on the device for this K");
+        ensure_lw(data, (int)K);
         data->resp_dev.reserve(sizeof(double) * data->ldr * K);
         RespArgs a{data->lw.as<double>(), data->ldr, data->lse.as<double>(), data->n, (int)K,
                    data->resp_dev.as<double>(), data->ldr, nullptr};
@@ -873,6 +942,7 @@ int mlhip_em_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, uint32_t* labe
         check_em_args(ctx, data, K);
         require(labels, "null argument");
         require(data->have_estep && data->em_K == (int)K, "no E-step results on the device for this K");
+        ensure_lw(data, (int)K);
         data->labels_dev.reserve(sizeof(uint32_t) * data->n_pad);
         RespArgs a{data->lw.as<double>(), data->ldr, data->lse.as<double>(), data->n, (int)K, nullptr, 0,
                    data->labels_dev.as<uint32_t>()};
