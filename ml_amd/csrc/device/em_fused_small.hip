@@ -69,39 +69,52 @@ __global__ __launch_bounds__(256, (D <= 4 && RBW <= 2) ? 3 : 2) void em_fused_sm
         // ---- 1. log-densities of all components (statically unrolled: the values stay in registers)
         double lwv[KMAX];
         double m = -__builtin_inf();
+        // Guards are per group of 4 components (wave-uniform branches; per-component guards cost more in register copies
+        // at the joins than the arithmetic they save): inside a live group a record index beyond K is clamped and the
+        // value replaced by -inf, which the normalisation below turns into an exact 0.
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            lwv[k] = -__builtin_inf();
-            if (k < K) {                                 // wave-uniform
-                const double* __restrict__ p = recs + k * PS;   // LDS broadcast reads at compile-time offsets
-                double z[D];
+        for (int k4 = 0; k4 < KMAX; k4 += 4) {
+            if (k4 < K) {
 #pragma unroll
-                for (int j = 0; j < D; ++j) z[j] = x[j] - p[j];
-                const double* __restrict__ w = p + D;
-                double q = 0.0;
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k4 + u;
+                    const double* __restrict__ p = recs + min(k, K - 1) * PS;   // LDS broadcast reads
+                    double z[D];
 #pragma unroll
-                for (int j = 0; j < D; ++j) {
-                    double y = w[j * (j + 1) / 2] * z[0];
+                    for (int j = 0; j < D; ++j) z[j] = x[j] - p[j];
+                    const double* __restrict__ w = p + D;
+                    double q = 0.0;
 #pragma unroll
-                    for (int l = 1; l <= j; ++l) y = __builtin_fma(w[j * (j + 1) / 2 + l], z[l], y);
-                    q = __builtin_fma(y, y, q);
+                    for (int j = 0; j < D; ++j) {
+                        double y = w[j * (j + 1) / 2] * z[0];
+#pragma unroll
+                        for (int l = 1; l <= j; ++l) y = __builtin_fma(w[j * (j + 1) / 2 + l], z[l], y);
+                        q = __builtin_fma(y, y, q);
+                    }
+                    const double lw = k < K ? __builtin_fma(-0.5, q, p[PS - 1]) : -__builtin_inf();
+                    lwv[k] = lw;
+                    m = lw > m ? lw : m;
                 }
-                const double lw = __builtin_fma(-0.5, q, p[PS - 1]);
-                lwv[k] = lw;
-                m = lw > m ? lw : m;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) lwv[k4 + u] = -__builtin_inf();
             }
         }
         // ---- 2. normalisation
         double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            if (k < K) {
-                const double e = exp(lwv[k] - m);
-                lwv[k] = e;
-                s += e;
-                __builtin_amdgcn_sched_barrier(0);
+        for (int k4 = 0; k4 < KMAX; k4 += 4) {
+            if (k4 < K) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double e = exp(lwv[k4 + u] - m);       // exp(-inf) = 0 for the clamped tail
+                    lwv[k4 + u] = e;
+                    s += e;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             } else {
-                lwv[k] = 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) lwv[k4 + u] = 0.0;
             }
         }
         const double lse = m + log(s);
