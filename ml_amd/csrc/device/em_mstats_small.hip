@@ -80,14 +80,20 @@ __global__ __launch_bounds__(256, 2) void em_mstats_small_kernel(
             // ---- responsibility block rb -> LDS (exp once per (sample, component); padding rows are zero)
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                double r = 0.0;
-                if ((rb0 + rb) * 16 + it < K) {                 // wave-uniform
-                    r = rv[it];
-                    if (EXP) r = exp(r - lcur);
-                    r = live ? r : 0.0;
+            for (int it4 = 0; it4 < 16; it4 += 4) {
+                // guards per group of 4 rows (wave-uniform): rows beyond K inside a live group were loaded from row K-1
+                // (clamped) and are zeroed by the select
+                if ((rb0 + rb) * 16 + it4 < K) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        double r = rv[it4 + u];
+                        if (EXP) r = exp(r - lcur);
+                        Rw[lane * RSS + it4 + u] = (live && (rb0 + rb) * 16 + it4 + u < K) ? r : 0.0;
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) Rw[lane * RSS + it4 + u] = 0.0;
                 }
-                Rw[lane * RSS + it] = r;
             }
             // next block of rows (or the first block of the next tile): in flight during the MFMA phase
             if (rb + 1 < RBW) load_rows(tile, rb + 1); else load_rows(next, 0);
