@@ -103,9 +103,9 @@ def kmeans_workload(args, rank, local_rank, world, dist, torch):
     counts(K), sums(K*d)] per step."""
     from ml_amd import _lib, synth
     from ml_amd import dist as mldist
-    n = args.n if args.n != N_TOTAL else 100_000_000
-    d = args.dim if args.dim != DIM else 8
-    K = args.components if args.components != COMPONENTS else 256
+    n = args.n if args.n is not None else 100_000_000
+    d = args.dim if args.dim is not None else 8
+    K = args.components if args.components is not None else 256
     lo, hi = mldist.shard_bounds(n, world, rank)
     mix = synth.Mixture(d, K, seed=77, diagonal=True)
     X = np.empty((hi - lo, d))
@@ -185,9 +185,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=N_TOTAL, help="total samples (default: the BASELINE.json configuration)")
-    ap.add_argument("--dim", type=int, default=DIM)
-    ap.add_argument("--components", type=int, default=COMPONENTS)
+    ap.add_argument("--n", type=int, default=None, help="total samples (default: the BASELINE.json configuration)")
+    ap.add_argument("--dim", type=int, default=None)
+    ap.add_argument("--components", type=int, default=None, help="mixture components / clusters")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=200_000)
     ap.add_argument("--force-hook", action="store_true",
@@ -220,7 +220,9 @@ def main():
             dist.destroy_process_group()
         return
 
-    n, d, K = args.n, args.dim, args.components
+    n = args.n if args.n is not None else N_TOTAL
+    d = args.dim if args.dim is not None else DIM
+    K = args.components if args.components is not None else COMPONENTS
     lo, hi = mldist.shard_bounds(n, world, rank)
     mix = synth.Mixture(d, K)
     X, _ = mix.sample(hi - lo, stream=rank)
