@@ -90,6 +90,7 @@ struct KmeansArgs {
     double* min_dist;                          // out (may be null): per-sample min squared distance
     int accumulate;                            // also accumulate per-cluster sums / counts
     double* partials; size_t partials_capacity;
+    double* cnorm;                             // device scratch, K rounded up to 16 doubles: -|c_k|^2/2 (chunked-table kernel)
     double* out;                               // device: [inertia, n_changed, counts(K), sums(K*d)]
 };
 size_t kmeans_scratch_doubles(int d, int K, int num_cus);

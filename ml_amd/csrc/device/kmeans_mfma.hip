@@ -71,14 +71,15 @@ template <int D, bool USE_LDS, bool CHUNKED>
 __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
     const double* __restrict__ xt, size_t ldx, uint32_t n, uint32_t n_pad, int d, const double* __restrict__ cent, int K,
     const double* __restrict__ scale, uint32_t* __restrict__ labels, const uint32_t* __restrict__ old_labels,
-    int have_old, double* __restrict__ min_dist, int accumulate, double* __restrict__ partials, size_t pstride, int KC)
+    int have_old, double* __restrict__ min_dist, int accumulate, double* __restrict__ partials, size_t pstride, int KC,
+    const double* __restrict__ cnorm)
 {
     constexpr int Q = D / 4;          // 4-dimension steps of the MFMA
     constexpr int NSB = D <= kMidDim ? 4 : 2;   // 16-sample blocks per wave: the coordinates take Q * NSB doubles per lane
     constexpr int GS = 16 * NSB;      // samples per wave group
     // exact phase: fully unrolled on register-resident coordinates up to d = 64; above, rolled loops that re-read the
     // sample (unrolling would let the compiler hoist all D loads back into registers)
-    constexpr int kExactUnroll = D <= kMidDim ? D : 2;
+    constexpr int kExactUnroll = D <= kMidDim ? D : 8;   // 8 loads in flight per trip: a trip per load is latency-bound
     constexpr int DS = D + 1;         // odd row stride of the centroid table: conflict-free A-operand reads
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int Kp = (K + 15) & ~15;
@@ -120,11 +121,7 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
         }
     } else {
         double mx = 0.0;
-        for (int k = tid; k < K; k += BSM) {
-            double nn = 0.0;
-            for (int j = 0; j < D; ++j) nn = __builtin_fma(cent[(size_t)k * D + j], cent[(size_t)k * D + j], nn);
-            mx = fmax(mx, nn);
-        }
+        for (int k = tid; k < K; k += BSM) mx = fmax(mx, -2.0 * cnorm[k]);      // cnorm = -|c|^2/2 (kmeans_cnorm_kernel)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
         if (lane == 0) red[wave] = mx;
@@ -166,16 +163,24 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
         const int rows = min(KT, Kp - k0);      // a multiple of 16
         if constexpr (CHUNKED) {
             __syncthreads();                    // every wave is done with the previous chunk
-            for (int e = tid; e < rows * DS; e += BSM) {
-                const int k = e / DS, j = e - k * DS;
-                Cs[e] = (k0 + k < K && j < D) ? cent[(size_t)(k0 + k) * D + j] : 0.0;
+            // the chunk is one contiguous range of the centroid array: 4 independent loads per thread in flight, then the
+            // LDS writes with the row padding (column D of a row is never read)
+            const int total = rows * D;
+            const double* __restrict__ src = cent + (size_t)k0 * D;
+            for (int g0 = tid; g0 < total; g0 += 4 * BSM) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int gi = g0 + u * BSM;
+                    v[u] = (gi < total && k0 + gi / D < K) ? src[gi] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int gi = g0 + u * BSM;
+                    if (gi < total) Cs[(gi / D) * DS + gi % D] = v[u];
+                }
             }
-            for (int k = tid; k < rows; k += BSM) {
-                double nn = 0.0;
-                if (k0 + k < K)
-                    for (int j = 0; j < D; ++j) nn = __builtin_fma(cent[(size_t)(k0 + k) * D + j], cent[(size_t)(k0 + k) * D + j], nn);
-                cn[k] = k0 + k < K ? -0.5 * nn : -__builtin_inf();
-            }
+            for (int k = tid; k < rows; k += BSM) cn[k] = cnorm[k0 + k];     // -inf for the padding rows
             __syncthreads();
         }
         for (int cb = 0; cb < rows / 16; ++cb) {
@@ -194,14 +199,47 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
                     for (int q = 0; q < Q; ++q) acc[sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], xb[q][sb], acc[sb], 0, 0, 0);
                 }
             } else {
-                // large d: the A operands are read step by step (Q of them would not fit next to the coordinates)
+                // large d: the A operands are read step by step (Q of them would not fit next to the coordinates), and
+                // TWO cluster blocks advance together where the chunk has a second one: with 2 sample blocks per wave
+                // that gives 4 independent accumulator chains instead of 2 (a dependent MFMA waits out the pipeline).
+                const bool pair = cb + 1 < rows / 16;               // wave-uniform
+                d4 acc2[NSB];
 #pragma unroll
                 for (int sb = 0; sb < NSB; ++sb) acc[sb] = init;
+                if (pair) {
+                    d4 init2;
 #pragma unroll
-                for (int q = 0; q < Q; ++q) {
-                    const double aq = Cs[(16 * cb + s) * DS + 4 * q + g];
+                    for (int r = 0; r < 4; ++r) init2[r] = cn[16 * (cb + 1) + g + 4 * r];
 #pragma unroll
-                    for (int sb = 0; sb < NSB; ++sb) acc[sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, xb[q][sb], acc[sb], 0, 0, 0);
+                    for (int sb = 0; sb < NSB; ++sb) acc2[sb] = init2;
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        const double aq = Cs[(16 * cb + s) * DS + 4 * q + g];
+                        const double aq2 = Cs[(16 * (cb + 1) + s) * DS + 4 * q + g];
+#pragma unroll
+                        for (int sb = 0; sb < NSB; ++sb) {
+                            acc[sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, xb[q][sb], acc[sb], 0, 0, 0);
+                            acc2[sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq2, xb[q][sb], acc2[sb], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int sb = 0; sb < NSB; ++sb) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const double v = acc[sb][r];
+                            idx[sb] = (v > best[sb]) ? k0 + 16 * cb + g + 4 * r : idx[sb];
+                            track_top2(best[sb], second[sb], v, idx[sb]);
+                        }
+                        acc[sb] = acc2[sb];                          // the second block goes through the common tail
+                    }
+                    ++cb;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        const double aq = Cs[(16 * cb + s) * DS + 4 * q + g];
+#pragma unroll
+                        for (int sb = 0; sb < NSB; ++sb) acc[sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, xb[q][sb], acc[sb], 0, 0, 0);
+                    }
                 }
             }
 #pragma unroll
@@ -240,15 +278,16 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
         if (active && lane < GS && i < n) {
             const SampleRow<D> x(xt, ldx, i);
             double xn = 0.0;
-#pragma unroll kExactUnroll
-            for (int j = 0; j < D; ++j) { const double v = x(j); xn = __builtin_fma(v, v, xn); }
             uint32_t arg = (uint32_t)my_idx;
             double dist = 0.0;
             {
+                // |x|^2 and the exact distance to the winner in one pass over the sample (two independent fma chains)
                 const double* c = CHUNKED ? cent + (size_t)arg * D : Cs + (size_t)arg * DS;
 #pragma unroll kExactUnroll
                 for (int j = 0; j < D; ++j) {
-                    const double t = x(j) - c[j];
+                    const double v = x(j);
+                    xn = __builtin_fma(v, v, xn);
+                    const double t = v - c[j];
                     dist = __builtin_fma(t, t, dist);
                 }
             }
@@ -313,6 +352,20 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
     }
 }
 
+/// cnorm[k] = -|c_k|^2 / 2 with the ascending-j fma chain used everywhere, -inf for the rows that pad K up to a multiple
+/// of 16: computed once per step for the chunked-table kernel (per chunk and sweep it would be a serial chain of D
+/// dependent loads in front of every barrier).
+__global__ __launch_bounds__(256) void kmeans_cnorm_kernel(const double* __restrict__ cent, int K, int Kp, int D,
+                                                            double* __restrict__ cnorm)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= Kp) return;
+    double nn = 0.0;
+    if (k < K)
+        for (int j = 0; j < D; ++j) nn = __builtin_fma(cent[(size_t)k * D + j], cent[(size_t)k * D + j], nn);
+    cnorm[k] = k < K ? -0.5 * nn : -__builtin_inf();
+}
+
 template <int D>
 int launch_t(const KmeansArgs& a, int num_cus, size_t pstride, hipStream_t stream)
 {
@@ -332,14 +385,15 @@ int launch_t(const KmeansArgs& a, int num_cus, size_t pstride, hipStream_t strea
 #define MLHIP_KM_ARGS a.xt, a.ldx, a.n, n_pad, a.d, a.centroids, a.K, a.scale, a.labels, a.old_labels, a.have_old, a.min_dist, \
                       accumulate_here, a.partials, pstride
     if (chunked) {
-        int KC = (int)((36 * 1024) / (sizeof(double) * (D + 2))) & ~15;     // rows per chunk: ~36 KB of table
+        int KC = (int)(((D <= kMidDim ? 36 : 60) * 1024) / (sizeof(double) * (D + 2))) & ~15;   // rows per chunk: ~36 / 60 KB of table
         if (KC < 16) KC = 16;
         const size_t smem = sizeof(double) * ((size_t)KC * (D + 1) + KC + 1);
-        hipLaunchKernelGGL((kmeans_mfma_kernel<D, false, true>), dim3(grid), dim3(BSM), smem, stream, MLHIP_KM_ARGS, KC);
+        hipLaunchKernelGGL(kmeans_cnorm_kernel, dim3((Kp + 255) / 256), dim3(256), 0, stream, a.centroids, a.K, Kp, D, a.cnorm);
+        hipLaunchKernelGGL((kmeans_mfma_kernel<D, false, true>), dim3(grid), dim3(BSM), smem, stream, MLHIP_KM_ARGS, KC, a.cnorm);
     } else if (use_lds) {
-        hipLaunchKernelGGL((kmeans_mfma_kernel<D, true, false>), dim3(grid), dim3(BSM), table + accb, stream, MLHIP_KM_ARGS, 0);
+        hipLaunchKernelGGL((kmeans_mfma_kernel<D, true, false>), dim3(grid), dim3(BSM), table + accb, stream, MLHIP_KM_ARGS, 0, a.cnorm);
     } else {
-        hipLaunchKernelGGL((kmeans_mfma_kernel<D, false, false>), dim3(grid), dim3(BSM), table, stream, MLHIP_KM_ARGS, 0);
+        hipLaunchKernelGGL((kmeans_mfma_kernel<D, false, false>), dim3(grid), dim3(BSM), table, stream, MLHIP_KM_ARGS, 0, a.cnorm);
     }
 #undef MLHIP_KM_ARGS
     if (a.accumulate && !use_lds) launch_kmeans_update(a, grid, pstride, stream);

@@ -159,7 +159,7 @@ struct mlhip_data {
     DevBuf refine_shift, refine_stats;
     uint64_t refined_components = 0;   // diagnostic counter
     // K-means workspace
-    DevBuf km_labels[2], km_cent, km_partials, km_out, km_mind, km_scale;
+    DevBuf km_labels[2], km_cent, km_partials, km_out, km_mind, km_scale, km_cnorm;
     PinnedBuf km_host;
     int km_cur = 0;
     bool km_have_old = false;
@@ -167,7 +167,7 @@ struct mlhip_data {
     ~mlhip_data()
     {
         for (DevBuf* b : {&xt, &shift_dev, &lw, &lse, &ll_partials, &params_dev, &partials, &stats_dev, &resp_dev,
-                          &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_partials, &km_out, &km_mind, &km_scale,
+                          &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_partials, &km_out, &km_mind, &km_scale, &km_cnorm,
                           &refine_shift, &refine_stats})
             b->release();
         params_host.release(); stats_host.release(); km_host.release();
@@ -634,6 +634,7 @@ void ensure_km_workspace(mlhip_data* dt, int K)
         ctx->sync();
     }
     dt->km_cent.reserve(sizeof(double) * (size_t)K * dt->D);
+    dt->km_cnorm.reserve(sizeof(double) * (size_t)((K + 15) & ~15));
     dt->km_partials.reserve(sizeof(double) * kmeans_scratch_doubles(dt->d, K, ctx->num_cus));
     const size_t ob = sizeof(double) * (2 + (size_t)K * (dt->d + 1));
     dt->km_out.reserve(ob);
@@ -662,6 +663,7 @@ void run_kmeans(mlhip_data* dt, int K, const double* centroids, bool accumulate)
     a.min_dist = dt->km_mind.as<double>();
     a.accumulate = accumulate ? 1 : 0;
     a.partials = dt->km_partials.as<double>(); a.partials_capacity = dt->km_partials.bytes / sizeof(double);
+    a.cnorm = dt->km_cnorm.as<double>();
     a.out = dt->km_out.as<double>();
     int rc = 0;
     ctx->timed("kmeans_assign", [&] { rc = launch_kmeans_assign(a, ctx->num_cus, ctx->stream); });
