@@ -1,4 +1,4 @@
-// E-step of Gaussian-mixture EM on the gfx950 fp64 matrix cores with ELEMENT-BLOCK triangular work (dimensions 12..32)
+// E-step of Gaussian-mixture EM on the gfx950 fp64 matrix cores with ELEMENT-BLOCK triangular work (dimensions 12..128)
 // -- replaces EM::expectation_step (reference ML/EM.cpp:190-219) and its xAx_symmetric calls (ML/LinearAlgebra.cpp:8-31).
 //
 // Same arithmetic as em_estep_mfma.hip (z = x - mu_k, y = W_k z with W_k = L_k^-1 lower triangular, q = |y|^2,
@@ -65,9 +65,10 @@ __device__ __forceinline__ double reduce_scatter_groups(double v0, double v1, do
     return t01 + t23;
 }
 
-/// SB = 16-sample blocks per wave (4: 64 samples per wave, 4 waves per workgroup, 2 waves per SIMD; 2: 32 samples per
-/// wave, 8 waves per workgroup, half the coordinate/accumulator registers -> 4 waves per SIMD). A workgroup always
-/// covers 256 samples per component sweep, so the record staging traffic is the same.
+/// SB = 16-sample blocks per wave (4: 64 samples per wave, 4 waves per workgroup, 2 waves per SIMD -- d <= 32; 2: 32
+/// samples per wave, 8 waves per workgroup, half the coordinate/accumulator registers -- 32 < d <= 64, or
+/// MLHIP_ESTEP_SB=2; 1: 16 samples per wave, 8 waves of 512 threads -- 64 < d <= 128). A workgroup covers 256 samples
+/// per component sweep for SB = 4 and 2 (128 for SB = 1); the component record is staged once per sweep.
 template <int D, int SB>
 __global__ __launch_bounds__(SB == 1 ? 512 : 1024 / SB, D <= 32 ? 8 / SB : 2) void em_estep_mfma4_kernel(
     const double* __restrict__ xt, size_t ldx, uint32_t n, uint32_t n_groups, const double* __restrict__ params, int K,
