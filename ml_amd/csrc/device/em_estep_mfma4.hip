@@ -69,14 +69,16 @@ __device__ __forceinline__ double reduce_scatter_groups(double v0, double v1, do
 /// samples per wave, 8 waves per workgroup, half the coordinate/accumulator registers -- 32 < d <= 64, or
 /// MLHIP_ESTEP_SB=2; 1: 16 samples per wave, 8 waves of 512 threads -- 64 < d <= 128). A workgroup covers 256 samples
 /// per component sweep for SB = 4 and 2 (128 for SB = 1); the component record is staged once per sweep.
-template <int D, int SB>
-__global__ __launch_bounds__(SB == 1 ? 512 : 1024 / SB, D <= 32 ? 8 / SB : 2) void em_estep_mfma4_kernel(
+template <int SB> constexpr int default_waves() { return SB == 1 ? 8 : 16 / SB; }
+
+template <int D, int SB, int NW = default_waves<SB>()>
+__global__ __launch_bounds__(64 * NW, D <= 32 ? 8 / SB : 2) void em_estep_mfma4_kernel(
     const double* __restrict__ xt, size_t ldx, uint32_t n, uint32_t n_groups, const double* __restrict__ params, int K,
     double* __restrict__ lw_out, size_t ldr, double* __restrict__ lse_out, double* __restrict__ ll_partials)
 {
     using B = Blocks<D>;
     constexpr int Q = B::Q, NB = B::NB, PS = B::PS;
-    constexpr int NT = SB == 1 ? 512 : 1024 / SB, NWV = NT / 64;   // threads / waves per workgroup
+    constexpr int NT = 64 * NW, NWV = NW;          // threads / waves per workgroup
     constexpr int GS = 16 * SB;                    // samples per wave
     constexpr int W = 4;                           // LDS read-ahead window (blocks)
     constexpr int NLD = (PS + NT - 1) / NT;        // doubles of a record each thread moves to LDS
@@ -202,19 +204,19 @@ __global__ __launch_bounds__(SB == 1 ? 512 : 1024 / SB, D <= 32 ? 8 / SB : 2) vo
     }
 }
 
-template <int D, int SB>
+template <int D, int SB, int NW = default_waves<SB>()>
 int launch_sb(const EstepArgs& a, int num_cus, hipStream_t stream)
 {
-    constexpr int NT = SB == 1 ? 512 : 1024 / SB, NWV = NT / 64, GS = 16 * SB;
+    constexpr int NT = 64 * NW, NWV = NW, GS = 16 * SB;
     constexpr int NLD = (Blocks<D>::PS + NT - 1) / NT;
     const size_t smem = sizeof(double) * 2 * NLD * NT;
     const uint32_t n_pad = (a.n + kSampleTile - 1) / kSampleTile * kSampleTile;
     const uint32_t n_groups = n_pad / GS;
     uint32_t grid = (n_groups + NWV - 1) / NWV;
-    const uint32_t cap = (uint32_t)num_cus * 2;          // 2 workgroups per CU, persistent
+    const uint32_t cap = (uint32_t)num_cus * 2 * default_waves<SB>() / NW;   // the CU's resident waves, persistent
     if (grid > cap) grid = cap;
     if (grid > (uint32_t)a.n_ll_partials) grid = (uint32_t)a.n_ll_partials;
-    hipLaunchKernelGGL((em_estep_mfma4_kernel<D, SB>), dim3(grid), dim3(NT), smem, stream, a.xt, a.ldx, a.n, n_groups, a.params,
+    hipLaunchKernelGGL((em_estep_mfma4_kernel<D, SB, NW>), dim3(grid), dim3(NT), smem, stream, a.xt, a.ldx, a.n, n_groups, a.params,
                        a.K, a.lw, a.ldr, a.lse, a.ll_partials);
     return (int)grid;
 }
