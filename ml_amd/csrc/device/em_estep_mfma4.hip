@@ -207,6 +207,10 @@ __global__ __launch_bounds__(64 * NW, D <= 32 ? 8 / SB : 2) void em_estep_mfma4_
 template <int D, int SB, int NW = default_waves<SB>()>
 int launch_sb(const EstepArgs& a, int num_cus, hipStream_t stream)
 {
+    // the waves of a workgroup share barriers inside the component loop: a workgroup sweep must cover a whole number of
+    // 256-sample tiles, or the last sweep would leave some waves outside the loop
+    static_assert((16 * SB * NW) % kSampleTile == 0 || kSampleTile % (16 * SB * NW) == 0, "sweep vs tile");
+    static_assert(16 * SB * NW <= kSampleTile, "a workgroup sweep may not exceed the padding granule of N");
     constexpr int NT = 64 * NW, NWV = NW, GS = 16 * SB;
     constexpr int NLD = (Blocks<D>::PS + NT - 1) / NT;
     const size_t smem = sizeof(double) * 2 * NLD * NT;
