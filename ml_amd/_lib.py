@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmlhip.so")
+LIB_PATH = os.environ.get("MLHIP_LIBRARY") or os.path.join(_HERE, "libmlhip.so")   # override: sanitizer / debug builds
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
