@@ -69,7 +69,8 @@ int mlhip_ctx_world(const mlhip_ctx* ctx, int* world_size, int* rank);
 /* ---- resident data ------------------------------------------------------------------------------ */
 /* Copies this rank's d x n block to HBM (stored dimension-major for coalesced per-sample access) and
  * computes the statistics shift (global column mean; all-reduced when a hook is set). The host block is
- * only read during the call (the reference borrows `data` for the duration of fit, ML/EM.cpp:91). */
+ * only read during the call (the reference borrows `data` for the duration of fit, ML/EM.cpp:91).
+ * 1 <= d <= 128 (MLHIP_E_UNSUPPORTED above), n < 2^32 - 256 per rank. */
 int mlhip_data_upload(mlhip_ctx* ctx, const double* x, uint32_t d, uint64_t n, int64_t ld, mlhip_data** out);
 /* Same, from a sample-major block already in device memory (e.g. a torch tensor's data_ptr()). */
 int mlhip_data_upload_dev(mlhip_ctx* ctx, const double* x_dev, uint32_t d, uint64_t n, int64_t ld, mlhip_data** out);
@@ -84,8 +85,9 @@ int mlhip_data_shift(const mlhip_data* data, double* shift);
  *   in : mixing[K], means[d*K] (column k = mean k), covariances[K*d*d] (symmetric, column-major each)
  *   out: *log_likelihood  = mean_i log sum_k pi_k N(x_i|mu_k,Sigma_k)  under the INPUT parameters (:211)
  *        mixing_out/means_out/covariances_out = the M-step result (:229-257, ridge 1e-15 included)
- * Output arrays may alias the input arrays. The unnormalised log-responsibilities of this E-step stay on
- * the device for mlhip_em_responsibilities / mlhip_em_labels. */
+ * Output arrays may alias the input arrays. The E-step results stay available on the device for
+ * mlhip_em_responsibilities / mlhip_em_labels (for small shapes, where the iteration runs as one fused kernel, the
+ * N x K block is rebuilt from the same parameter records when one of them is called). */
 int mlhip_em_step(mlhip_ctx* ctx, mlhip_data* data, uint32_t K,
                   const double* mixing, const double* means, const double* covariances,
                   double* log_likelihood, double* mixing_out, double* means_out, double* covariances_out);
