@@ -159,7 +159,7 @@ struct mlhip_data {
     DevBuf refine_shift, refine_stats;
     uint64_t refined_components = 0;   // diagnostic counter
     // K-means workspace
-    DevBuf km_labels[2], km_cent, km_partials, km_out, km_mind, km_scale, km_cnorm;
+    DevBuf km_labels[2], km_cent, km_partials, km_out, km_mind, km_scale, km_cnorm, km_xt_pad;
     PinnedBuf km_host;
     int km_cur = 0;
     bool km_have_old = false;
@@ -167,7 +167,7 @@ struct mlhip_data {
     ~mlhip_data()
     {
         for (DevBuf* b : {&xt, &shift_dev, &lw, &lse, &ll_partials, &params_dev, &partials, &stats_dev, &resp_dev,
-                          &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_partials, &km_out, &km_mind, &km_scale, &km_cnorm,
+                          &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_partials, &km_out, &km_mind, &km_scale, &km_cnorm, &km_xt_pad,
                           &refine_shift, &refine_stats})
             b->release();
         params_host.release(); stats_host.release(); km_host.release();
@@ -633,12 +633,13 @@ void ensure_km_workspace(mlhip_data* dt, int K)
         HIP_CHECK(hipMemcpyAsync(dt->km_scale.p, m.data(), sizeof(double) * dt->d, hipMemcpyHostToDevice, ctx->stream));
         ctx->sync();
     }
-    dt->km_cent.reserve(sizeof(double) * (size_t)K * dt->D);
+    const int Dp = (dt->D + 3) & ~3;                              // (the K-means kernels may run on a zero-padded copy)
+    dt->km_cent.reserve(sizeof(double) * (size_t)K * Dp);
     dt->km_cnorm.reserve(sizeof(double) * (size_t)((K + 15) & ~15));
     dt->km_partials.reserve(sizeof(double) * kmeans_scratch_doubles(dt->d, K, ctx->num_cus));
     const size_t ob = sizeof(double) * (2 + (size_t)K * (dt->d + 1));
     dt->km_out.reserve(ob);
-    const size_t hb = ob > sizeof(double) * (size_t)K * dt->D ? ob : sizeof(double) * (size_t)K * dt->D;
+    const size_t hb = ob > sizeof(double) * (size_t)K * Dp ? ob : sizeof(double) * (size_t)K * Dp;
     dt->km_host.reserve(hb);
 }
 
@@ -647,14 +648,29 @@ void run_kmeans(mlhip_data* dt, int K, const double* centroids, bool accumulate)
 {
     mlhip_ctx* ctx = dt->ctx;
     ensure_km_workspace(dt, K);
+    // The matrix-core kernel needs a multiple of 4 dimensions. For d = 1, 2, 3, 5, 6 (stored with D = d or 6 rows) and many
+    // clusters it still beats the direct-form kernel (d = 6, K = 256: 1.9 -> 1.2 ms at N = 10M), so such blocks get a copy
+    // padded with zero rows once: zero coordinates add exactly 0 to every distance, labels and sums are unchanged.
+    int D = dt->D;
+    const double* xt = dt->xt.as<double>();
+    if (D % 4 != 0 && K >= 128 && !std::getenv("MLHIP_KMEANS")) {
+        const int Dp = (D + 3) & ~3;
+        if (!dt->km_xt_pad.p) {
+            dt->km_xt_pad.reserve(sizeof(double) * dt->ldx * Dp);
+            HIP_CHECK(hipMemsetAsync(dt->km_xt_pad.p, 0, sizeof(double) * dt->ldx * Dp, ctx->stream));
+            HIP_CHECK(hipMemcpyAsync(dt->km_xt_pad.p, dt->xt.p, sizeof(double) * dt->ldx * D, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        D = Dp;
+        xt = dt->km_xt_pad.as<double>();
+    }
     double* ch = dt->km_host.as<double>();
     for (int k = 0; k < K; ++k)
-        for (int j = 0; j < dt->D; ++j) ch[(size_t)k * dt->D + j] = j < dt->d ? centroids[(size_t)k * dt->d + j] : 0.0;
-    HIP_CHECK(hipMemcpyAsync(dt->km_cent.p, ch, sizeof(double) * (size_t)K * dt->D, hipMemcpyHostToDevice, ctx->stream));
+        for (int j = 0; j < D; ++j) ch[(size_t)k * D + j] = j < dt->d ? centroids[(size_t)k * dt->d + j] : 0.0;
+    HIP_CHECK(hipMemcpyAsync(dt->km_cent.p, ch, sizeof(double) * (size_t)K * D, hipMemcpyHostToDevice, ctx->stream));
     ctx->sync();   // km_host is reused for the results below
     const int nxt = dt->km_cur ^ 1;
     KmeansArgs a{};
-    a.xt = dt->xt.as<double>(); a.ldx = dt->ldx; a.n = dt->n; a.D = dt->D; a.d = dt->d;
+    a.xt = xt; a.ldx = dt->ldx; a.n = dt->n; a.D = D; a.d = dt->d;
     a.centroids = dt->km_cent.as<double>(); a.K = K;
     a.scale = dt->km_scale.as<double>();
     a.labels = dt->km_labels[nxt].as<uint32_t>();
