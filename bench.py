@@ -98,6 +98,24 @@ def cpu_baseline_all_cores(mix, d, K, n_per_thread, iters):
     return (time.perf_counter() - t0) / iters, n_per_thread * threads, threads
 
 
+ROW_CHUNK = 1_250_000
+
+
+def sample_rows(mix, lo, hi):
+    """Rows [lo, hi) of the synthetic data set, which is defined chunk-wise (chunk c = ROW_CHUNK rows drawn from the
+    generator's stream c): every sharding of the rows over ranks sees the same data, so the final log-likelihood of the
+    1-, 2-, 4- and 8-GPU runs can be compared directly."""
+    out = np.empty((hi - lo, mix.d))
+    c = lo // ROW_CHUNK
+    while c * ROW_CHUNK < hi:
+        a, b = c * ROW_CHUNK, (c + 1) * ROW_CHUNK
+        block = mix.sample(ROW_CHUNK, stream=c)[0]
+        s0, s1 = max(lo, a), min(hi, b)
+        out[s0 - lo:s1 - lo] = block[s0 - a:s1 - a]
+        c += 1
+    return out
+
+
 def kmeans_workload(args, rank, local_rank, world, dist, torch):
     """K-means steps/sec, N row-sharded over the ranks, centroids replicated, one all-reduce of [inertia, n_changed,
     counts(K), sums(K*d)] per step."""
@@ -108,11 +126,7 @@ def kmeans_workload(args, rank, local_rank, world, dist, torch):
     K = args.components if args.components is not None else 256
     lo, hi = mldist.shard_bounds(n, world, rank)
     mix = synth.Mixture(d, K, seed=77, diagonal=True)
-    X = np.empty((hi - lo, d))
-    chunk = 12_500_000                                       # bounded temporaries: the block itself is 6.4 GB at N=100M
-    for c, a in enumerate(range(0, hi - lo, chunk)):
-        b = min(hi - lo, a + chunk)
-        X[a:b] = mix.sample(b - a, stream=1000 * rank + c)[0]
+    X = sample_rows(mix, lo, hi)             # chunk-wise definition: the same rows for any number of ranks
     ctx = _lib.Context(local_rank)
     if world > 1 or args.force_hook:
         mldist.install_allreduce(ctx, world, rank)
@@ -225,7 +239,7 @@ def main():
     K = args.components if args.components is not None else COMPONENTS
     lo, hi = mldist.shard_bounds(n, world, rank)
     mix = synth.Mixture(d, K)
-    X, _ = mix.sample(hi - lo, stream=rank)
+    X = sample_rows(mix, lo, hi)             # the same N rows whatever the number of ranks
 
     ctx = _lib.Context(local_rank)
     if world > 1 or args.force_hook:
