@@ -11,15 +11,14 @@
 #include "dll.hpp"
 
 namespace ml {
-/** @brief Methods and classes for clustering algorithms. */
 namespace Clustering {
 
-/** @brief Abstract clustering model. */
+/** What every clustering estimator of this library offers once fitted (pure interface). */
 class Model {
 public:
     DLL_DECLSPEC virtual ~Model();
-    /** @brief Fits the model. @param[in] data Column-major matrix with a data point in every column.
-    @return `true` if fitting converged. @throw std::invalid_argument If `data` has no rows or too few columns. */
+    /** Estimates the model from `data` (d x N, one sample per column); the block is only borrowed for the call.
+    Returns whether the iteration converged; throws std::invalid_argument for d == 0 or fewer samples than clusters. */
     virtual bool fit(ConstMatrixRef data) = 0;
     virtual unsigned int number_clusters() const = 0;
     virtual const std::vector<unsigned int>& labels() const = 0;
@@ -27,35 +26,36 @@ public:
     virtual bool converged() const = 0;
 };
 
-/** @brief Chooses initial locations of centroids. */
+/** Strategy object: produces the K starting centroids of a fit. Subclass it to plug in your own. */
 class CentroidsInitialiser {
 public:
     DLL_DECLSPEC virtual ~CentroidsInitialiser();
-    /** @param[out] centroids `data.rows()` x `number_components`. */
+    /** Fills `centroids` (d x K, one centroid per column) from the d x N sample block, drawing from `prng` if it needs randomness. */
     DLL_DECLSPEC virtual void init(ConstMatrixRef data, std::default_random_engine& prng, unsigned int number_components, MatrixRef centroids) const = 0;
 };
 
-/** @brief Chooses initial component responsibilities. */
+/** Strategy object: produces the N x K starting responsibilities of an EM fit that begins with an M-step. */
 class ResponsibilitiesInitialiser {
 public:
     DLL_DECLSPEC virtual ~ResponsibilitiesInitialiser();
-    /** @param[out] responsibilities `data.cols()` x `number_components`. */
+    /** Fills `responsibilities` (N x K, rows sum to one). */
     DLL_DECLSPEC virtual void init(ConstMatrixRef data, std::default_random_engine& prng, unsigned int number_components, MatrixRef responsibilities) const = 0;
 };
 
-/** @brief Chooses random points as new centroids. */
+/** K distinct samples, picked uniformly (selection sampling: ascending sample indices). */
 class Forgy : public CentroidsInitialiser {
 public:
     DLL_DECLSPEC void init(ConstMatrixRef data, std::default_random_engine& prng, unsigned int number_components, MatrixRef centroids) const override;
 };
 
-/** @brief Assigns points to clusters randomly and then returns cluster means. */
+/** Every sample gets a uniformly random cluster; the centroids are the (running) means of those random groups. */
 class RandomPartition : public CentroidsInitialiser {
 public:
     DLL_DECLSPEC void init(ConstMatrixRef data, std::default_random_engine& prng, unsigned int number_components, MatrixRef centroids) const override;
 };
 
-/** @brief K-means++ seeding. */
+/** K-means++: each new centroid is a sample drawn with probability proportional to its squared distance from the
+nearest centroid chosen so far (the first one uniformly). */
 class KPP : public CentroidsInitialiser {
 public:
     DLL_DECLSPEC void init(ConstMatrixRef data, std::default_random_engine& prng, unsigned int number_components, MatrixRef centroids) const override;
@@ -72,7 +72,8 @@ private:
     MatrixXd centroids_;
 };
 
-/** @brief Initialises centroids and then assigns the responsibility for each point to its closest centroid. */
+/** One-hot responsibilities: asks a CentroidsInitialiser for centroids, then gives each sample to its nearest one
+(first minimum wins). */
 class ClosestCentroid : public ResponsibilitiesInitialiser {
 public:
     /** @throw std::invalid_argument If `centroids_initialiser` is null. */
