@@ -69,6 +69,9 @@ int resolve_host_threads(int local_ranks)
     return t < 1 ? 1 : (t > 8 ? 8 : t);
 }
 
+/// A thread team costs 10-20 us to wake: only worth it when the K factorizations (~2.3 d^3 flop each) are more than that.
+inline bool worth_threads(int K, int d) { return (double)K * d * d * d >= 4.0e5; }
+
 int host_threads()
 {
     int t = g_host_threads.load(std::memory_order_relaxed);
@@ -126,7 +129,7 @@ void build_estep_params_mfma4(int d, int D, int K, const double* mixing, const d
     const int PS = estep_mfma4_param_stride(D);
     const int NB = estep_mfma4_block_count(D);
     const int Q = D / 4;
-#pragma omp parallel num_threads(host_threads()) if (K >= 8)
+#pragma omp parallel num_threads(host_threads()) if (worth_threads(K, d))
     {
     std::vector<double> L((size_t)d * d), W((size_t)d * d);
 #pragma omp for schedule(static)
@@ -169,7 +172,7 @@ void finalize_mstep(int d, int K, const double* stats, const double* shift, doub
                     double* means, double* covariances)
 {
     const int F = stats_count(d);
-#pragma omp parallel num_threads(host_threads()) if (K >= 8)
+#pragma omp parallel num_threads(host_threads()) if (worth_threads(K, d))
     {
     std::vector<double> m(d);
 #pragma omp for schedule(static)
