@@ -222,11 +222,25 @@ def main():
     from ml_amd import dist as mldist
 
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    elif args.force_hook:
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29544", rank=0, world_size=1,
-                                device_id=torch.device("cuda", local_rank))
+    # RCCL prints a version banner on the C-level stdout when its first communicator comes up; stdout is reserved for
+    # the one JSON line, so fd 1 points at stderr until the communicator exists.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if world > 1:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        elif args.force_hook:
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29544", rank=0, world_size=1,
+                                    device_id=torch.device("cuda", local_rank))
+        if world > 1 or args.force_hook:
+            warm = torch.zeros(1, dtype=torch.float64, device="cuda")
+            dist.all_reduce(warm)                      # creates the communicator (and its banner) now
+            torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
 
     if args.workload == "kmeans":
         kmeans_workload(args, rank, local_rank, world, dist, torch)
