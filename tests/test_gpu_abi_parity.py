@@ -307,14 +307,15 @@ def test_kmeans_mfma_and_valu_kernels_agree_bitwise(ctx, oracle, n, d, K, monkey
     assert np.array_equal(a[4][::step], ref)          # distances bit-identical to the oracle's fma chain
 
 
+@pytest.mark.parametrize("d", [8, 4])        # d = 4: the fused small-shape kernel (the refinement rebuilds lw first)
 @pytest.mark.parametrize("sigma,tol", [(1.0, 1e-12), (1e-2, 1e-11), (1e-4, 1e-10), (1e-6, 1e-8)])
-def test_tight_clusters_far_from_the_global_mean(ctx, oracle, sigma, tol):
+def test_tight_clusters_far_from_the_global_mean(ctx, oracle, sigma, tol, d):
     """Clusters whose width is tiny next to their distance from the global mean: the one-GEMM statistics (shared shift)
     would cancel log10((spread/sigma)^2) digits of the covariances, so such components get a second pass about their own
     mean. Parity with the reference's two-pass form holds down to the conditioning of the problem itself
     (~1e-16 * spread / sigma); well-conditioned components are never refined."""
     rng = np.random.default_rng(5)
-    d, K, n = 8, 4, 4000
+    K, n = 4, 4000
     means = 10.0 * rng.standard_normal((K, d))
     comp = rng.integers(0, K, n)
     X = np.ascontiguousarray(means[comp] + sigma * rng.standard_normal((n, d)))
