@@ -80,7 +80,7 @@ def cpu_baseline_all_cores(mix, d, K, n_per_thread, iters):
     the reference's sample loops would do; the K x d x d combine is negligible). The reference itself is single-threaded."""
     import threading
     from oracle import oracle_ctypes as orc
-    threads = usable_cores()
+    threads = min(usable_cores(), 32)         # bounded: every thread holds its own N_t x K responsibility block
     X, _ = mix.sample(n_per_thread * threads, stream=998)
     cov0 = np.stack([np.cov(X[:n_per_thread].T)] * K)
     models = []
