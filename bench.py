@@ -1,26 +1,36 @@
 #!/usr/bin/env python3
 """Headline benchmark: Gaussian-mixture EM iterations/sec at N=10M, d=32, K=64, fp64 (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 either arrives already launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+environment, one rank per GPU) or -- as a bare command -- starts its own N rank processes: the parent does so BEFORE
+anything touches a GPU (it imports neither torch nor the HIP library), waits for them and exits with their status;
+rank 0's JSON line is the only thing on stdout either way.
 
 One step = one EM iteration = E-step + M-step statistics + statistics all-reduce + M-step closing arithmetic
 (K Cholesky/inverse) + convergence bookkeeping, i.e. one trip of the reference loop ML/EM.cpp:143-170, executed
 through the C ABI entry point mlhip_em_step on data already resident in HBM. The N samples are row-sharded
 over the ranks (strong scaling: the job size is fixed), the only exchange is one all-reduce of the K*561+1
-sufficient statistics per iteration through torch.distributed (backend nccl == RCCL over xGMI).
+sufficient statistics per iteration: ncclAllReduce on the library's own RCCL communicator (mlhip_ctx_init_rccl;
+`--allreduce torch` routes it through torch.distributed's nccl backend instead). torch.distributed carries the
+RCCL unique id, the barriers around the timed region and the max-over-ranks of the elapsed time.
 
-Prints ONE JSON line on rank 0 (see the fields below).
+Prints ONE JSON line on rank 0. At N=1 the line also carries `secondary`: K-means (BASELINE.json configs[4]) at one
+GPU's share of that job, N=12.5M, d=8, K=256, with its own roofline and cpu_baseline.
 
-    python bench.py --workload kmeans [--gpus N ...]       second workload, same contract: K-means steps/sec at
-        N=100M, d=8, K=256 (BASELINE.json configs[4]); one step = mlhip_kmeans_step = assignment + exact update sums +
-        all-reduce of counts/sums + new centroids (ML/KMeans.cpp:82-108)."""
+    python bench.py --workload kmeans [--gpus N ...]       K-means steps/sec at N=100M, d=8, K=256 as the primary line;
+        one step = mlhip_kmeans_step = assignment + exact update sums + all-reduce of counts/sums + new centroids
+        (ML/KMeans.cpp:82-108).
+    python bench.py --workload em-diag [...]               diagonal-covariance EM at N=1M, d=16, K=16 (BASELINE.json
+        configs[1]; an extension: the reference has full covariances only)."""
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -28,6 +38,7 @@ sys.path.insert(0, ROOT)
 N_TOTAL, DIM, COMPONENTS = 10_000_000, 32, 64
 FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector == matrix peak (spec); measured ceilings: tools/microbench_fp64
 HBM_PEAK_GBS = 8000.0
+CPU_ITERATIONS = 3           # the CPU baseline is timed over T = 3 iterations
 
 
 def algorithmic_flops(n, d, K):
@@ -43,12 +54,23 @@ def mstats_flops(n, d, K):
     return float(n) * K * (d * d + 3 * d)
 
 
-def cpu_baseline(mix, d, K, n_cpu, iters):
+def diag_flops(n, d, K):
+    """SURVEY.md section 8(d), diagonal covariances: N*K*(8d + 25) per EM iteration."""
+    return float(n) * K * (8 * d + 25)
+
+
+def cpu_baseline(mix, d, K, n_cpu, iters, diagonal=False):
     """The CPU restatement of the reference (oracle/, single thread like the reference) on a bounded sample."""
+    import numpy as np
     from oracle import oracle_ctypes as orc
     X, _ = mix.sample(n_cpu, stream=999)
     em = orc.EM(K)
-    em.set_parameters(mix.initial_means(), np.stack([np.cov(X.T)] * K), np.full(K, 1.0 / K))
+    if diagonal:
+        em.set_covariance_type("diag")
+        cov0 = np.stack([np.diag(np.var(X, axis=0, ddof=1))] * K)
+    else:
+        cov0 = np.stack([np.cov(X.T)] * K)
+    em.set_parameters(mix.initial_means(), cov0, np.full(K, 1.0 / K))
     sec_per_iter = em.time_iterations(X, iters)
     return sec_per_iter, n_cpu
 
@@ -79,6 +101,7 @@ def cpu_baseline_all_cores(mix, d, K, n_per_thread, iters):
     thread on its own sample shard (the E and M steps are sums over samples, so this is what an OpenMP `parallel for` over
     the reference's sample loops would do; the K x d x d combine is negligible). The reference itself is single-threaded."""
     import threading
+    import numpy as np
     from oracle import oracle_ctypes as orc
     threads = min(usable_cores(), 32)         # bounded: every thread holds its own N_t x K responsibility block
     X, _ = mix.sample(n_per_thread * threads, stream=998)
@@ -105,6 +128,7 @@ def sample_rows(mix, lo, hi):
     """Rows [lo, hi) of the synthetic data set, which is defined chunk-wise (chunk c = ROW_CHUNK rows drawn from the
     generator's stream c): every sharding of the rows over ranks sees the same data, so the final log-likelihood of the
     1-, 2-, 4- and 8-GPU runs can be compared directly."""
+    import numpy as np
     out = np.empty((hi - lo, mix.d))
     c = lo // ROW_CHUNK
     while c * ROW_CHUNK < hi:
@@ -116,86 +140,287 @@ def sample_rows(mix, lo, hi):
     return out
 
 
-def kmeans_workload(args, rank, local_rank, world, dist, torch):
+class Job:
+    """What one rank needs around a workload: its GPU context with the statistics all-reduce installed, the barrier that
+    brackets the timed region, and the reductions over ranks for the report."""
+
+    def __init__(self, args, rank, local_rank, world, dist, torch):
+        from ml_amd import _lib
+        from ml_amd import dist as mldist
+        self.args, self.rank, self.local_rank, self.world, self.dist, self.torch = args, rank, local_rank, world, dist, torch
+        self.ctx = _lib.Context(local_rank)
+        self.allreduce = "none"
+        self.rccl_ranks = 1
+        if world > 1 or args.force_hook:
+            if args.allreduce == "native":
+                try:
+                    mldist.install_native_rccl(self.ctx, world, rank)
+                    self.allreduce = "rccl-native (ncclAllReduce on the library's own communicator)"
+                    self.rccl_ranks = self.ctx.rccl_ranks
+                except Exception as e:                       # stay measurable: fall back to torch's communicator
+                    print(f"[bench] native RCCL unavailable on rank {rank} ({e}); using torch.distributed", file=sys.stderr)
+            if self.allreduce == "none":
+                mldist.install_allreduce(self.ctx, world, rank)
+                self.allreduce = "torch.distributed nccl hook"
+                self.rccl_ranks = dist.get_world_size()
+            # every rank must have taken the same route, or the collectives would not match
+            routes = self.gather(self.allreduce)
+            if len(set(routes)) != 1:
+                raise SystemExit(f"ranks disagree on the all-reduce route: {routes}")
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.ctx.synchronize()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        if self.world == 1:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather(self, obj):
+        if self.world == 1:
+            return [obj]
+        box = [None] * self.world
+        self.dist.all_gather_object(box, obj)
+        return box
+
+    def timed(self, step, steps, warmup):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+        for _ in range(warmup):
+            step()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+    def kernel_ms(self, step, names, reps=3):
+        """Per-kernel device time (HIP events on the kernels' own stream) in a separate pass, so that the event
+        synchronisation does not perturb the timed region."""
+        self.ctx.timing_enable(True)
+        self.ctx.timing_reset()
+        for _ in range(reps):
+            step()
+        out = {name: self.ctx.timing_get(name)[0] for name in names}
+        self.ctx.timing_enable(False)
+        return out
+
+    def close(self):
+        self.ctx.close()
+
+
+def traffic_for(kernel, headline):
+    """HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs of this same command at the
+    headline shape; not re-measured inside this run). Returns (bytes or None, provenance string or None)."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not (headline and os.path.exists(tpath)):
+        return None, None
+    try:
+        t = json.load(open(tpath))
+        return t.get(kernel), f"profiles/traffic.json@{t.get('_tag', 'r01_v8')} (rocprofv3 --pmc passes of this command, committed; not measured in this run)"
+    except Exception:
+        return None, None
+
+
+def kmeans_measure(job, n, d, K, steps, warmup, with_cpu, cpu_samples):
     """K-means steps/sec, N row-sharded over the ranks, centroids replicated, one all-reduce of [inertia, n_changed,
-    counts(K), sums(K*d)] per step."""
+    counts(K), sums(K*d)] per step. Returns the report dict on rank 0 (None elsewhere)."""
+    import numpy as np
     from ml_amd import _lib, synth
     from ml_amd import dist as mldist
-    n = args.n if args.n is not None else 100_000_000
-    d = args.dim if args.dim is not None else 8
-    K = args.components if args.components is not None else 256
-    lo, hi = mldist.shard_bounds(n, world, rank)
+    lo, hi = mldist.shard_bounds(n, job.world, job.rank)
     mix = synth.Mixture(d, K, seed=77, diagonal=True)
     X = sample_rows(mix, lo, hi)             # chunk-wise definition: the same rows for any number of ranks
-    ctx = _lib.Context(local_rank)
-    if world > 1 or args.force_hook:
-        mldist.install_allreduce(ctx, world, rank)
-    data = _lib.Data(ctx, X)
+    data = _lib.Data(job.ctx, X)
     del X
-    C = mix.means + 0.3 * np.random.default_rng(1).standard_normal((K, d))
+    state = {"C": mix.means + 0.3 * np.random.default_rng(1).standard_normal((K, d)), "inertia": None}
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        ctx.synchronize()
-        torch.cuda.synchronize()
+    def step():
+        state["inertia"], _, _, state["C"] = data.kmeans_step(state["C"])
 
-    inertia = None
-    for _ in range(args.warmup):
-        inertia, _, _, C = data.kmeans_step(C)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        inertia, _, _, C = data.kmeans_step(C)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ctx.timing_enable(True)
-    ctx.timing_reset()
-    for _ in range(3):
-        inertia, _, _, C = data.kmeans_step(C)
-    k_ms, _ = ctx.timing_get("kmeans_assign")
-    ctx.timing_enable(False)
-    if rank == 0:
+    elapsed = job.timed(step, steps, warmup)
+    k_ms = job.kernel_ms(step, ["kmeans_assign"])["kmeans_assign"]
+    n_locals = job.gather(hi - lo)
+    out = None
+    if job.rank == 0:
         n_local = hi - lo
         flops = float(n_local) * K * 3 * d                  # SURVEY 8(d): N*K*3d (direct-form distances)
         achieved = flops / (k_ms * 1e-3) / 1e12
         out = {
-            "metric": "K-means steps/sec at N=100M d=8 K=256 (fp64)" if (n, d, K) == (100_000_000, 8, 256)
-                      else f"K-means steps/sec at N={n} d={d} K={K} (fp64; diagnostic shape)",
-            "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "metric": f"K-means steps/sec at N={n} d={d} K={K} (fp64)",
+            "value": steps / elapsed, "unit": "steps/s", "n_gpus": job.world, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"K-means (Lloyd) N={n} d={d} K={K}, row-sharded over {world} GPU(s)", "N": n, "d": d,
-                       "K": K, "parallelism": f"dp{world}", "inertia": inertia},
+            "config": {"workload": f"K-means (Lloyd) N={n} d={d} K={K}, row-sharded over {job.world} GPU(s)", "N": n, "d": d,
+                       "K": K, "parallelism": f"dp{job.world}", "inertia": state["inertia"]},
+            "rccl_ranks": job.rccl_ranks, "allreduce": job.allreduce, "n_local": n_locals,
             "roofline": {"bound": "mfma", "kernel": "kmeans_assign", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
                          "kernel_ms": {"kmeans_assign": k_ms},
                          "hbm_algorithmic_gbs": n_local * (8.0 * d + 4) / (k_ms * 1e-3) / 1e9, "hbm_peak_gbs": HBM_PEAK_GBS},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if with_cpu:
             from oracle import oracle_ctypes as orc
-            n_cpu = min(n, 5 * args.cpu_samples)
+            n_cpu = min(n, 5 * cpu_samples)
             Xc, _ = mix.sample(n_cpu, stream=999)
             km = orc.KMeans(K)
-            km.set_centroids(C, n_cpu)
-            sec = km.time_steps(Xc, 1)
+            km.set_centroids(state["C"], n_cpu)
+            sec = km.time_steps(Xc, CPU_ITERATIONS)
             out["cpu_baseline"] = {"value": 1.0 / (sec * n / n_cpu), "unit": "steps/s", "cores": 1, "kind": "port",
-                                   "sample": f"1 K-means step of the single-threaded CPU restatement (oracle/) on {n_cpu} "
-                                             f"samples, time scaled x{n / n_cpu:g} to N={n} (cost is linear in N, "
-                                             f"ML/KMeans.cpp:173-177,187-191)",
+                                   "sample": f"{CPU_ITERATIONS} K-means steps of the single-threaded CPU restatement (oracle/) "
+                                             f"on {n_cpu} samples, time per step scaled x{n / n_cpu:g} to N={n} (cost is "
+                                             f"linear in N, ML/KMeans.cpp:173-177,187-191)",
                                    "seconds_per_step_on_sample": sec}
-        print(json.dumps(out))
     data.close()
-    ctx.close()
+    return out
+
+
+def em_measure(job, n, d, K, steps, warmup, with_cpu, cpu_samples, diagonal=False):
+    """EM iterations/sec (full covariances, or the diagonal extension), N row-sharded over the ranks."""
+    import numpy as np
+    from ml_amd import _lib, synth
+    from ml_amd import dist as mldist
+    lo, hi = mldist.shard_bounds(n, job.world, job.rank)
+    mix = synth.Mixture(d, K, diagonal=diagonal)
+    X = sample_rows(mix, lo, hi)             # the same N rows whatever the number of ranks
+    data = _lib.Data(job.ctx, X)
+    del X
+
+    # Start exactly like EM::fit without maximise_first (ML/EM.cpp:127-135): given means, shared sample covariance.
+    _, cov = data.sample_covariance()
+    if diagonal:
+        cov = np.diag(np.diag(cov))
+    state = {"ll": None, "pi": np.full(K, 1.0 / K), "mu": mix.initial_means(), "S": np.stack([cov] * K)}
+    em_step = data.em_step_diag if diagonal else data.em_step
+
+    def step():
+        state["ll"], state["pi"], state["mu"], state["S"] = em_step(state["pi"], state["mu"], state["S"])
+
+    elapsed = job.timed(step, steps, warmup)
+    names = ["em_diag"] if diagonal else ["em_estep", "em_mstats", "em_fused", "em_fused_wide"]
+    ms = job.kernel_ms(step, names)
+    n_locals = job.gather(hi - lo)
+    if job.rank != 0:
+        data.close()
+        return None
+
+    n_local = hi - lo
+    headline = (n, d, K) == (N_TOTAL, DIM, COMPONENTS) and not diagonal
+    it_tflops = (diag_flops if diagonal else algorithmic_flops)(n_local, d, K) / (elapsed / steps) / 1e12
+    if diagonal:
+        k_ms = ms["em_diag"]
+        gbs = n_local * d * 8.0 / (k_ms * 1e-3) / 1e9          # SURVEY 8(d): algorithmic bytes = X once (fused)
+        roof = {"bound": "hbm", "kernel": "em_diag", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs / HBM_PEAK_GBS, "traffic": None, "kernel_ms": {"em_diag": k_ms},
+                "kernel_algorithmic_tflops": diag_flops(n_local, d, K) / (k_ms * 1e-3) / 1e12,
+                "iteration_algorithmic_tflops": it_tflops}
+    elif ms["em_fused_wide"] > 0:
+        k_ms = ms["em_fused_wide"]                              # E-step + statistics in one kernel: the whole iteration's flops
+        achieved = algorithmic_flops(n_local, d, K) / (k_ms * 1e-3) / 1e12
+        traffic, source = traffic_for("em_fused_wide", headline and job.world == 1)
+        roof = {"bound": "mfma", "kernel": "em_fused_wide", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": source,
+                "kernel_ms": {"em_fused_wide": k_ms}, "iteration_algorithmic_tflops": it_tflops}
+    elif ms["em_fused"] > 0 and ms["em_estep"] == 0:
+        # fused small-shape kernel: algorithmic traffic = X once + LSE once; it is bound by that or by its exp work
+        k_ms = ms["em_fused"]
+        gbs = n_local * (d + 1) * 8.0 / (k_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "em_fused", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs / HBM_PEAK_GBS, "traffic": None, "kernel_ms": {"em_fused": k_ms},
+                "iteration_algorithmic_tflops": it_tflops}
+    else:
+        e_ms, m_ms = ms["em_estep"], ms["em_mstats"]
+        dom_name, dom_ms, dom_flops = ("em_estep", e_ms, estep_flops(n_local, d, K)) if e_ms >= m_ms else \
+                                      ("em_mstats", m_ms, mstats_flops(n_local, d, K))
+        achieved = dom_flops / (dom_ms * 1e-3) / 1e12
+        traffic, source = traffic_for(dom_name, headline and job.world == 1)
+        roof = {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": source,
+                "kernel_ms": {"em_estep": e_ms, "em_mstats": m_ms}, "iteration_algorithmic_tflops": it_tflops}
+    kind = "diagonal covariance (extension; the reference is full-covariance only)" if diagonal else "full covariance"
+    out = {
+        "metric": f"GMM-EM iterations/sec at N={n} d={d} K={K} ({kind}, fp64)" if not headline
+                  else "GMM-EM iterations/sec at N=10M d=32 K=64 (full covariance, fp64)",
+        "value": steps / elapsed, "unit": "iterations/s", "n_gpus": job.world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"GMM-EM N={n} d={d} K={K} {kind}, row-sharded over {job.world} GPU(s)",
+                   "N": n, "d": d, "K": K, "parallelism": f"dp{job.world}", "final_mean_log_likelihood": state["ll"]},
+        "rccl_ranks": job.rccl_ranks, "allreduce": job.allreduce, "n_local": n_locals,
+        "roofline": roof,
+    }
+    data.close()
+    if with_cpu:
+        sec, n_cpu = cpu_baseline(mix, d, K, cpu_samples, CPU_ITERATIONS, diagonal)
+        out["cpu_baseline"] = {"value": 1.0 / (sec * n / n_cpu), "unit": "iterations/s", "cores": 1, "kind": "port",
+                               "sample": f"{CPU_ITERATIONS} EM iterations of the single-threaded CPU restatement (oracle/) on "
+                                         f"{n_cpu} samples (d={d}, K={K}), time per iteration scaled x{n / n_cpu:g} to N={n} "
+                                         f"(cost is linear in N, ML/EM.cpp:205,245)",
+                               "seconds_per_iteration_on_sample": sec}
+        if not diagonal:
+            psec, pn, threads = cpu_baseline_all_cores(mix, d, K, max(1000, cpu_samples // 4), 1)
+            out["cpu_baseline_all_cores"] = {
+                "value": 1.0 / (psec * n / pn), "unit": "iterations/s", "cores": threads, "kind": "port",
+                "sample": f"1 EM iteration, row-parallel: {threads} threads x {pn // threads} samples each "
+                          f"(one oracle instance per thread), time scaled x{n / pn:g} to N={n}; the reference is "
+                          f"single-threaded, this is the all-cores bound for it",
+                "seconds_per_iteration_on_sample": psec}
+    return out
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` as a bare command: one fresh process per GPU through torch.distributed.run, started
+    before this process has imported torch or opened a HIP context (a process that has touched the GPU is never
+    re-executed). Rank 0 of the children prints the JSON line on the inherited stdout; their exit status is ours."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # this pool's driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // args.gpus)))
+    print(f"[bench] starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_launch(rank, world):
+    """--dry-launch: proves the launch plumbing without a GPU -- every rank joins a gloo group and reports what it was
+    given; rank 0 prints the one JSON line."""
+    import torch.distributed as dist
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)                                   # gloo reports its connections on the C-level stdout
+    try:
+        dist.init_process_group("gloo")
+        if os.environ.get("BENCH_DRY_FAIL_RANK") == str(rank):      # (test) a rank that dies must fail the whole command
+            raise SystemExit(3)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+    box = [None] * world
+    dist.all_gather_object(box, {"rank": rank, "world_size_env": int(os.environ["WORLD_SIZE"]), "pid": os.getpid(),
+                                 "local_rank": int(os.environ.get("LOCAL_RANK", "0"))})
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "group_size": dist.get_world_size(), "ranks": box}))
+    dist.destroy_process_group()
+    return 0
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=("em", "kmeans"), default="em")
+    ap.add_argument("--workload", choices=("em", "kmeans", "em-diag"), default="em")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
@@ -203,27 +428,35 @@ def main():
     ap.add_argument("--dim", type=int, default=None)
     ap.add_argument("--components", type=int, default=None, help="mixture components / clusters")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the K-means `secondary` object of the N=1 EM line")
     ap.add_argument("--cpu-samples", type=int, default=200_000)
+    ap.add_argument("--allreduce", choices=("native", "torch"), default="native",
+                    help="native: ncclAllReduce on the library's own RCCL communicator; torch: torch.distributed hook")
     ap.add_argument("--force-hook", action="store_true",
-                    help="(diagnostic) single rank, but with the torch.distributed/RCCL all-reduce hook installed")
+                    help="(diagnostic) single rank, but with the RCCL all-reduce installed (1-rank communicator)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="(test) start the ranks, join a gloo group, report the launch environment; no GPU work")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if args.dry_launch:
+        return dry_launch(rank, world)
 
     import torch
     import torch.distributed as dist
-    from ml_amd import _lib, synth
-    from ml_amd import dist as mldist
 
     torch.cuda.set_device(local_rank)
     # RCCL prints a version banner on the C-level stdout when its first communicator comes up; stdout is reserved for
-    # the one JSON line, so fd 1 points at stderr until the communicator exists.
+    # the one JSON line, so fd 1 points at stderr until the communicators exist.
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
@@ -231,137 +464,43 @@ def main():
         if world > 1:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         elif args.force_hook:
-            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29544", rank=0, world_size=1,
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1,
                                     device_id=torch.device("cuda", local_rank))
         if world > 1 or args.force_hook:
             warm = torch.zeros(1, dtype=torch.float64, device="cuda")
-            dist.all_reduce(warm)                      # creates the communicator (and its banner) now
+            dist.all_reduce(warm)                      # creates torch's communicator (and its banner) now
             torch.cuda.synchronize()
+        job = Job(args, rank, local_rank, world, dist, torch)
     finally:
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
 
+    with_cpu = world == 1 and not args.no_cpu_baseline
     if args.workload == "kmeans":
-        kmeans_workload(args, rank, local_rank, world, dist, torch)
-        if world > 1 or args.force_hook:
-            dist.destroy_process_group()
-        return
-
-    n = args.n if args.n is not None else N_TOTAL
-    d = args.dim if args.dim is not None else DIM
-    K = args.components if args.components is not None else COMPONENTS
-    lo, hi = mldist.shard_bounds(n, world, rank)
-    mix = synth.Mixture(d, K)
-    X = sample_rows(mix, lo, hi)             # the same N rows whatever the number of ranks
-
-    ctx = _lib.Context(local_rank)
-    if world > 1 or args.force_hook:
-        mldist.install_allreduce(ctx, world, rank)
-    data = _lib.Data(ctx, X)
-    del X
-
-    # Start exactly like EM::fit without maximise_first (ML/EM.cpp:127-135): given means, shared sample covariance.
-    _, cov = data.sample_covariance()
-    pi = np.full(K, 1.0 / K)
-    mu = mix.initial_means()
-    S = np.stack([cov] * K)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        ctx.synchronize()
-        torch.cuda.synchronize()
-
-    ll = None
-    for _ in range(args.warmup):
-        ll, pi, mu, S = data.em_step(pi, mu, S)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ll, pi, mu, S = data.em_step(pi, mu, S)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # Per-kernel device time (HIP events on the kernels' own stream), measured in a separate pass so that the
-    # event synchronisation does not perturb the timed region above.
-    ctx.timing_enable(True)
-    ctx.timing_reset()
-    for _ in range(3):
-        ll, pi, mu, S = data.em_step(pi, mu, S)
-    e_ms, _ = ctx.timing_get("em_estep")
-    m_ms, _ = ctx.timing_get("em_mstats")
-    f_ms, _ = ctx.timing_get("em_fused")     # small shapes (d <= 8): E-step + statistics in one kernel, X read once
-    ctx.timing_enable(False)
-
+        out = kmeans_measure(job, args.n or 100_000_000, args.dim or 8, args.components or 256, args.steps, args.warmup,
+                             with_cpu, args.cpu_samples)
+    elif args.workload == "em-diag":
+        out = em_measure(job, args.n or 1_000_000, args.dim or 16, args.components or 16, args.steps, args.warmup,
+                         with_cpu, args.cpu_samples, diagonal=True)
+    else:
+        out = em_measure(job, args.n or N_TOTAL, args.dim or DIM, args.components or COMPONENTS, args.steps, args.warmup,
+                         with_cpu, args.cpu_samples)
+        default_shape = (args.n, args.dim, args.components) == (None, None, None)
+        if world == 1 and default_shape and not args.no_secondary:
+            # BASELINE.json configs[4] (K-means N=100M, d=8, K=256 on 8 GPUs) at ONE GPU's share of it, in the same
+            # driver-timed run: the EM block has been freed above.
+            sec = kmeans_measure(job, 12_500_000, 8, 256, args.steps, args.warmup, with_cpu, args.cpu_samples)
+            if out is not None and sec is not None:
+                sec["config"]["workload"] += " = one GPU's row shard of BASELINE.json configs[4] (N=100M on 8 GPUs)"
+                out["secondary"] = sec
     if rank == 0:
-        n_local = hi - lo
-        dom_name, dom_ms, dom_flops = ("em_estep", e_ms, estep_flops(n_local, d, K)) if e_ms >= m_ms else \
-                                      ("em_mstats", m_ms, mstats_flops(n_local, d, K))
-        roof = None
-        if f_ms > 0 and e_ms == 0:
-            # fused small-shape kernel: algorithmic traffic = X once + LSE once; it is bound by that or by its exp work
-            gbs = n_local * (d + 1) * 8.0 / (f_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "em_fused", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": gbs / HBM_PEAK_GBS, "traffic": None, "kernel_ms": {"em_fused": f_ms},
-                    "iteration_algorithmic_tflops": algorithmic_flops(n_local, d, K) / (elapsed / args.steps) / 1e12}
-            dom_name, dom_ms = "em_fused", f_ms
-        achieved = dom_flops / (dom_ms * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        headline = (n, d, K) == (10_000_000, 32, 64) and world == 1     # the shape the PMC passes were collected on
-        if os.path.exists(tpath) and headline:
-            try:
-                traffic = json.load(open(tpath)).get(dom_name)
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "GMM-EM iterations/sec at N=10M d=32 K=64 (full covariance, fp64)" if (n, d, K) == (10_000_000, 32, 64)
-                      else f"GMM-EM iterations/sec at N={n} d={d} K={K} (full covariance, fp64; diagnostic shape)",
-            "value": args.steps / elapsed,
-            "unit": "iterations/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": f"GMM-EM N={n} d={d} K={K} full covariance, row-sharded over {world} GPU(s)",
-                       "N": n, "d": d, "K": K, "parallelism": f"dp{world}",
-                       "final_mean_log_likelihood": ll},
-            "roofline": roof or {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
-                                 "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
-                                 "kernel_ms": {"em_estep": e_ms, "em_mstats": m_ms},
-                                 "iteration_algorithmic_tflops": algorithmic_flops(n_local, d, K) / (elapsed / args.steps) / 1e12},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            iters = 1
-            sec, n_cpu = cpu_baseline(mix, d, K, args.cpu_samples, iters)
-            out["cpu_baseline"] = {"value": 1.0 / (sec * n / n_cpu), "unit": "iterations/s", "cores": 1, "kind": "port",
-                                   "sample": f"{iters} EM iteration(s) of the single-threaded CPU restatement (oracle/) on "
-                                             f"{n_cpu} samples (d={d}, K={K}), time scaled x{n / n_cpu:g} to N={n} "
-                                             f"(cost is linear in N, ML/EM.cpp:205,245)",
-                                   "seconds_per_iteration_on_sample": sec}
-            psec, pn, threads = cpu_baseline_all_cores(mix, d, K, max(1000, args.cpu_samples // 2), iters)
-            out["cpu_baseline_all_cores"] = {
-                "value": 1.0 / (psec * n / pn), "unit": "iterations/s", "cores": threads, "kind": "port",
-                "sample": f"{iters} EM iteration(s), row-parallel: {threads} threads x {pn // threads} samples each "
-                          f"(one oracle instance per thread), time scaled x{n / pn:g} to N={n}; the reference is "
-                          f"single-threaded, this is the all-cores bound for it",
-                "seconds_per_iteration_on_sample": psec}
         print(json.dumps(out))
-    data.close()
-    ctx.close()
+    job.close()
     if world > 1 or args.force_hook:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

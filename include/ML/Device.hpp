@@ -10,6 +10,9 @@ namespace device {
 /** Process-wide context used by the facade, created on first use (device: MLHIP_DEVICE, else LOCAL_RANK, else 0).
 @throw std::runtime_error If no HIP device is usable -- there is no CPU fallback. */
 DLL_DECLSPEC mlhip_ctx* context();
+/** The context the facade would use right now, WITHOUT creating one: the override, else the default if it already
+exists, else nullptr. Lets `fit` see a multi-rank (row-sharded) context before deciding anything from the local shard size. */
+DLL_DECLSPEC mlhip_ctx* peek_context();
 /** Replaces the process-wide context (not owned); nullptr restores the lazily created default. */
 DLL_DECLSPEC void set_context(mlhip_ctx* ctx);
 /** Throws the C++ exception matching a failed C-ABI call (std::invalid_argument / std::domain_error / std::runtime_error). */

@@ -61,7 +61,8 @@ private:
     bool verbose_;
     bool converged_;
 
-    bool fit_once(ConstMatrixRef data, mlhip_data* device_data);
+    /// exact_fit: the WHOLE sample has exactly K rows (one cluster per sample, ML/KMeans.cpp:67-75).
+    bool fit_once(ConstMatrixRef data, mlhip_data* device_data, bool exact_fit);
     void fetch_assignment(mlhip_data* device_data, std::size_t sample_size);
     void sequential_inertia(mlhip_data* device_data, std::size_t sample_size);
 };

@@ -61,6 +61,22 @@ typedef int (*mlhip_allreduce_fn)(void* user, double* buf, size_t count, int on_
 int mlhip_ctx_set_allreduce(mlhip_ctx* ctx, mlhip_allreduce_fn fn, void* user, int on_device,
                             int world_size, int rank);
 
+/* Native RCCL (no Python, no hook to write): the library opens its own communicator on the context's GPU and sums the
+ * statistics with ncclAllReduce(ncclDouble, ncclSum) on the context's stream -- what a multi-GPU ml::EM::fit /
+ * ml::Clustering::KMeans::fit (ML/EM.hpp:82, ML/KMeans.hpp:36) uses from C++. One process per GPU:
+ *   rank 0:   mlhip_rccl_unique_id(id);  ...hand the 128 bytes to the other ranks (file, pipe, MPI_Bcast, a store)...
+ *   all:      mlhip_ctx_init_rccl(ctx, id, world_size, rank);        (collective: returns when all ranks have joined)
+ * mlhip_ctx_init_rccl_file does the hand-over through a file that all ranks can see (rank 0 writes it atomically,
+ * the others wait for it up to MLHIP_RCCL_TIMEOUT_S seconds, default 120); use a fresh path per job.
+ * librccl.so.1 is loaded on first use (override: MLHIP_RCCL_LIBRARY). RCCL refuses two ranks on the same GPU. */
+#define MLHIP_RCCL_UNIQUE_ID_BYTES 128
+int mlhip_rccl_unique_id(void* unique_id /* MLHIP_RCCL_UNIQUE_ID_BYTES bytes */);
+int mlhip_ctx_init_rccl(mlhip_ctx* ctx, const void* unique_id, int world_size, int rank);
+int mlhip_ctx_init_rccl_file(mlhip_ctx* ctx, const char* path, int world_size, int rank);
+/* Number of ranks of the context's own RCCL communicator as RCCL reports it (ncclCommCount); 0 without one. */
+int mlhip_ctx_rccl_ranks(const mlhip_ctx* ctx, int* nranks);
+int mlhip_ctx_finalize_rccl(mlhip_ctx* ctx);
+
 /* In-place sum of `count` host doubles across ranks through the installed hook (no-op without one). The facade
  * uses it to agree on initial parameters (rank 0 contributes them, the others contribute zeros). */
 int mlhip_ctx_allreduce(mlhip_ctx* ctx, double* buf, size_t count);

@@ -79,6 +79,16 @@ def u32ptr(a):
     return a.ctypes.data_as(c_u32p)
 
 
+RCCL_UNIQUE_ID_BYTES = 128
+
+
+def rccl_unique_id():
+    """128 opaque bytes from ncclGetUniqueId (rank 0 calls this and hands them to every rank: Context.init_rccl)."""
+    buf = C.create_string_buffer(RCCL_UNIQUE_ID_BYTES)
+    check(lib.mlhip_rccl_unique_id(buf))
+    return buf.raw
+
+
 def device_count():
     n = C.c_int()
     check(lib.mlhip_device_count(C.byref(n)))
@@ -153,6 +163,33 @@ class Context:
 
         self._hook = ALLREDUCE_FN(trampoline)
         check(lib.mlhip_ctx_set_allreduce(self._h, self._hook, None, int(on_device), int(world_size), int(rank)))
+
+    def init_rccl(self, unique_id, world_size, rank):
+        """The library's own RCCL communicator (collective call): statistics are summed by ncclAllReduce on the context's
+        stream, no Python in the iteration."""
+        if len(unique_id) != RCCL_UNIQUE_ID_BYTES:
+            raise ValueError("unique_id must be the 128 bytes of rccl_unique_id()")
+        self._hook = None
+        check(lib.mlhip_ctx_init_rccl(self._h, C.c_char_p(bytes(unique_id)), int(world_size), int(rank)))
+
+    def init_rccl_file(self, path, world_size, rank):
+        check(lib.mlhip_ctx_init_rccl_file(self._h, os.fsencode(path), int(world_size), int(rank)))
+
+    @property
+    def rccl_ranks(self):
+        """Ranks of the library-owned communicator as RCCL counts them (0: none)."""
+        n = C.c_int()
+        check(lib.mlhip_ctx_rccl_ranks(self._h, C.byref(n)))
+        return n.value
+
+    def finalize_rccl(self):
+        check(lib.mlhip_ctx_finalize_rccl(self._h))
+
+    @property
+    def world(self):
+        w, r = C.c_int(), C.c_int()
+        check(lib.mlhip_ctx_world(self._h, C.byref(w), C.byref(r)))
+        return w.value, r.value
 
     def timing_enable(self, on=True):
         check(lib.mlhip_timing_enable(self._h, int(on)))

@@ -29,8 +29,10 @@ struct EstepArgs {
 };
 /// Returns the grid size used (= number of ll partials written), or <0 if D is not instantiated.
 int launch_em_estep(const EstepArgs& a, hipStream_t stream);
-/// Matrix-core variant (em_estep_mfma.hip); params use the estep_mfma_param_stride(D) record layout.
+#ifdef MLHIP_EXPERIMENTS
+/// 16x16x4 block-triangular variant (experiments/em_estep_mfma16.hip); params use the estep_mfma_param_stride(D) layout.
 int launch_em_estep_mfma(const EstepArgs& a, int num_cus, hipStream_t stream);
+#endif
 /// 4x4-block triangular variant (em_estep_mfma4.hip); params use the estep_mfma4_param_stride(D) record layout.
 int launch_em_estep_mfma4(const EstepArgs& a, int num_cus, hipStream_t stream);
 

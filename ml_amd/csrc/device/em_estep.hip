@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void em_estep_kernel(const double* __restrict_
 template <int D>
 int launch_t(const EstepArgs& a, hipStream_t stream)
 {
-    const uint32_t n_pad = (a.n + kSampleTile - 1) / kSampleTile * kSampleTile;
+    const uint32_t n_pad = padded_samples(a.n);
     const uint32_t blocks_needed = n_pad / 256;
     const int grid = (int)(blocks_needed < (uint32_t)a.n_ll_partials ? blocks_needed : (uint32_t)a.n_ll_partials);
     hipLaunchKernelGGL(em_estep_kernel<D>, dim3(grid), dim3(256), 0, stream, a.xt, a.ldx, a.n, n_pad, a.params, a.K,

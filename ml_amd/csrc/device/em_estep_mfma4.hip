@@ -214,7 +214,7 @@ int launch_sb(const EstepArgs& a, int num_cus, hipStream_t stream)
     constexpr int NT = 64 * NW, NWV = NW, GS = 16 * SB;
     constexpr int NLD = (Blocks<D>::PS + NT - 1) / NT;
     const size_t smem = sizeof(double) * 2 * NLD * NT;
-    const uint32_t n_pad = (a.n + kSampleTile - 1) / kSampleTile * kSampleTile;
+    const uint32_t n_pad = padded_samples(a.n);
     const uint32_t n_groups = n_pad / GS;
     uint32_t grid = (n_groups + NWV - 1) / NWV;
     const uint32_t cap = (uint32_t)num_cus * 2 * default_waves<SB>() / NW;   // the CU's resident waves, persistent

@@ -39,6 +39,9 @@ Plan make_plan(int d, int K, int num_cus);
 
 int launch_wide(const MstatsArgs& a, const Plan& p, int grid_x, hipStream_t stream);
 int launch_small(const MstatsArgs& a, const Plan& p, int grid_x, hipStream_t stream);
+#ifdef MLHIP_EXPERIMENTS
+int launch_narrow(const MstatsArgs& a, const Plan& p, int grid_x, hipStream_t stream);   // experiments/em_mstats_narrow.hip
+#endif
 
 }  // namespace mstats
 }  // namespace mlhip

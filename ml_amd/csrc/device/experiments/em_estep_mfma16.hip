@@ -19,7 +19,7 @@
 // After the chain, lane (g = lane>>4, s = lane&15) holds y[16J + g + 4r][s] in register r of block J; the squares are
 // summed per lane, across the 4 lane groups by two xor-shuffles, and lane (g, s) keeps the q of sample 16g + s, so the
 // log-domain epilogue (one exp per component) and the LW store are one sample per lane, fully coalesced.
-#include "device.hpp"
+#include "../device.hpp"
 
 namespace mlhip {
 namespace {
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void em_estep_mfma_kernel(const double* __r
 template <int D>
 int launch_t(const EstepArgs& a, int num_cus, hipStream_t stream)
 {
-    const uint32_t n_pad = (a.n + kSampleTile - 1) / kSampleTile * kSampleTile;
+    const uint32_t n_pad = padded_samples(a.n);
     const uint32_t n_groups = n_pad / 64;
     uint32_t grid = (n_groups + 3) / 4;
     const uint32_t cap = (uint32_t)num_cus * 2;          // 2 workgroups (8 waves) per CU, persistent

@@ -376,7 +376,7 @@ int launch_t(const KmeansArgs& a, int num_cus, size_t pstride, hipStream_t strea
     const bool use_lds = !chunked && table + accb <= 78 * 1024;
     // Accumulators that do not fit next to the centroid table: assignment only here, the sums by a separate sweep.
     const int accumulate_here = use_lds ? a.accumulate : 0;
-    const uint32_t n_pad = (a.n + kSampleTile - 1) / kSampleTile * kSampleTile;
+    const uint32_t n_pad = padded_samples(a.n);
     int grid = num_cus * 2;
     const uint32_t groups = n_pad / (D <= kMidDim ? 64 : 32);
     const uint32_t need = (groups + BSM / 64 - 1) / (BSM / 64);

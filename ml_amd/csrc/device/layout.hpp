@@ -7,6 +7,13 @@ namespace mlhip {
 
 // ---- layout constants shared by host and device code -------------------------------------------
 constexpr int kSampleTile = 256;  // N is padded to a multiple of this in HBM
+/// Samples allocated for a block of n: a whole number of tiles and at least one (an EMPTY shard of a row-sharded job still
+/// runs every kernel of the iteration on one all-padding tile, so that every rank launches the same sequence).
+inline uint32_t padded_samples(uint64_t n)
+{
+    const uint64_t p = (n + kSampleTile - 1) / kSampleTile * kSampleTile;
+    return (uint32_t)(p ? p : kSampleTile);
+}
 
 /// Largest dimension the kernels are instantiated for. Up to kRegDim every kernel variant exists (the headline shapes);
 /// above it only the 4x4-block matrix-core E-step, the wide statistics kernel and the matrix-core K-means kernel, with

@@ -100,6 +100,7 @@ double whitening_matrix(int d, const double* cov, std::vector<double>& L, std::v
 }
 }  // namespace
 
+#ifdef MLHIP_EXPERIMENTS
 void build_estep_params_mfma(int d, int D, int K, const double* mixing, const double* means, const double* covariances,
                              double* records)
 {
@@ -122,6 +123,8 @@ void build_estep_params_mfma(int d, int D, int K, const double* mixing, const do
         rec[NC * 64 + D] = std::log(mixing[k]) - log_det_half;
     }
 }
+
+#endif
 
 void build_estep_params_mfma4(int d, int D, int K, const double* mixing, const double* means, const double* covariances,
                               double* records)

@@ -33,6 +33,12 @@ mlhip_ctx* context()
     return g_default;
 }
 
+mlhip_ctx* peek_context()
+{
+    std::lock_guard<std::mutex> lock(g_mutex);
+    return g_override ? g_override : g_default;
+}
+
 void set_context(mlhip_ctx* ctx)
 {
     std::lock_guard<std::mutex> lock(g_mutex);

@@ -172,6 +172,15 @@ void kpp_sharded(const Shard& sh, ConstMatrixRef data, std::default_random_engin
 
 }  // namespace
 
+void locate_rows(mlhip_ctx* ctx, Index n_local, Index& first_row, Index& n_global)
+{
+    const Shard sh = locate_shard(ctx, n_local);
+    first_row = sh.lo;
+    n_global = sh.n_global;
+}
+
+void sum_across_ranks(mlhip_ctx* ctx, MatrixRef m) { allreduce_matrix(ctx, m); }
+
 void init_centroids(const CentroidsInitialiser& initialiser, ConstMatrixRef data, std::default_random_engine& prng,
                     const unsigned int number_components, MatrixRef centroids, mlhip_ctx* ctx, mlhip_data* device_data)
 {

@@ -20,6 +20,13 @@ namespace detail {
 void init_centroids(const CentroidsInitialiser& initialiser, ConstMatrixRef data, std::default_random_engine& prng,
                     unsigned int number_components, MatrixRef centroids, mlhip_ctx* ctx, mlhip_data* device_data);
 
+/// Row-sharded job: global index of this rank's first row and the global row count (rank-ordered shards; one short
+/// all-reduce). Single rank: 0 and n_local.
+void locate_rows(mlhip_ctx* ctx, Index n_local, Index& first_row, Index& n_global);
+
+/// Sums a d x K block across ranks in place (each rank contributes its own columns, zeros elsewhere).
+void sum_across_ranks(mlhip_ctx* ctx, MatrixRef m);
+
 }  // namespace detail
 }  // namespace Clustering
 }  // namespace ml

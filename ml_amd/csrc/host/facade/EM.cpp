@@ -133,16 +133,16 @@ bool EM::fit(ConstMatrixRef data)
     responsibilities_on_device_ = false;
     release_device_data();
 
-    // The exact fit (N == K) and the "not enough data" test are about the whole sample; with a row-sharded
-    // multi-rank context the local shard may legitimately be smaller than K.
+    // The exact fit (N == K) and the "not enough data" test are about the WHOLE sample: in a row-sharded multi-rank job
+    // (a hook or a communicator installed on the facade's context, which therefore exists already) the local shard may
+    // be smaller than K, even empty, and every rank must still take the same branch and join the same collectives.
     int world = 1, rank = 0;
-    mlhip_ctx* ctx = nullptr;
-    const bool trivially_local = sample_size <= K;
-    if (!trivially_local) {
-        ctx = device::context();
-        check(mlhip_ctx_world(ctx, &world, &rank));
+    mlhip_ctx* ctx = device::peek_context();
+    if (ctx) check(mlhip_ctx_world(ctx, &world, &rank));
+    if (world == 1) {
+        if (sample_size < K) throw std::invalid_argument("EM: Not enough data ");
+        if (sample_size > K) ctx = device::context();     // (N == K needs no device at all)
     }
-    if (world == 1 && sample_size < K) throw std::invalid_argument("EM: Not enough data ");
 
     means_.resize(number_dimensions, K);
     mixing_probabilities_.fill(1. / static_cast<double>(K));
@@ -167,7 +167,26 @@ bool EM::fit(ConstMatrixRef data)
     check(mlhip_data_upload(ctx, data.data(), number_dimensions, sample_size, data.outerStride(), &dev.h));
     uint64_t n_global = 0;
     check(mlhip_data_shape(dev.h, nullptr, nullptr, &n_global));
-    if (n_global < K) throw std::invalid_argument("EM: Not enough data ");
+    if (n_global < K) throw std::invalid_argument("EM: Not enough data ");       // the same on every rank
+    if (n_global == K) {
+        // The exact fit of a row-sharded sample: component (first_row + i) is this rank's sample i; the means are
+        // put together across ranks, everything else is local (ML/EM.cpp:108-118).
+        Index first_row = 0, total = 0;
+        Clustering::detail::locate_rows(ctx, sample_size, first_row, total);
+        responsibilities_.setZero(sample_size, K);
+        means_.setZero();
+        for (unsigned int i = 0; i < sample_size; ++i) {
+            const auto g = static_cast<unsigned int>(first_row) + i;
+            responsibilities_(i, g) = 1;
+            std::copy_n(data.col(i), number_dimensions, means_.col(g));
+            labels_[i] = g;
+        }
+        Clustering::detail::sum_across_ranks(ctx, means_);
+        for (unsigned int k = 0; k < K; ++k) covariances_[k].setZero(number_dimensions, number_dimensions);
+        log_likelihood_ = std::numeric_limits<double>::infinity();
+        converged_ = true;
+        return converged_;
+    }
 
     const std::size_t dd = static_cast<std::size_t>(number_dimensions) * number_dimensions;
     std::vector<double> cov_flat(dd * K);

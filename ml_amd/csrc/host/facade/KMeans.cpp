@@ -116,26 +116,35 @@ bool KMeans::fit(ConstMatrixRef data)
     const auto sample_size = static_cast<unsigned int>(data.cols());
     if (!number_dimensions) throw std::invalid_argument("KMeans: At least one dimension required");
 
+    // "Not enough data" and the exact fit are about the WHOLE sample: in a row-sharded multi-rank job (hook or
+    // communicator installed on the facade's context, which therefore exists already) a shard may hold fewer than K
+    // rows, or none, and every rank must still take the same branch and join the same collectives.
     DataGuard dev;
     int world = 1;
-    if (sample_size > num_clusters_) {
-        mlhip_ctx* ctx = device::context();
-        check(mlhip_ctx_world(ctx, &world, nullptr));
+    mlhip_ctx* ctx = device::peek_context();
+    if (ctx) check(mlhip_ctx_world(ctx, &world, nullptr));
+    uint64_t n_global = sample_size;
+    if (world == 1) {
+        if (sample_size < num_clusters_) throw std::invalid_argument("KMeans: Not enough data ");
+        if (sample_size > num_clusters_)      // (N == K needs no device at all)
+            check(mlhip_data_upload(device::context(), data.data(), number_dimensions, sample_size, data.outerStride(), &dev.h));
+    } else {
         check(mlhip_data_upload(ctx, data.data(), number_dimensions, sample_size, data.outerStride(), &dev.h));
-    } else if (sample_size < num_clusters_) {
-        throw std::invalid_argument("KMeans: Not enough data ");
+        check(mlhip_data_shape(dev.h, nullptr, nullptr, &n_global));
+        if (n_global < num_clusters_) throw std::invalid_argument("KMeans: Not enough data ");   // the same on every rank
     }
+    const bool exact_fit = n_global == num_clusters_;
 
-    if (num_inits_ == 1) {
-        const bool ok = fit_once(data, dev.h);
-        if (dev.h) fetch_assignment(dev.h, sample_size);
+    if (num_inits_ == 1 || exact_fit) {
+        const bool ok = fit_once(data, dev.h, exact_fit);
+        if (dev.h && !exact_fit) fetch_assignment(dev.h, sample_size);
         return ok;
     }
     converged_ = false;
     double min_inertia = std::numeric_limits<double>::infinity();
     MatrixXd best_centroids;
     for (unsigned int i = 0; i < num_inits_; ++i) {
-        if (fit_once(data, dev.h)) {
+        if (fit_once(data, dev.h, false)) {
             if (inertia_ < min_inertia) {
                 min_inertia = inertia_;
                 best_centroids = centroids_;
@@ -154,7 +163,7 @@ bool KMeans::fit(ConstMatrixRef data)
     return converged_;
 }
 
-bool KMeans::fit_once(ConstMatrixRef data, mlhip_data* device_data)
+bool KMeans::fit_once(ConstMatrixRef data, mlhip_data* device_data, const bool exact_fit)
 {
     converged_ = false;
     steps_done_ = 0;
@@ -166,12 +175,21 @@ bool KMeans::fit_once(ConstMatrixRef data, mlhip_data* device_data)
     old_centroids_.resize(number_dimensions, K);
     labels_.resize(sample_size);
 
-    if (sample_size == K) {
-        // Exact fit: every sample is its own cluster (ML/KMeans.cpp:67-75). Host only.
+    if (exact_fit) {
+        // Exact fit: every sample is its own cluster (ML/KMeans.cpp:67-75). Host only; in a row-sharded job cluster
+        // (first_row + i) is this rank's sample i and the centroid block is put together across ranks.
+        Index first_row = 0, total = sample_size;
+        mlhip_ctx* shared = device::peek_context();
+        int ranks = 1;
+        if (shared) check(mlhip_ctx_world(shared, &ranks, nullptr));
+        if (ranks > 1) detail::locate_rows(shared, sample_size, first_row, total);
+        centroids_.setZero();
         for (unsigned int i = 0; i < sample_size; ++i) {
-            std::copy_n(data.col(i), number_dimensions, centroids_.col(i));
-            labels_[i] = i;
+            const auto g = static_cast<unsigned int>(first_row) + i;
+            std::copy_n(data.col(i), number_dimensions, centroids_.col(g));
+            labels_[i] = g;
         }
+        if (ranks > 1) detail::sum_across_ranks(shared, centroids_);
         inertia_ = 0;
         converged_ = true;
         return converged_;

@@ -5,6 +5,10 @@
 #include "mlhip.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types only: the library is dlopen'ed on first use (librccl is 570 MB; single-GPU users never pay for it)
+
+#include <dlfcn.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -80,6 +84,54 @@ struct Timer {
     uint64_t launches = 0;
 };
 
+/// RCCL entry points, resolved from librccl.so.1 the first time a communicator is asked for. A process that already
+/// holds an RCCL (e.g. the copy bundled with PyTorch-ROCm, same soname) gets that one back from dlopen.
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+
+    static Rccl& get()
+    {
+        static Rccl r = [] {
+            Rccl x;
+            const char* env = std::getenv("MLHIP_RCCL_LIBRARY");
+            const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+            for (const char* n : names) {
+                if (!n || !*n) continue;
+                x.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+                if (x.handle) break;
+            }
+            if (!x.handle) return x;
+            auto sym = [&](const char* name) { return dlsym(x.handle, name); };
+            x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(sym("ncclGetUniqueId"));
+            x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(sym("ncclCommInitRank"));
+            x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
+            x.CommCount = reinterpret_cast<decltype(x.CommCount)>(sym("ncclCommCount"));
+            x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(sym("ncclAllReduce"));
+            x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
+            x.GetVersion = reinterpret_cast<decltype(x.GetVersion)>(sym("ncclGetVersion"));
+            if (!(x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.CommCount && x.AllReduce && x.GetErrorString)) {
+                dlclose(x.handle);
+                x.handle = nullptr;
+            }
+            return x;
+        }();
+        if (!r.handle)
+            throw std::runtime_error("RCCL is not available: librccl.so.1 could not be loaded (set MLHIP_RCCL_LIBRARY)");
+        return r;
+    }
+    void check(ncclResult_t rc, const char* what) const
+    {
+        if (rc != ncclSuccess) throw std::runtime_error(std::string("RCCL error in ") + what + ": " + GetErrorString(rc));
+    }
+};
+
 }  // namespace
 
 struct mlhip_ctx {
@@ -90,6 +142,7 @@ struct mlhip_ctx {
     mlhip_allreduce_fn reduce_fn = nullptr;
     void* reduce_user = nullptr;
     int reduce_on_device = 0, world_size = 1, rank = 0;
+    ncclComm_t comm = nullptr;   // library-owned RCCL communicator (mlhip_ctx_init_rccl); its all-reduce is the hook then
     // scratch
     DevBuf small_dev;        // for all-reducing short host vectors through a device hook
     PinnedBuf small_host;
@@ -258,7 +311,7 @@ mlhip_data* upload_common(mlhip_ctx* ctx, const double* x, bool on_device, uint3
         dt->d = (int)d;
         dt->D = D;
         dt->n = (uint32_t)n;
-        dt->n_pad = (uint32_t)((n + kSampleTile - 1) / kSampleTile * kSampleTile);
+        dt->n_pad = padded_samples(n);
         if (dt->n_pad == 0) dt->n_pad = kSampleTile;
         dt->ldx = dt->n_pad;
         dt->xt.reserve(sizeof(double) * dt->ldx * D);
@@ -358,7 +411,9 @@ void ensure_em_workspace(mlhip_data* dt, int K)
     dt->lse.reserve(sizeof(double) * dt->n_pad);
     dt->ll_partials.reserve(sizeof(double) * kMaxLlPartials);
     size_t ps = (size_t)estep_param_stride(dt->D) * K * sizeof(double);
+#ifdef MLHIP_EXPERIMENTS
     if (estep_mfma_supported(dt->D)) ps = std::max(ps, (size_t)estep_mfma_param_stride(dt->D) * K * sizeof(double));
+#endif
     if (estep_mfma4_supported(dt->D)) ps = std::max(ps, (size_t)estep_mfma4_param_stride(dt->D) * K * sizeof(double));
     dt->params_dev.reserve(ps);
     dt->params_host.reserve(ps);
@@ -374,23 +429,28 @@ void prepare_estep(mlhip_data* dt, int K, const double* mixing, const double* me
 {
     mlhip_ctx* ctx = dt->ctx;
     ensure_em_workspace(dt, K);
-    // d in 12..128: 4x4-block triangular matrix-core kernel (mfma4). For d <= 32, MLHIP_ESTEP=mfma16 selects the 16x16x4
-    // block-triangular one and MLHIP_ESTEP=valu the scalar-fed VALU kernel (the only one below d = 12), for A/B runs.
-    bool use_mfma = estep_mfma_supported(dt->D), use_mfma4 = estep_mfma4_supported(dt->D);
+    // d in 12..128: 4x4-block triangular matrix-core kernel (mfma4). For d <= 32, MLHIP_ESTEP=valu selects the scalar-fed
+    // VALU kernel (the only one below d = 12) and, in a `make EXPERIMENTS=1` build, MLHIP_ESTEP=mfma16 the 16x16x4
+    // block-triangular one, for A/B runs.
+    bool use_mfma = false, use_mfma4 = estep_mfma4_supported(dt->D);
     if (dt->D <= kRegDim) {
         if (const char* e = std::getenv("MLHIP_ESTEP")) {
-            if (std::strcmp(e, "valu") == 0) use_mfma = use_mfma4 = false;
-            if (std::strcmp(e, "mfma16") == 0) use_mfma4 = false;
+            if (std::strcmp(e, "valu") == 0) use_mfma4 = false;
+#ifdef MLHIP_EXPERIMENTS
+            if (std::strcmp(e, "mfma16") == 0 && estep_mfma_supported(dt->D)) { use_mfma4 = false; use_mfma = true; }
+#endif
         }
     }
     if (use_mfma4) {
         host::build_estep_params_mfma4(dt->d, dt->D, K, mixing, means, covs, dt->params_host.as<double>());
         HIP_CHECK(hipMemcpyAsync(dt->params_dev.p, dt->params_host.p, sizeof(double) * estep_mfma4_param_stride(dt->D) * K,
                                  hipMemcpyHostToDevice, ctx->stream));
+#ifdef MLHIP_EXPERIMENTS
     } else if (use_mfma) {
         host::build_estep_params_mfma(dt->d, dt->D, K, mixing, means, covs, dt->params_host.as<double>());
         HIP_CHECK(hipMemcpyAsync(dt->params_dev.p, dt->params_host.p, sizeof(double) * estep_mfma_param_stride(dt->D) * K,
                                  hipMemcpyHostToDevice, ctx->stream));
+#endif
     } else {
         host::build_estep_params(dt->d, dt->D, K, mixing, means, covs, dt->params_host.as<double>());
         HIP_CHECK(hipMemcpyAsync(dt->params_dev.p, dt->params_host.p, sizeof(double) * estep_param_stride(dt->D) * K,
@@ -410,8 +470,11 @@ void launch_estep(mlhip_data* dt, int K)
     a.ll_partials = dt->ll_partials.as<double>(); a.n_ll_partials = kMaxLlPartials;
     int grid = 0;
     ctx->timed("em_estep", [&] {
-        grid = dt->estep_variant == 2 ? launch_em_estep_mfma4(a, ctx->num_cus, ctx->stream)
-             : dt->estep_variant == 1 ? launch_em_estep_mfma(a, ctx->num_cus, ctx->stream) : launch_em_estep(a, ctx->stream);
+        if (dt->estep_variant == 2) grid = launch_em_estep_mfma4(a, ctx->num_cus, ctx->stream);
+#ifdef MLHIP_EXPERIMENTS
+        else if (dt->estep_variant == 1) grid = launch_em_estep_mfma(a, ctx->num_cus, ctx->stream);
+#endif
+        else grid = launch_em_estep(a, ctx->stream);
     });
     if (grid < 0) throw Unsupported("E-step kernel not instantiated for this dimension");
     HIP_CHECK(hipGetLastError());
@@ -701,6 +764,51 @@ void run_kmeans(mlhip_data* dt, int K, const double* centroids, bool accumulate)
     }
 }
 
+/// The all-reduce hook of a context that owns an RCCL communicator: one ncclAllReduce(double, sum), in place, on the
+/// context's stream -- ordered with the kernels before it and the copies after it, no host synchronisation.
+int rccl_allreduce_hook(void* user, double* buf, size_t count, int on_device, void* stream)
+{
+    auto* ctx = static_cast<mlhip_ctx*>(user);
+    if (!ctx || !ctx->comm || !on_device) return 1;
+    const Rccl& r = Rccl::get();
+    return r.AllReduce(buf, buf, count, ncclDouble, ncclSum, ctx->comm, static_cast<hipStream_t>(stream)) == ncclSuccess ? 0 : 1;
+}
+
+void drop_rccl(mlhip_ctx* ctx)
+{
+    if (!ctx->comm) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)Rccl::get().CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    if (ctx->reduce_fn == rccl_allreduce_hook) {
+        ctx->reduce_fn = nullptr; ctx->reduce_user = nullptr; ctx->reduce_on_device = 0; ctx->world_size = 1; ctx->rank = 0;
+    }
+}
+
+void init_rccl(mlhip_ctx* ctx, const ncclUniqueId& id, int world_size, int rank)
+{
+    require(world_size >= 1 && rank >= 0 && rank < world_size, "bad world_size / rank");
+    ctx->use();
+    const Rccl& r = Rccl::get();
+    drop_rccl(ctx);
+    // RCCL prints its version banner on the C-level stdout when NCCL_DEBUG=VERSION/INFO is set; nothing else is written.
+    r.check(r.CommInitRank(&ctx->comm, world_size, id, rank), "ncclCommInitRank");
+    int count = 0;
+    r.check(r.CommCount(ctx->comm, &count), "ncclCommCount");
+    if (count != world_size) throw std::runtime_error("RCCL communicator size does not match world_size");
+    ctx->reduce_fn = rccl_allreduce_hook;
+    ctx->reduce_user = ctx;
+    ctx->reduce_on_device = 1;
+    ctx->world_size = world_size;
+    ctx->rank = rank;
+    int local = world_size;
+    if (const char* e = std::getenv("LOCAL_WORLD_SIZE")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= world_size) local = v;
+    }
+    host::set_host_ranks(local);
+}
+
 }  // namespace
 
 extern "C" {
@@ -753,6 +861,7 @@ int mlhip_ctx_destroy(mlhip_ctx* ctx)
         if (!ctx) return;
         (void)hipSetDevice(ctx->device);
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->comm) drop_rccl(ctx);
         ctx->small_dev.release();
         ctx->small_host.release();
         for (int b = 0; b < 2; ++b) { ctx->up_stage[b].release(); ctx->up_pin[b].release(); }
@@ -781,6 +890,7 @@ int mlhip_ctx_set_allreduce(mlhip_ctx* ctx, mlhip_allreduce_fn fn, void* user, i
     return guarded([&] {
         require(ctx, "null context");
         require(world_size >= 1 && rank >= 0 && rank < world_size, "bad world_size / rank");
+        if (ctx->comm) drop_rccl(ctx);          // a caller-supplied hook replaces the library's own communicator
         ctx->reduce_fn = fn;
         ctx->reduce_user = user;
         ctx->reduce_on_device = on_device;
@@ -794,6 +904,75 @@ int mlhip_ctx_set_allreduce(mlhip_ctx* ctx, mlhip_allreduce_fn fn, void* user, i
         }
         host::set_host_ranks(local);
     });
+}
+
+int mlhip_rccl_unique_id(void* unique_id)
+{
+    return guarded([&] {
+        require(unique_id != nullptr, "null unique_id");
+        static_assert(sizeof(ncclUniqueId) == MLHIP_RCCL_UNIQUE_ID_BYTES, "unique id size");
+        const Rccl& r = Rccl::get();
+        ncclUniqueId id;
+        r.check(r.GetUniqueId(&id), "ncclGetUniqueId");
+        std::memcpy(unique_id, &id, sizeof id);
+    });
+}
+
+int mlhip_ctx_init_rccl(mlhip_ctx* ctx, const void* unique_id, int world_size, int rank)
+{
+    return guarded([&] {
+        require(ctx && unique_id, "null argument");
+        ncclUniqueId id;
+        std::memcpy(&id, unique_id, sizeof id);
+        init_rccl(ctx, id, world_size, rank);
+    });
+}
+
+int mlhip_ctx_init_rccl_file(mlhip_ctx* ctx, const char* path, int world_size, int rank)
+{
+    return guarded([&] {
+        require(ctx && path && *path, "null argument");
+        require(world_size >= 1 && rank >= 0 && rank < world_size, "bad world_size / rank");
+        ncclUniqueId id;
+        if (rank == 0) {
+            const Rccl& r = Rccl::get();
+            r.check(r.GetUniqueId(&id), "ncclGetUniqueId");
+            const std::string tmp = std::string(path) + ".tmp";     // written whole, then renamed: readers never see a part
+            FILE* f = std::fopen(tmp.c_str(), "wb");
+            if (!f || std::fwrite(&id, 1, sizeof id, f) != sizeof id || std::fclose(f) != 0 || std::rename(tmp.c_str(), path) != 0)
+                throw std::runtime_error(std::string("cannot write the RCCL rendezvous file ") + path);
+        } else {
+            const int limit_s = std::max(1, env_int("MLHIP_RCCL_TIMEOUT_S", 120));
+            const auto t0 = std::chrono::steady_clock::now();
+            for (;;) {
+                if (FILE* f = std::fopen(path, "rb")) {
+                    const size_t got = std::fread(&id, 1, sizeof id, f);
+                    std::fclose(f);
+                    if (got == sizeof id) break;
+                }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(limit_s))
+                    throw std::runtime_error(std::string("timed out waiting for the RCCL rendezvous file ") + path);
+                usleep(20000);
+            }
+        }
+        init_rccl(ctx, id, world_size, rank);
+    });
+}
+
+int mlhip_ctx_rccl_ranks(const mlhip_ctx* ctx, int* nranks)
+{
+    return guarded([&] {
+        require(ctx && nranks, "null argument");
+        *nranks = 0;
+        if (!ctx->comm) return;
+        const Rccl& r = Rccl::get();
+        r.check(r.CommCount(ctx->comm, nranks), "ncclCommCount");
+    });
+}
+
+int mlhip_ctx_finalize_rccl(mlhip_ctx* ctx)
+{
+    return guarded([&] { require(ctx, "null context"); ctx->use(); drop_rccl(ctx); });
 }
 
 int mlhip_ctx_allreduce(mlhip_ctx* ctx, double* buf, size_t count)

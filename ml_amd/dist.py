@@ -61,3 +61,14 @@ def install_allreduce(ctx, world_size, rank, on_device=None, group=None):
         on_device = dist.get_backend(group) == "nccl"
     ctx.set_allreduce(lambda ptr, count, dev, stream: allreduce_sum(ptr, count, dev, stream, group),
                       on_device, world_size, rank)
+
+
+def install_native_rccl(ctx, world_size, rank, group=None):
+    """The library's own RCCL communicator as the statistics all-reduce (mlhip_ctx_init_rccl): rank 0 draws the unique id,
+    torch.distributed (any backend) only carries its 128 bytes to the other ranks; the iterations never enter Python."""
+    import torch.distributed as dist
+    from . import _lib
+    box = [_lib.rccl_unique_id() if rank == 0 else None]
+    if world_size > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    ctx.init_rccl(box[0], world_size, rank)

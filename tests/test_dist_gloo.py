@@ -297,3 +297,112 @@ def test_facade_fit_row_sharded_over_two_ranks():
     assert abs(km.inertia - a["kmeans"][2]) <= 1e-13 * km.inertia
     assert np.max(np.abs(km.centroids - a["kmeans"][3])) <= 1e-13 * np.max(np.abs(km.centroids))
     assert np.array_equal(np.concatenate([a["kmeans"][4], b["kmeans"][4]]), np.asarray(km.labels_array))
+
+
+# ---- shards with <= K rows: decisions are taken from the GLOBAL sample size on every rank -----------------
+
+def _small_shard_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        import torch.distributed as dist
+        from ml_amd import cppyml
+        from ml_amd import dist as mldist
+        from ml_amd.cppyml import clustering as cl
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        mldist.install_allreduce(cppyml.device_context(), world, rank, on_device=False)
+        d, K = 3, 4
+        rng = np.random.default_rng(3)
+        centres = 8.0 * rng.standard_normal((K, d))
+        X = np.ascontiguousarray(centres[np.arange(60) % K] + 0.3 * rng.standard_normal((60, d)))
+        out = {}
+        # (a) uneven shards: rank 1 holds exactly K rows (it used to take the local "exact fit" shortcut), then fewer than
+        #     K, then none at all
+        for name, cut in (("k_rows", 60 - K), ("two_rows", 58), ("empty", 60)):
+            shard = np.ascontiguousarray(X[:cut] if rank == 0 else X[cut:])
+            em = cl.EM(K)
+            em.set_means_initialiser(cl.FixedCentroids(centres + 0.1))
+            em.set_maximum_steps(50)
+            conv = em.fit(shard)
+            km = cl.KMeans(K)
+            km.set_centroids_initialiser(cl.FixedCentroids(centres + 0.1))
+            kconv = km.fit(shard)
+            out[name] = (conv, em.steps_done, em.log_likelihood, em.means.copy(), np.asarray(em.labels),
+                         kconv, km.inertia, km.centroids.copy(), np.asarray(km.labels_array))
+        # (b) the whole sample has exactly K rows, 3 + 1 over the ranks: the exact fit, put together across ranks
+        shard = np.ascontiguousarray(X[:3] if rank == 0 else X[3:4])
+        em = cl.EM(K)
+        conv = em.fit(shard)
+        km = cl.KMeans(K)
+        kconv = km.fit(shard)
+        out["exact"] = (conv, em.log_likelihood, em.means.copy(), np.asarray(em.labels), em.responsibilities.copy(),
+                        kconv, km.inertia, km.centroids.copy(), np.asarray(km.labels_array))
+        # (c) fewer than K rows in total: every rank raises, nobody is left waiting in a collective
+        shard = np.ascontiguousarray(X[:2] if rank == 0 else X[2:3])
+        errors = []
+        for model in (cl.EM(K), cl.KMeans(K)):
+            try:
+                model.fit(shard)
+                errors.append(None)
+            except ValueError as e:
+                errors.append(str(e))
+        out["too_few"] = errors
+        q.put((rank, out))
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), str(e)))
+
+
+@pytest.mark.gpu
+def test_small_and_empty_shards_follow_the_global_sample_size():
+    import torch.multiprocessing as mp
+    from ml_amd.cppyml import clustering as cl
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = _free_port()
+    procs = [mpctx.Process(target=_small_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+            p.join()
+    for r in results:
+        assert r[1] != "error", r[2]
+    results.sort(key=lambda r: r[0])
+    a, b = results[0][1], results[1][1]
+
+    d, K = 3, 4
+    rng = np.random.default_rng(3)
+    centres = 8.0 * rng.standard_normal((K, d))
+    X = np.ascontiguousarray(centres[np.arange(60) % K] + 0.3 * rng.standard_normal((60, d)))
+    em = cl.EM(K)
+    em.set_means_initialiser(cl.FixedCentroids(centres + 0.1))
+    em.set_maximum_steps(50)
+    conv1 = em.fit(X)
+    km = cl.KMeans(K)
+    km.set_centroids_initialiser(cl.FixedCentroids(centres + 0.1))
+    kconv1 = km.fit(X)
+    for name in ("k_rows", "two_rows", "empty"):
+        ra, rb = a[name], b[name]
+        assert ra[0] == rb[0] == conv1 and ra[1] == rb[1] == em.steps_done, name
+        assert ra[2] == rb[2] and abs(ra[2] - em.log_likelihood) <= 1e-12 * abs(em.log_likelihood), name
+        assert np.array_equal(ra[3], rb[3]) and np.max(np.abs(ra[3] - em.means)) <= 1e-11 * np.max(np.abs(em.means)), name
+        assert np.array_equal(np.concatenate([ra[4], rb[4]]), np.asarray(em.labels)), name
+        assert ra[5] == rb[5] == kconv1 and abs(ra[6] - km.inertia) <= 1e-13 * km.inertia, name
+        assert np.array_equal(ra[7], rb[7]) and np.max(np.abs(ra[7] - km.centroids)) <= 1e-13 * np.max(np.abs(km.centroids)), name
+        assert np.array_equal(np.concatenate([ra[8], rb[8]]), np.asarray(km.labels_array)), name
+
+    ea, eb = a["exact"], b["exact"]
+    assert ea[0] and eb[0] and ea[1] == eb[1] == np.inf
+    assert np.array_equal(ea[2], eb[2]) and np.array_equal(ea[2], X[:4].T)          # means d x K = the samples themselves
+    assert list(ea[3]) == [0, 1, 2] and list(eb[3]) == [3]
+    assert np.array_equal(ea[4], np.eye(4)[:3]) and np.array_equal(eb[4], np.eye(4)[3:])
+    assert ea[5] and eb[5] and ea[6] == eb[6] == 0
+    assert np.array_equal(ea[7], eb[7]) and np.array_equal(ea[7], X[:4])             # centroids K x d
+    assert list(ea[8]) == [0, 1, 2] and list(eb[8]) == [3]
+
+    for errs in (a["too_few"], b["too_few"]):
+        assert all(e and "Not enough data" in e for e in errs), errs

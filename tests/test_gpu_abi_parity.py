@@ -235,8 +235,9 @@ def test_bad_arguments(ctx):
 
 @pytest.mark.parametrize("d,K", [(12, 7), (16, 16), (20, 5), (24, 9), (28, 3), (32, 64)])
 def test_estep_kernel_variants_agree(ctx, oracle, d, K, monkeypatch):
-    """The three E-step kernels that exist for d in 12..32 (4x4x4 MFMA = default, 16x16x4 MFMA, scalar-fed VALU) compute the
-    same log-likelihood / responsibilities / labels; the default one is also checked against the oracle."""
+    """The two E-step kernels of the default build that exist for d in 12..32 (4x4x4 MFMA = default, scalar-fed VALU) compute
+    the same log-likelihood / responsibilities / labels; the default one is also checked against the oracle. (The 16x16x4
+    variant is an experiment: `make EXPERIMENTS=1`.)"""
     rng = np.random.default_rng(d * 100 + K)
     n = 3000
     means = 2.5 * rng.standard_normal((K, d))
@@ -245,7 +246,7 @@ def test_estep_kernel_variants_agree(ctx, oracle, d, K, monkeypatch):
     S0 = np.stack([np.cov(X.T) * rng.uniform(0.2, 0.6) + 0.1 * np.eye(d) for _ in range(K)])
     pi0 = rng.dirichlet(np.ones(K) * 5)
     out = {}
-    for variant in ("", "mfma16", "valu"):
+    for variant in ("", "valu"):
         if variant:
             monkeypatch.setenv("MLHIP_ESTEP", variant)
         else:
@@ -261,7 +262,7 @@ def test_estep_kernel_variants_agree(ctx, oracle, d, K, monkeypatch):
     ll0, R0, lab0, m0 = out[""]
     assert abs(ll0 - em.log_likelihood) <= 1e-12 * abs(em.log_likelihood)
     assert np.max(np.abs(R0 - em.responsibilities)) < 1e-12
-    for variant in ("mfma16", "valu"):
+    for variant in ("valu",):
         ll, R, lab, m = out[variant]
         assert abs(ll - ll0) <= 1e-13 * abs(ll0)
         assert np.max(np.abs(R - R0)) < 1e-12
