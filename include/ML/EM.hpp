@@ -36,6 +36,13 @@ public:
     DLL_DECLSPEC void set_responsibilities_initialiser(std::shared_ptr<const Clustering::ResponsibilitiesInitialiser> responsibilities_initialiser);
     void set_verbose(bool verbose) { verbose_ = verbose; }
     void set_maximise_first(bool maximise_first) { maximise_first_ = maximise_first; }
+    /** EXTENSION -- not part of the reference API, whose EM is full-covariance only (reference ML/EM.hpp:175). With
+    `Diagonal` every covariance is restricted to its diagonal (the E-/M-step loops of ML/EM.cpp:190-263 on the diagonal
+    entries only; covariances() returns diagonal matrices). Default `Full` == the reference's behaviour.
+    Diagonal mode is built for number_dimensions <= 32 and number_components <= 64 (std::runtime_error otherwise). */
+    enum class CovarianceType { Full, Diagonal };
+    void set_covariance_type(CovarianceType covariance_type) { covariance_type_ = covariance_type; }
+    CovarianceType covariance_type() const { return covariance_type_; }
 
     /** @brief Fits the model. @param[in] data Column-major, a data point in every column (this rank's row shard when an
     all-reduce hook is installed on the device context). @return `true` if fitting converged.
@@ -88,6 +95,7 @@ private:
     bool verbose_;
     bool maximise_first_;
     bool converged_;
+    CovarianceType covariance_type_ = CovarianceType::Full;
     mlhip_data* device_data_ = nullptr;
 
     void process_covariances(Index number_dimensions);

@@ -108,6 +108,15 @@ int mlhip_em_step(mlhip_ctx* ctx, mlhip_data* data, uint32_t K,
                   const double* mixing, const double* means, const double* covariances,
                   double* log_likelihood, double* mixing_out, double* means_out, double* covariances_out);
 
+/* EXTENSION (no counterpart in the reference, whose ml::EM is full-covariance only, ML/EM.hpp:175; BASELINE.json configs[1]):
+ * one EM iteration with DIAGONAL covariances -- the loops of mlhip_em_step restricted to the diagonal, in one kernel
+ * (X read once, no N x K block in HBM). variances / variances_out: K*d doubles, variances[k*d + j] = sigma_kj^2 (ridge 1e-15
+ * included on output, ML/EM.cpp:252). 1 <= d <= 32, 1 <= K <= 64 (MLHIP_E_UNSUPPORTED otherwise). mlhip_em_responsibilities /
+ * mlhip_em_labels afterwards work as after mlhip_em_step (the block is rebuilt from the same parameters on demand). */
+int mlhip_em_step_diag(mlhip_ctx* ctx, mlhip_data* data, uint32_t K,
+                       const double* mixing, const double* means, const double* variances,
+                       double* log_likelihood, double* mixing_out, double* means_out, double* variances_out);
+
 /* E-step only (ML/EM.cpp:190-219): leaves log-responsibilities on the device, returns the log-likelihood. */
 int mlhip_em_expectation(mlhip_ctx* ctx, mlhip_data* data, uint32_t K,
                          const double* mixing, const double* means, const double* covariances,

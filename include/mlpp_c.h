@@ -46,6 +46,8 @@ int mlpp_em_set_means_initialiser(mlpp_em* h, const mlpp_centroids_initialiser* 
 int mlpp_em_set_responsibilities_initialiser(mlpp_em* h, const mlpp_responsibilities_initialiser* init);
 int mlpp_em_set_verbose(mlpp_em* h, int v);
 int mlpp_em_set_maximise_first(mlpp_em* h, int v);
+/* Extension (ml::EM::set_covariance_type): 0 = full covariances (the reference), 1 = diagonal. */
+int mlpp_em_set_covariance_type(mlpp_em* h, int diagonal);
 int mlpp_em_fit(mlpp_em* h, const double* data, uint64_t n, uint32_t d, int* converged);
 int mlpp_em_number_components(const mlpp_em* h, uint32_t* out);
 int mlpp_em_dims(const mlpp_em* h, uint32_t* d, uint64_t* n);

@@ -259,6 +259,25 @@ class Data:
                                 dptr(pi1), dptr(mu1), dptr(S1)))
         return ll.value, pi1, mu1, S1
 
+    def em_step_diag(self, mixing, means, variances):
+        """Diagonal-covariance extension. variances: K x d (a K x d x d stack of diagonal matrices is accepted too and
+        returned in the same form)."""
+        K = len(mixing)
+        mixing = np.ascontiguousarray(mixing, dtype=np.float64)
+        means = np.ascontiguousarray(means, dtype=np.float64)
+        v = np.asarray(variances, dtype=np.float64)
+        stacked = v.ndim == 3
+        if stacked:
+            v = np.stack([np.diag(m) for m in v])
+        v = np.ascontiguousarray(v)
+        ll = C.c_double()
+        pi1, mu1, v1 = np.empty(K), np.empty((K, self.d)), np.empty((K, self.d))
+        check(lib.mlhip_em_step_diag(self.ctx.handle, self._h, K, dptr(mixing), dptr(means), dptr(v), C.byref(ll),
+                                     dptr(pi1), dptr(mu1), dptr(v1)))
+        if stacked:
+            v1 = np.stack([np.diag(row) for row in v1])
+        return ll.value, pi1, mu1, v1
+
     def em_expectation(self, mixing, means, covs):
         K = len(mixing)
         mixing = np.ascontiguousarray(mixing, dtype=np.float64)

@@ -170,6 +170,13 @@ class EM:
         """Turns on/off doing an initial maximisation step before the E-M iterations."""
         _check(_l.mlpp_em_set_maximise_first(self._h, int(bool(maximise_first))))
 
+    def set_covariance_type(self, covariance_type):
+        """Extension (not in the reference surface): "full" (default, the reference's only mode) or "diag" -- every
+        covariance restricted to its diagonal; `covariance(k)` then returns a diagonal matrix. d <= 32, K <= 64."""
+        if covariance_type not in ("full", "diag"):
+            raise ValueError("covariance_type must be 'full' or 'diag'")
+        _check(_l.mlpp_em_set_covariance_type(self._h, int(covariance_type == "diag")))
+
     def fit(self, data):
         """Fits the components to the data (2D array with data points in rows). Returns True if EM converged."""
         data = _require_data(data)

@@ -62,6 +62,24 @@ int em_fused_partial_rows(int K);
 int em_fused_partial_cols(int d);
 int launch_em_fused_small(const FusedArgs& a, int num_cus, hipStream_t stream);
 }
+/// Diagonal-covariance EM iteration in one kernel (em_diag.hip): params are em_diag_partial_rows(K) records of
+/// diag_param_stride(padded_dim(d)) -- K real ones, then neutral padding (coef = -inf) -- and shift holds padded_dim(d)
+/// doubles (zeros beyond d).
+struct DiagArgs {
+    const double* xt; size_t ldx; uint32_t n; int d;
+    const double* shift; const double* params; int K;
+    double* lse;                                             // out: per-sample log-sum-exp
+    double* partials; size_t partials_capacity;              // scratch: [grid][KP][FP]
+    double* ll_partials; int n_ll_partials;                  // out: per-workgroup log-likelihood sums
+};
+namespace mstats {
+bool em_diag_supported(int d, int K);                        // d <= 32, K <= 64
+int em_diag_partial_rows(int K);
+int em_diag_partial_cols(int d);
+int em_diag_grid(int d, int K, uint32_t n, int num_cus);
+/// Returns the number of per-workgroup partial blocks written (stats and log-likelihood alike), or < 0.
+int launch_em_diag(const DiagArgs& a, int num_cus, hipStream_t stream);
+}
 /// Fixed-order combination of `n_partials` blocks [KP][FP] (and of the log-likelihood partials) into stats[K*F (+1)].
 void launch_em_reduce_blocks(const double* partials, int n_partials, int KP, int FP, int K, int F, const double* ll_partials,
                              int n_ll, double* stats, hipStream_t stream);

@@ -1,0 +1,329 @@
+// One EM iteration's device work for DIAGONAL covariances in ONE kernel (d <= 32, K <= 64): E-step + M-step statistics,
+// X read once, only the per-sample log-sum-exp written. EXTENSION: the reference's ml::EM is full-covariance only
+// (ML/EM.hpp:175); this is the same pair of loops -- EM::expectation_step (ML/EM.cpp:190-219) and the sums of
+// EM::maximisation_step (:229-250) -- with every covariance restricted to its diagonal, as BASELINE.json configs[1]
+// (N=1M, d=16, K=16) asks. Arithmetic per (sample, component):
+//     z_j = x_j - mu_kj ;  q = sum_j (z_j * iv_kj) * z_j  (ascending j; iv = 1/sigma^2) ;  lw = log pi_k - sum_j log sigma_kj - q/2
+// then per sample m = max_k lw, e_k = exp(lw_k - m), s = sum e_k, lse = m + log s, r_k = e_k / s, and per component
+//     S0 = sum_i r,  S1'_j = sum_i r x~_j,  S2'_j = sum_i r x~_j^2,   x~ = x - shift  (2d + 1 numbers instead of (d+1)(d+2)/2).
+//
+// Mapping (the structure of em_fused_small.hip): a wave owns a stream of 64-sample tiles, lane = sample while the
+// densities are evaluated (coordinates in VGPRs, component records [mu | iv | coef] staged once per workgroup in LDS and read
+// as broadcasts); r and x~ then go through the wave's private LDS tiles into ONE GEMM on the fp64 matrix cores,
+//     stats[K x 2d] += R^T[K x 64] * Phi[64 x 2d],   Phi_i = [x~_i ; x~_i^2],
+// whose B operand is generated in registers as a product of two LDS reads (x~_j * 1 or x~_j * x~_j); S0 is a per-lane
+// running sum folded once at the end. No atomics; per-workgroup partials are combined in fixed order by em_reduce_kernel.
+// Bound: ~3d VALU + one exp per (sample, component) against 8d bytes per sample -- VALU/latency-bound at d = K = 16, not HBM.
+#include "em_mstats_common.hpp"
+
+namespace mlhip {
+namespace mstats {
+namespace {
+
+typedef __attribute__((address_space(3))) const double lds_cdouble;
+constexpr int RSS = 17;                                      // LDS row stride of one 16-component responsibility block (odd)
+template <int D> constexpr int xsd() { return (D + 2) | 1; }  // LDS row stride of the sample tile: d coords + [1, 0], odd
+
+/// RBT = 16-component row blocks that exist (K <= 16 RBT), RBW = row blocks this workgroup accumulates (blockIdx.y picks the
+/// group; every group evaluates all K densities -- the normalisation needs them), CB = 16-column blocks of the 2d features,
+/// S = samples per lane: a wave's tile is 64 S samples. The density loop is bound by its LDS operand traffic (every
+/// (component, dimension) needs mu and 1/sigma^2 as per-lane broadcast reads: 64 x 16 bytes through the CU's one LDS pipe for
+/// 3 VALU operations), so two samples per lane halve it where the registers allow (measured at d = K = 16: 126 -> see DESIGN).
+template <int D, int RBT, int RBW, int CB, int S>
+__global__ __launch_bounds__(256, (D <= 16 && RBT <= 2) ? 2 : 1) void em_diag_kernel(
+    const double* __restrict__ xt, size_t ldx, uint32_t n, int d, const double* __restrict__ shift,
+    const double* __restrict__ params, int K, double* __restrict__ lse_out, double* __restrict__ partials, int KP, int FP,
+    double* __restrict__ ll_partials)
+{
+    constexpr int PS = 2 * D + 2;                             // diag_param_stride(D)
+    constexpr int KMAX = 16 * RBT;
+    constexpr int JC = D % 2 == 0 ? 2 : 1;                    // dimensions per operand batch of the density loop
+    constexpr int XSS = xsd<D>();
+    constexpr int TW = TS * S;                                // samples per wave tile
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double red[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double* Xw = smem + (size_t)wave * (TS * XSS + TS * RSS);
+    double* Rw = Xw + TS * XSS;
+    double* recs = smem + 4 * (TS * XSS + TS * RSS);          // [KMAX][PS]: records beyond K are neutral (coef = -inf)
+    constexpr int ONE = D, ZERO = D + 1;                      // LDS row: [x~_0 .. x~_(D-1) | 1 | 0]
+    const int rb0 = blockIdx.y * RBW;                         // first row block accumulated here
+    for (int e = tid; e < KMAX * PS; e += 256) recs[e] = params[e];
+    __syncthreads();
+
+    // feature f of the GEMM: f < d -> x~_f * 1 ; d <= f < 2d -> x~_(f-d)^2 ; beyond -> 0 * 0
+    int offa[CB], offb[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+        const int f = c * 16 + (lane & 15);
+        offa[c] = f < d ? f : (f < 2 * d ? f - d : ZERO);
+        offb[c] = f < d ? ONE : (f < 2 * d ? f - d : ZERO);
+    }
+
+    d4 acc[RBW][CB];
+    double s0[RBW];                                           // lane (g, c): partial S0 of component c of each row block
+#pragma unroll
+    for (int r = 0; r < RBW; ++r) {
+        s0[r] = 0.0;
+#pragma unroll
+        for (int c = 0; c < CB; ++c) acc[r][c] = d4{0.0, 0.0, 0.0, 0.0};
+    }
+
+    const uint32_t n_tiles = (n + TW - 1) / TW;
+    const uint32_t stride = gridDim.x * 4;
+    const double* xbase = Xw + 16 * (lane >> 4) * XSS;
+    const double* rbase = Rw + 16 * (lane >> 4) * RSS + (lane & 15);
+    double ll_acc = 0.0;
+
+    for (uint32_t tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += stride) {
+        // Loop-invariant values the compiler would otherwise keep in (spilled) SGPRs: K (the guards below become scalar
+        // compares) and the record base, which lives in ONE VGPR so that every operand read is `ds_read base offset:imm`
+        // (a constant LDS address per read gets materialised in an SGPR each: measured 279 SGPR spills at d = K = 16).
+        asm volatile("" ::: "memory");
+        int Kt = K;
+        asm volatile("" : "+s"(Kt));
+        lds_cdouble* recv = (lds_cdouble*)recs;
+        asm volatile("" : "+v"(recv));
+        const uint32_t i0 = tile * TW + lane;                 // sample of slot s: i0 + 64 s (< n_pad: n_pad is a multiple of 256)
+        double x[S][D];
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int j = 0; j < D; ++j) x[s][j] = xt[(size_t)j * ldx + i0 + TS * s];
+
+        // ---- 1. log-densities of all K components (statically unrolled; wave-uniform guards per group of 4)
+        double lwv[S][KMAX];
+        double m[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) m[s] = -__builtin_inf();
+#pragma unroll
+        for (int k4 = 0; k4 < KMAX; k4 += 4) {
+            if (k4 < Kt) {
+                // 4 components x JC dimensions per batch: the 2 * 4 * JC operands are read from LDS in one go, then consumed
+                // by all S samples of the lane. Every q accumulates in ascending j.
+                lds_cdouble* p = recv + k4 * PS;
+                double q[S][4];
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) q[s][u] = 0.0;
+#pragma unroll
+                for (int j0 = 0; j0 < D; j0 += JC) {
+                    double mu[4][JC], iv[4][JC];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int jj = 0; jj < JC; ++jj) {
+                            mu[u][jj] = p[u * PS + j0 + jj];
+                            iv[u][jj] = p[u * PS + D + j0 + jj];
+                        }
+#pragma unroll
+                    for (int jj = 0; jj < JC; ++jj)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int s = 0; s < S; ++s) {
+                                const double z = x[s][j0 + jj] - mu[u][jj];
+                                q[s][u] = __builtin_fma(z * iv[u][jj], z, q[s][u]);
+                            }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double coef = p[u * PS + 2 * D];                          // records k >= K: coef = -inf
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const double lw = __builtin_fma(-0.5, q[s][u], coef);
+                        lwv[s][k4 + u] = lw;
+                        m[s] = lw > m[s] ? lw : m[s];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) lwv[s][k4 + u] = -__builtin_inf();
+            }
+        }
+        // ---- 2. normalisation: one exp per (sample, component)
+        double inv[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            double sum = 0.0;
+#pragma unroll
+            for (int k4 = 0; k4 < KMAX; k4 += 4) {
+                if (k4 < Kt) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double e = exp(lwv[s][k4 + u] - m[s]);       // exp(-inf) = 0 for the neutral tail
+                        lwv[s][k4 + u] = e;
+                        sum += e;
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) lwv[s][k4 + u] = 0.0;
+                }
+            }
+            const double lse = m[s] + log(sum);
+            const bool live = i0 + TS * s < n;
+            if (blockIdx.y == 0) {
+                lse_out[i0 + TS * s] = lse;
+                if (live) ll_acc += lse;
+            }
+            inv[s] = live ? 1.0 / sum : 0.0;                     // padding samples contribute nothing
+        }
+
+        // ---- 3. per 64-sample slot: tiles -> LDS, statistics on the matrix cores
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < D; ++j) Xw[lane * XSS + j] = x[s][j] - shift[j];   // shift is zero-padded to D entries
+            Xw[lane * XSS + ONE] = 1.0;
+            Xw[lane * XSS + ZERO] = 0.0;
+#pragma unroll
+            for (int rb = 0; rb < RBW; ++rb) {
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    // (rb0 is uniform over the workgroup; the row-block index is resolved at compile time per group)
+                    double r = 0.0;
+#pragma unroll
+                    for (int g = 0; g < RBT / RBW; ++g)
+                        if (rb0 == g * RBW) r = lwv[s][(g * RBW + rb) * 16 + it];
+                    Rw[lane * RSS + it] = r * inv[s];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if ((rb0 + rb) * 16 < Kt) {                          // wave-uniform: skip all-zero row blocks
+#pragma unroll 4
+                    for (int sg = 0; sg < TS / 4; ++sg) {
+                        const double av = rbase[sg * RSS];           // r of (sample 16 g + sg, component lane & 15)
+                        const double* xr = xbase + sg * XSS;
+                        s0[rb] += av;
+#pragma unroll
+                        for (int c = 0; c < CB; ++c) {
+                            const double bv = xr[offa[c]] * xr[offb[c]];
+                            acc[rb][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[rb][c], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: fold the 4 waves' accumulators, S0 sums and log-likelihood sums in fixed order
+    // partial block of this workgroup column: [KP][FP], row = component, columns [0, 2d) features, column 2d = S0
+#pragma unroll
+    for (int r = 0; r < RBW; ++r) {
+        double v = s0[r];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        s0[r] = v;                                               // every lane (g, c): S0 of component c over the wave's samples
+    }
+    double* out = partials + (size_t)blockIdx.x * KP * FP;
+    for (int w = 0; w < 4; ++w) {
+        if (w == wave) {
+#pragma unroll
+            for (int r = 0; r < RBW; ++r) {
+#pragma unroll
+                for (int c = 0; c < CB; ++c)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int k = (rb0 + r) * 16 + (lane >> 4) + 4 * g;
+                        const int f = c * 16 + (lane & 15);
+                        if (f < 2 * d) {
+                            double* p = out + (size_t)k * FP + f;
+                            *p = (w == 0 ? 0.0 : *p) + acc[r][c][g];
+                        }
+                    }
+                if (lane < 16) {
+                    double* p = out + (size_t)((rb0 + r) * 16 + lane) * FP + 2 * d;
+                    *p = (w == 0 ? 0.0 : *p) + s0[r];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (blockIdx.y == 0) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ll_acc += __shfl_down(ll_acc, off, 64);
+        if (lane == 0) red[wave] = ll_acc;
+        __syncthreads();
+        if (tid == 0) ll_partials[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+    }
+}
+
+constexpr int rbw_of(int RBT) { return RBT >= 2 ? 2 : 1; }
+
+/// Samples per lane: 2 while coordinates + densities of both fit the registers of 2 waves per SIMD, else 1.
+constexpr int samples_per_lane(int D, int RBT) { return (D <= 16 && RBT == 1) || (D <= 8 && RBT == 2) ? 2 : 1; }
+
+template <int D, int RBT>
+int launch_t(const DiagArgs& a, int grid, hipStream_t stream)
+{
+    constexpr int CB = (2 * D + 15) / 16, RBW = rbw_of(RBT), PS = 2 * D + 2, XSS = xsd<D>(), S = samples_per_lane(D, RBT);
+    const size_t smem = sizeof(double) * (4 * ((size_t)TS * XSS + (size_t)TS * RSS) + (size_t)16 * RBT * PS);
+    hipLaunchKernelGGL((em_diag_kernel<D, RBT, RBW, CB, S>), dim3(grid, RBT / RBW), dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d,
+                       a.shift, a.params, a.K, a.lse, a.partials, em_diag_partial_rows(a.K), em_diag_partial_cols(a.d),
+                       a.ll_partials);
+    return grid;
+}
+
+template <int D>
+int launch_d(const DiagArgs& a, int grid, hipStream_t stream)
+{
+    const int RB = (a.K + 15) / 16;
+    if (RB == 1) return launch_t<D, 1>(a, grid, stream);
+    if (RB == 2) return launch_t<D, 2>(a, grid, stream);
+    if (RB <= 4) return launch_t<D, 4>(a, grid, stream);
+    return -1;
+}
+
+}  // namespace
+
+bool em_diag_supported(int d, int K) { return d >= 1 && d <= kRegDim && K >= 1 && K <= 64; }
+int em_diag_partial_rows(int K) { const int RB = (K + 15) / 16; return (RB == 1 ? 1 : RB == 2 ? 2 : 4) * 16; }
+int em_diag_partial_cols(int d) { return (2 * d + 1 + 15) / 16 * 16; }
+
+/// Workgroups in x the launch will use for (d, K, n) -- also the number of partial blocks / log-likelihood partials.
+int em_diag_grid(int d, int K, uint32_t n, int num_cus)
+{
+    const int RB = (K + 15) / 16;
+    const int D = padded_dim(d), RBT = RB == 1 ? 1 : (RB == 2 ? 2 : 4);
+    const uint32_t tw = (uint32_t)TS * samples_per_lane(D, RBT);
+    const uint32_t n_tiles = (n + tw - 1) / tw;
+    const int groups = RB >= 4 ? 2 : 1;                          // row-block groups in grid.y
+    int per_cu = (padded_dim(d) <= 16 && RB <= 2) ? 2 : 1;
+    int grid = per_cu * num_cus / groups;
+    if ((uint32_t)grid * 4 > n_tiles) grid = (int)((n_tiles + 3) / 4);
+    return grid < 1 ? 1 : grid;
+}
+
+int launch_em_diag(const DiagArgs& a, int num_cus, hipStream_t stream)
+{
+    if (!em_diag_supported(a.d, a.K)) return -1;
+    int grid = em_diag_grid(a.d, a.K, a.n, num_cus);
+    if (grid > a.n_ll_partials) grid = a.n_ll_partials;
+    const size_t block = (size_t)em_diag_partial_rows(a.K) * em_diag_partial_cols(a.d);
+    if ((size_t)grid * block > a.partials_capacity) grid = (int)(a.partials_capacity / block);
+    if (grid < 1) return -2;
+    switch (padded_dim(a.d)) {
+    case 1: return launch_d<1>(a, grid, stream);
+    case 2: return launch_d<2>(a, grid, stream);
+    case 3: return launch_d<3>(a, grid, stream);
+    case 4: return launch_d<4>(a, grid, stream);
+    case 6: return launch_d<6>(a, grid, stream);
+    case 8: return launch_d<8>(a, grid, stream);
+    case 12: return launch_d<12>(a, grid, stream);
+    case 16: return launch_d<16>(a, grid, stream);
+    case 20: return launch_d<20>(a, grid, stream);
+    case 24: return launch_d<24>(a, grid, stream);
+    case 28: return launch_d<28>(a, grid, stream);
+    case 32: return launch_d<32>(a, grid, stream);
+    default: return -1;
+    }
+}
+
+}  // namespace mstats
+}  // namespace mlhip

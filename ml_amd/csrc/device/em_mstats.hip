@@ -135,6 +135,10 @@ size_t em_mstats_scratch_doubles(int d, int K, int num_cus)
 {
     const Plan p = make_plan(d, K, num_cus);
     size_t need = (size_t)p.grid_x * p.KP * p.FP;
+    if (mstats::em_diag_supported(d, K)) {    // the diagonal-covariance kernel: up to 2 workgroups per CU
+        const size_t diag = (size_t)2 * num_cus * mstats::em_diag_partial_rows(K) * mstats::em_diag_partial_cols(d);
+        if (diag > need) need = diag;
+    }
     if (mstats::em_fused_supported(d, K)) {   // the fused small-shape kernel runs up to 3 workgroups per CU
         const size_t fused = (size_t)3 * num_cus * mstats::em_fused_partial_rows(K) * mstats::em_fused_partial_cols(d);
         if (fused > need) need = fused;

@@ -56,6 +56,11 @@ inline int estep_mfma4_param_stride(int D) { return estep_mfma4_block_count(D) *
 /// xt = [x - shift ; 1] (length d+1). Entry (a,b), a >= b, sits at a(a+1)/2 + b; so
 ///   S0 = (d,d), S1'_b = (d,b), M2'_ab = (a,b).
 inline int stats_count(int d) { return (d + 1) * (d + 2) / 2; }
+/// Diagonal-covariance extension (device/em_diag.hip). Parameter record of one component, diag_param_stride(D) doubles:
+///   [ mean(D) | iv(D) = 1 / sigma_j^2 | coef = log(pi) - sum_j log sigma_j | pad ]   (even stride: 16-byte aligned LDS reads).
+/// Statistics of one component, diag_stats_count(d) doubles: [ S1'(d) = sum r xt_j | S2'(d) = sum r xt_j^2 | S0 = sum r ].
+inline int diag_param_stride(int D) { return 2 * D + 2; }
+inline int diag_stats_count(int d) { return 2 * d + 1; }
 inline int stats_index(int a, int b) { return a * (a + 1) / 2 + b; }
 
 }  // namespace mlhip

@@ -200,6 +200,45 @@ void finalize_mstep(int d, int K, const double* stats, const double* shift, doub
     }
 }
 
+void build_diag_params(int d, int D, int K, int K_padded, const double* mixing, const double* means, const double* variances,
+                       double* records)
+{
+    const int PS = diag_param_stride(D);
+    for (int k = K; k < K_padded; ++k) {
+        double* rec = records + (size_t)k * PS;
+        for (int i = 0; i < PS; ++i) rec[i] = 0.0;
+        rec[2 * D] = -HUGE_VAL;
+    }
+    for (int k = 0; k < K; ++k) {
+        double* rec = records + (size_t)k * PS;
+        for (int i = 0; i < PS; ++i) rec[i] = 0.0;            // padded coordinates: mean 0, weight 0 -> contribute exactly 0
+        double log_det_half = 0.0;
+        for (int j = 0; j < d; ++j) {
+            const double l = std::sqrt(variances[(size_t)k * d + j]);
+            rec[j] = means[(size_t)k * d + j];
+            rec[D + j] = (1.0 / l) / l;
+            log_det_half += std::log(l);
+        }
+        rec[2 * D] = std::log(mixing[k]) - log_det_half;
+    }
+}
+
+void finalize_mstep_diag(int d, int K, const double* stats, const double* shift, double n_global, double* mixing,
+                         double* means, double* variances)
+{
+    const int F = diag_stats_count(d);
+    for (int k = 0; k < K; ++k) {
+        const double* s = stats + (size_t)k * F;
+        const double s0 = s[2 * d];
+        for (int a = 0; a < d; ++a) {
+            const double m = s[a] / s0;
+            means[(size_t)k * d + a] = shift[a] + m;
+            variances[(size_t)k * d + a] = (s[d + a] - s[a] * m) / s0 + 1e-15;   // ridge: ML/EM.cpp:252
+        }
+        mixing[k] = s0 / n_global;                                                // ML/EM.cpp:257
+    }
+}
+
 void set_host_ranks(int local_ranks) { g_host_threads.store(resolve_host_threads(local_ranks), std::memory_order_relaxed); }
 
 }  // namespace host

@@ -35,6 +35,18 @@ void build_estep_params_mfma4(int d, int D, int K, const double* mixing, const d
 void finalize_mstep(int d, int K, const double* stats, const double* shift, double n_global, double* mixing,
                     double* means, double* covariances);
 
+/// Diagonal-covariance extension: records [mean(D) | 1/sigma^2 (D) | log(pi) - sum log sigma] (layout.hpp diag_param_stride)
+/// from variances[K*d]; sigma_j = sqrt(var_j) is the diagonal Cholesky factor, 1/sigma^2 = (1/sigma)/sigma what
+/// llt.solve(I) yields for it (ML/EM.cpp:279-285 restricted to a diagonal matrix).
+/// `records` receives K_padded >= K records; those beyond K are neutral (coef = -inf: log-density -inf, responsibility 0).
+void build_diag_params(int d, int D, int K, int K_padded, const double* mixing, const double* means, const double* variances,
+                       double* records);
+
+/// Diagonal closing arithmetic from the all-reduced statistics [S1'(d) | S2'(d) | S0] per component:
+///   mean_k = shift + S1'/S0 ; var_kj = (S2'_j - S1'_j (S1'_j/S0)) / S0 + 1e-15 ; pi_k = S0 / N   (ML/EM.cpp:242-257, diagonal).
+void finalize_mstep_diag(int d, int K, const double* stats, const double* shift, double n_global, double* mixing,
+                         double* means, double* variances);
+
 /// Tells the host-side math how many ranks share this node, so that the OpenMP teams of the per-component
 /// factorizations together stay within the host's cores (MLHIP_HOST_THREADS overrides the per-rank thread count).
 void set_host_ranks(int local_ranks);

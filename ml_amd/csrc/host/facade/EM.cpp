@@ -189,7 +189,9 @@ bool EM::fit(ConstMatrixRef data)
     }
 
     const std::size_t dd = static_cast<std::size_t>(number_dimensions) * number_dimensions;
+    const bool diagonal = covariance_type_ == CovarianceType::Diagonal;   // extension, see ML/EM.hpp
     std::vector<double> cov_flat(dd * K);
+    std::vector<double> var_flat;                                          // diagonal mode: K x d variances
     auto unpack_covariances = [&] {
         for (unsigned int k = 0; k < K; ++k) {
             covariances_[k].resize(number_dimensions, number_dimensions);
@@ -229,11 +231,24 @@ bool EM::fit(ConstMatrixRef data)
         for (unsigned int k = 0; k < K; ++k) std::copy_n(sample_covariance.data(), dd, cov_flat.data() + dd * k);
     }
 
+    if (diagonal) {
+        // the diagonal of the starting covariances (a one-hot / responsibility-weighted M-step entry by entry, or the
+        // sample variances) is the diagonal-mode start
+        var_flat.resize(static_cast<std::size_t>(number_dimensions) * K);
+        for (unsigned int k = 0; k < K; ++k)
+            for (unsigned int j = 0; j < number_dimensions; ++j)
+                var_flat[static_cast<std::size_t>(k) * number_dimensions + j] = cov_flat[dd * k + static_cast<std::size_t>(j) * number_dimensions + j];
+    }
+
     double old_log_likelihood = -std::numeric_limits<double>::infinity();
     for (unsigned int step = 0; step < maximum_steps_; ++step) {
         // One E-step + M-step on the device; parameters are updated in place (ML/EM.cpp:145-147).
-        check(mlhip_em_step(ctx, dev.h, K, mixing_probabilities_.data(), means_.data(), cov_flat.data(), &log_likelihood_,
-                            mixing_probabilities_.data(), means_.data(), cov_flat.data()));
+        if (diagonal)
+            check(mlhip_em_step_diag(ctx, dev.h, K, mixing_probabilities_.data(), means_.data(), var_flat.data(), &log_likelihood_,
+                                     mixing_probabilities_.data(), means_.data(), var_flat.data()));
+        else
+            check(mlhip_em_step(ctx, dev.h, K, mixing_probabilities_.data(), means_.data(), cov_flat.data(), &log_likelihood_,
+                                mixing_probabilities_.data(), means_.data(), cov_flat.data()));
         ++steps_done_;
 
         if (verbose_) {
@@ -268,6 +283,12 @@ bool EM::fit(ConstMatrixRef data)
         old_log_likelihood = log_likelihood_;
     }
 
+    if (diagonal) {
+        std::fill(cov_flat.begin(), cov_flat.end(), 0.0);
+        for (unsigned int k = 0; k < K; ++k)
+            for (unsigned int j = 0; j < number_dimensions; ++j)
+                cov_flat[dd * k + static_cast<std::size_t>(j) * number_dimensions + j] = var_flat[static_cast<std::size_t>(k) * number_dimensions + j];
+    }
     unpack_covariances();
     process_covariances(number_dimensions);
     // The responsibilities of the last E-step stay in HBM; responsibilities() allocates and fetches them on demand.

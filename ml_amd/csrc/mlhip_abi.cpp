@@ -205,6 +205,9 @@ struct mlhip_data {
     bool have_estep = false;
     bool lw_valid = false;        // false after a fused step: lw is rebuilt from params_dev on demand (ensure_lw)
     int estep_variant = 0;        // record layout currently in params_dev: 0 = valu, 1 = mfma16, 2 = mfma4
+    // diagonal-covariance extension: parameters of the last mlhip_em_step_diag (the N x K block is rebuilt from them on demand)
+    bool diag_step = false;
+    std::vector<double> diag_mixing, diag_means, diag_vars;
     // source of the last statistics pass (for the per-component refinement pass)
     int stats_mode = 0;
     const double* stats_resp = nullptr;
@@ -290,7 +293,8 @@ void finish_upload(mlhip_data* dt)
     dt->n_global = (uint64_t)std::llround(v[dt->d]);
     dt->shift.resize(dt->d);
     for (int j = 0; j < dt->d; ++j) dt->shift[j] = v[j] / v[dt->d];
-    dt->shift_dev.reserve(sizeof(double) * dt->d);
+    dt->shift_dev.reserve(sizeof(double) * dt->D);              // zero-padded to the kernels' dimension D
+    HIP_CHECK(hipMemsetAsync(dt->shift_dev.p, 0, sizeof(double) * dt->D, ctx->stream));
     HIP_CHECK(hipMemcpyAsync(dt->shift_dev.p, dt->shift.data(), sizeof(double) * dt->d, hipMemcpyHostToDevice, ctx->stream));
     ctx->sync();
 }
@@ -485,6 +489,7 @@ void launch_estep(mlhip_data* dt, int K)
 
 void run_estep(mlhip_data* dt, int K, const double* mixing, const double* means, const double* covs)
 {
+    dt->diag_step = false;
     prepare_estep(dt, K, mixing, means, covs);
     launch_estep(dt, K);
 }
@@ -493,14 +498,24 @@ void run_estep(mlhip_data* dt, int K, const double* mixing, const double* means,
 /// responsibilities, a separate M-step, the refinement pass) gets it rebuilt from the same parameter records.
 void ensure_lw(mlhip_data* dt, int K)
 {
-    if (dt->have_estep && !dt->lw_valid) launch_estep(dt, K);
+    if (!dt->have_estep || dt->lw_valid) return;
+    if (dt->diag_step) {
+        // params_dev holds diagonal records: expand the same parameters to full (diagonal) covariances for the E-step kernel
+        const int d = dt->d;
+        std::vector<double> covs((size_t)K * d * d, 0.0);
+        for (int k = 0; k < K; ++k)
+            for (int j = 0; j < d; ++j) covs[(size_t)k * d * d + (size_t)j * d + j] = dt->diag_vars[(size_t)k * d + j];
+        prepare_estep(dt, K, dt->diag_mixing.data(), dt->diag_means.data(), covs.data());
+        dt->diag_step = false;
+    }
+    launch_estep(dt, K);
 }
 
 /// All-reduces the reduced statistics buffer [K*F stats, ll_sum] and leaves it in stats_host.
-void collect_stats(mlhip_data* dt, int K)
+void collect_stats(mlhip_data* dt, int K, size_t count = 0)
 {
     mlhip_ctx* ctx = dt->ctx;
-    const size_t count = (size_t)K * stats_count(dt->d) + 1;
+    if (!count) count = (size_t)K * stats_count(dt->d) + 1;
     if (ctx->reduce_fn && ctx->reduce_on_device) {
         if (ctx->reduce_fn(ctx->reduce_user, dt->stats_dev.as<double>(), count, 1, ctx->stream) != 0)
             throw std::runtime_error("all-reduce hook failed");
@@ -520,6 +535,7 @@ bool run_fused_step(mlhip_data* dt, int K, const double* mixing, const double* m
     const char* env = std::getenv("MLHIP_FUSED");
     if ((env && env[0] == '0') || !mstats::em_fused_supported(dt->d, K)) return false;
     mlhip_ctx* ctx = dt->ctx;
+    dt->diag_step = false;
     prepare_estep(dt, K, mixing, means, covs);
     if (dt->estep_variant != 0) return false;            // (cannot happen for d <= 8; the fused kernel reads VALU records)
     FusedArgs a{};
@@ -572,9 +588,15 @@ void run_mstats(mlhip_data* dt, int K, int mode, const double* resp_dev, size_t 
     collect_stats(dt, K);
 }
 
+double log_two_pi()
+{
+    static const double v = std::log(2. * 3.14159265358979323846);   // ML/EM.cpp:197
+    return v;
+}
+
 double ll_from_stats(const mlhip_data* dt, int K)
 {
-    static const double log_2_pi = std::log(2. * 3.14159265358979323846);   // ML/EM.cpp:197
+    const double log_2_pi = log_two_pi();
     const double sum = dt->stats_host.as<double>()[(size_t)K * stats_count(dt->d)];
     return sum / (double)dt->n_global - (double)dt->d * log_2_pi / 2;
 }
@@ -670,6 +692,27 @@ void finalize_out(mlhip_data* dt, int K, double* mixing_out, double* means_out, 
         }
         if (flag) refine_component(dt, k, means_out + (size_t)k * d, cov_out + (size_t)k * d * d);
     }
+}
+
+/// One diagonal-covariance EM iteration's device work (em_diag.hip) with the statistics shift at `shift_dev`; leaves the
+/// all-reduced [K * (2d+1) statistics, ll_sum] in stats_host. The records must already be in params_dev.
+void run_diag_kernel(mlhip_data* dt, int K, const double* shift_dev)
+{
+    mlhip_ctx* ctx = dt->ctx;
+    DiagArgs a{};
+    a.xt = dt->xt.as<double>(); a.ldx = dt->ldx; a.n = dt->n; a.d = dt->d;
+    a.shift = shift_dev; a.params = dt->params_dev.as<double>(); a.K = K;
+    a.lse = dt->lse.as<double>();
+    a.partials = dt->partials.as<double>(); a.partials_capacity = dt->partials.bytes / sizeof(double);
+    a.ll_partials = dt->ll_partials.as<double>(); a.n_ll_partials = kMaxLlPartials;
+    int grid = 0;
+    ctx->timed("em_diag", [&] { grid = mstats::launch_em_diag(a, ctx->num_cus, ctx->stream); });
+    if (grid <= 0) throw std::runtime_error("diagonal EM kernel launch failed");
+    launch_em_reduce_blocks(a.partials, grid, mstats::em_diag_partial_rows(K), mstats::em_diag_partial_cols(dt->d), K,
+                            diag_stats_count(dt->d), a.ll_partials, grid, dt->stats_dev.as<double>(), ctx->stream);
+    HIP_CHECK(hipGetLastError());
+    dt->n_ll = grid;
+    collect_stats(dt, K, (size_t)K * diag_stats_count(dt->d) + 1);
 }
 
 void ensure_km_workspace(mlhip_data* dt, int K)
@@ -1079,12 +1122,72 @@ int mlhip_em_step(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* mi
     });
 }
 
+int mlhip_em_step_diag(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* mixing, const double* means,
+                       const double* variances, double* log_likelihood, double* mixing_out, double* means_out,
+                       double* variances_out)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, K);
+        require(mixing && means && variances && log_likelihood && mixing_out && means_out && variances_out, "null argument");
+        const int d = data->d, Ki = (int)K;
+        if (!mstats::em_diag_supported(d, Ki))
+            throw Unsupported("diagonal-covariance EM is built for d <= 32 and K <= 64");
+        ensure_em_workspace(data, Ki);
+        // keep the input parameters: labels / responsibilities are produced from them on demand (ensure_lw)
+        data->diag_mixing.assign(mixing, mixing + K);
+        data->diag_means.assign(means, means + (size_t)K * d);
+        data->diag_vars.assign(variances, variances + (size_t)K * d);
+        const int KP = mstats::em_diag_partial_rows(Ki);          // records are padded to whole 16-component row blocks
+        const size_t rec_bytes = sizeof(double) * diag_param_stride(data->D) * (size_t)KP;
+        data->params_dev.reserve(rec_bytes);
+        data->params_host.reserve(rec_bytes);
+        host::build_diag_params(d, data->D, Ki, KP, mixing, means, variances, data->params_host.as<double>());
+        HIP_CHECK(hipMemcpyAsync(data->params_dev.p, data->params_host.p, rec_bytes, hipMemcpyHostToDevice, ctx->stream));
+        run_diag_kernel(data, Ki, data->shift_dev.as<double>());
+        data->have_estep = true;
+        data->lw_valid = false;
+        data->diag_step = true;
+        const int F = diag_stats_count(d);
+        const double* st = data->stats_host.as<double>();
+        *log_likelihood = st[(size_t)K * F] / (double)data->n_global - (double)d * log_two_pi() / 2;   // ML/EM.cpp:197-198, 211
+        host::finalize_mstep_diag(d, Ki, st, data->shift.data(), (double)data->n_global, mixing_out, means_out, variances_out);
+        // Same cancellation guard as the full-covariance path (refine_ratio): a component whose mean sits far from the
+        // shared shift, measured in its own standard deviations, gets its variances from a second pass with the shift at
+        // its new mean (the E part of that pass re-evaluates the SAME input parameters, still in params_dev).
+        const double limit = refine_ratio();
+        if (!(limit > 0)) return;
+        std::vector<double> st2;
+        for (int k = 0; k < Ki; ++k) {
+            if (!(mixing_out[k] > 0) || !std::isfinite(mixing_out[k])) continue;
+            bool flag = false;
+            for (int a = 0; a < d && !flag; ++a) {
+                const double off = means_out[(size_t)k * d + a] - data->shift[a], var = variances_out[(size_t)k * d + a];
+                if (!std::isfinite(off) || !std::isfinite(var)) { flag = false; break; }
+                flag = off * off > limit * var;
+            }
+            if (!flag) continue;
+            data->refine_shift.reserve(sizeof(double) * data->D);
+            HIP_CHECK(hipMemsetAsync(data->refine_shift.p, 0, sizeof(double) * data->D, ctx->stream));
+            HIP_CHECK(hipMemcpyAsync(data->refine_shift.p, means_out + (size_t)k * d, sizeof(double) * d, hipMemcpyHostToDevice, ctx->stream));
+            run_diag_kernel(data, Ki, data->refine_shift.as<double>());
+            const double* s = data->stats_host.as<double>() + (size_t)k * F;
+            const double s0 = s[2 * d];
+            for (int a = 0; a < d; ++a) {
+                const double m = s[a] / s0;                                      // ~0: the shift is the mean already
+                variances_out[(size_t)k * d + a] = (s[d + a] - s[a] * m) / s0 + 1e-15;
+                means_out[(size_t)k * d + a] += m;
+            }
+            data->refined_components += 1;
+        }
+    });
+}
+
 int mlhip_em_maximisation_from(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* resp, int64_t ldr,
                                double* mixing_out, double* means_out, double* covariances_out)
 {
     return guarded([&] {
         check_em_args(ctx, data, K);
-        require(resp && mixing_out && means_out && covariances_out, "null argument");
+        require((resp || data->n == 0) && mixing_out && means_out && covariances_out, "null argument");   // (an empty shard has no rows)
         require(ldr >= (int64_t)data->n, "ldr must be >= n_local");
         ensure_em_workspace(data, (int)K);
         data->resp_dev.reserve(sizeof(double) * data->ldr * K);
@@ -1102,10 +1205,11 @@ int mlhip_em_maximisation_from_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t
 {
     return guarded([&] {
         check_em_args(ctx, data, K);
-        require(labels && mixing_out && means_out && covariances_out, "null argument");
+        require((labels || data->n == 0) && mixing_out && means_out && covariances_out, "null argument");
         ensure_em_workspace(data, (int)K);
         data->labels_dev.reserve(sizeof(uint32_t) * data->n_pad);
-        HIP_CHECK(hipMemcpyAsync(data->labels_dev.p, labels, sizeof(uint32_t) * data->n, hipMemcpyHostToDevice, ctx->stream));
+        if (data->n)
+            HIP_CHECK(hipMemcpyAsync(data->labels_dev.p, labels, sizeof(uint32_t) * data->n, hipMemcpyHostToDevice, ctx->stream));
         // One-hot responsibilities are materialised in the (still unused) log-responsibility buffer of the workspace.
         data->have_estep = false;
         launch_fill_responsibilities(data->labels_dev.as<uint32_t>(), data->n, (int)K, data->lw.as<double>(), data->ldr, ctx->stream);
@@ -1118,7 +1222,7 @@ int mlhip_em_responsibilities(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, doub
 {
     return guarded([&] {
         check_em_args(ctx, data, K);
-        require(resp, "null argument");
+        require(resp || data->n == 0, "null argument");
         require(ldr >= (int64_t)data->n, "ldr must be >= n_local");
         require(data->have_estep && data->em_K == (int)K, "no E-step results on the device for this K");
         ensure_lw(data, (int)K);
@@ -1137,7 +1241,7 @@ int mlhip_em_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, uint32_t* labe
 {
     return guarded([&] {
         check_em_args(ctx, data, K);
-        require(labels, "null argument");
+        require(labels || data->n == 0, "null argument");
         require(data->have_estep && data->em_K == (int)K, "no E-step results on the device for this K");
         ensure_lw(data, (int)K);
         data->labels_dev.reserve(sizeof(uint32_t) * data->n_pad);
@@ -1183,7 +1287,7 @@ int mlhip_xxt_xy(mlhip_ctx* ctx, mlhip_data* data, const double* y, double* xxt,
 {
     return guarded([&] {
         check_em_args(ctx, data, 2);
-        require(y && xxt && xy, "null argument");
+        require((y || data->n == 0) && xxt && xy, "null argument");
         ensure_em_workspace(data, 2);
         data->have_estep = false;
         // weight rows: [0] = 1 (valid samples), [1] = y; the statistics kernel then yields, about the shift s,
@@ -1273,7 +1377,7 @@ int mlhip_kmeans_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t* labels)
 {
     return guarded([&] {
         check_em_args(ctx, data, 1);
-        require(labels, "null argument");
+        require(labels || data->n == 0, "null argument");
         require(data->km_have_old, "no K-means assignment on the device yet");
         ctx->sync();
         download_columns(ctx, reinterpret_cast<char*>(labels), 0, data->km_labels[data->km_cur].as<char>(), 0,
@@ -1285,7 +1389,7 @@ int mlhip_kmeans_distances(mlhip_ctx* ctx, mlhip_data* data, double* dist2)
 {
     return guarded([&] {
         check_em_args(ctx, data, 1);
-        require(dist2, "null argument");
+        require(dist2 || data->n == 0, "null argument");
         require(data->km_have_old, "no K-means assignment on the device yet");
         ctx->sync();
         download_columns(ctx, reinterpret_cast<char*>(dist2), 0, data->km_mind.as<char>(), 0, sizeof(double) * data->n, 1);
@@ -1296,7 +1400,7 @@ int mlhip_min_squared_distances(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, co
 {
     return guarded([&] {
         check_em_args(ctx, data, K);
-        require(centroids && dist2, "null argument");
+        require(centroids && (dist2 || data->n == 0), "null argument");
         // Must not disturb the label history used for n_changed: run on a scratch copy of the state.
         const int cur = data->km_cur;
         const bool have = data->km_have_old;

@@ -95,6 +95,10 @@ int mlpp_em_set_means_initialiser(mlpp_em* h, const mlpp_centroids_initialiser* 
 int mlpp_em_set_responsibilities_initialiser(mlpp_em* h, const mlpp_responsibilities_initialiser* i) { return guarded([&] { need(h); h->em.set_responsibilities_initialiser(i ? i->p : nullptr); }); }
 int mlpp_em_set_verbose(mlpp_em* h, int v) { return guarded([&] { need(h); h->em.set_verbose(v != 0); }); }
 int mlpp_em_set_maximise_first(mlpp_em* h, int v) { return guarded([&] { need(h); h->em.set_maximise_first(v != 0); }); }
+int mlpp_em_set_covariance_type(mlpp_em* h, int diagonal)
+{
+    return guarded([&] { need(h); h->em.set_covariance_type(diagonal ? ml::EM::CovarianceType::Diagonal : ml::EM::CovarianceType::Full); });
+}
 int mlpp_em_fit(mlpp_em* h, const double* data, uint64_t n, uint32_t d, int* converged)
 {
     return guarded([&] {

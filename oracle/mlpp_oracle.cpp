@@ -303,7 +303,11 @@ bool EM::fit(const DataView& data)
             maximisation_step(data);                                  // :125
         } else {
             means_init_->init(data, prng_, K_, means_);               // :128
-            const Mat sample_cov = calculate_sample_covariance(data); // :129
+            Mat sample_cov = calculate_sample_covariance(data);       // :129
+            if (diagonal_)                                            // extension: keep the variances only
+                for (std::size_t b = 0; b < d; ++b)
+                    for (std::size_t a = 0; a < d; ++a)
+                        if (a != b) sample_cov(a, b) = 0.0;
             for (unsigned k = 0; k < K_; ++k) cov_[k] = sample_cov;   // :132-134
             process_covariances(d);                                   // :135
         }
@@ -358,7 +362,13 @@ void EM::expectation_step(const DataView& data)
         for (std::size_t i = 0; i < n; ++i) {                         // :205-208
             const double* x = data.col(i);
             for (std::size_t j = 0; j < d; ++j) work_[j] = x[j] - mean[j];
-            w[i] = std::exp(-0.5 * xAx_symmetric(inv, work_.data(), d));
+            if (diagonal_) {
+                double q = 0;                                         // the diagonal terms of xAx_symmetric (:20-22)
+                for (std::size_t j = 0; j < d; ++j) q += inv(j, j) * work_[j] * work_[j];
+                w[i] = std::exp(-0.5 * q);
+            } else {
+                w[i] = std::exp(-0.5 * xAx_symmetric(inv, work_.data(), d));
+            }
         }
         const double scale = pi_[k] / sqrt_det_[k];                   // :209  column *= (pi/sqrt_det)
         for (std::size_t i = 0; i < n; ++i) w[i] *= scale;
@@ -405,7 +415,11 @@ void EM::maximisation_step(const DataView& data)
         for (std::size_t i = 0; i < n; ++i) {                         // :245-248
             const double* x = data.col(i);
             for (std::size_t j = 0; j < d; ++j) work_[j] = x[j] - mean[j];
-            add_a_xxT(work_.data(), d, cov, w[i]);
+            if (diagonal_) {
+                for (std::size_t j = 0; j < d; ++j) cov(j, j) += w[i] * work_[j] * work_[j];   // add_a_xxT's diagonal (:63-64)
+            } else {
+                add_a_xxT(work_.data(), d, cov, w[i]);
+            }
         }
         for (double& v : cov.a) v /= sum_w;                           // :250
         static constexpr double epsilon = 1e-15;                      // :252
@@ -455,6 +469,21 @@ static void cholesky_lower(const Mat& A, Mat& L)
 // ML/EM.cpp:274-287
 void EM::process_covariances(std::size_t d)
 {
+    for (unsigned k = 0; k < K_ && diagonal_; ++k) {
+        // extension: the same decomposition of a diagonal matrix, without the O(d^3) loops
+        Mat L(d, d, 0.0), inv(d, d, 0.0);
+        double sd = 1;
+        for (std::size_t j = 0; j < d; ++j) {
+            const double ljj = std::sqrt(cov_[k](j, j));
+            L(j, j) = ljj;
+            inv(j, j) = (1.0 / ljj) / ljj;
+            sd *= ljj;
+        }
+        chol_[k] = L;
+        inv_cov_[k] = inv;
+        sqrt_det_[k] = sd;
+    }
+    if (diagonal_) return;
     for (unsigned k = 0; k < K_; ++k) {
         cholesky_lower(cov_[k], chol_[k]);                            // :279
         const Mat& L = chol_[k];

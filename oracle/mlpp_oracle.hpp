@@ -82,6 +82,14 @@ public:
     void set_means_initialiser(std::shared_ptr<const CentroidsInitialiser> p);                  // :68-74
     void set_responsibilities_initialiser(std::shared_ptr<const ResponsibilitiesInitialiser> p); // :76-82
     void set_maximise_first(bool b) { maximise_first_ = b; }
+    /// EXTENSION, not in the reference (ml::EM is full-covariance only, ML/EM.hpp:175): diagonal covariances. The same loops
+    /// (E-step :190-219, M-step :221-263, process_covariances :274-287) restricted to the diagonal: q = sum_j A_jj x_j^2
+    /// (the diagonal terms of xAx_symmetric, :20-22), cov_jj += a x_j x_j (the diagonal terms of add_a_xxT, :63-64),
+    /// L_jj = sqrt(cov_jj), inverse_jj = (1 / L_jj) / L_jj (what llt.solve(I) yields for a diagonal factor), sqrt_det =
+    /// prod L_jj. Off-diagonal entries of every covariance stay 0. BASELINE.json configs[1] asks for it; the third-party
+    /// pin is scikit-learn's covariance_type='diag' (tests/golden/em_onestep_diag_*.npz).
+    void set_diagonal(bool b) { diagonal_ = b; }
+    bool diagonal() const { return diagonal_; }
     bool fit(const DataView& data);                          // :91-174
     void assign_responsibilities(const double* x, std::size_t xlen, double* u, std::size_t ulen) const;  // :176-188
 
@@ -119,7 +127,7 @@ private:
     std::vector<unsigned> labels_;
     double atol_ = 1e-8, rtol_ = 1e-8, ll_ = 0;
     unsigned K_, max_steps_ = 1000, steps_done_ = 0;
-    bool maximise_first_ = false, converged_ = false;
+    bool maximise_first_ = false, converged_ = false, diagonal_ = false;
 };
 
 // ---- ML/KMeans.cpp --------------------------------------------------------------------------

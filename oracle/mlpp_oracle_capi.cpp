@@ -117,6 +117,10 @@ int orc_em_set_relative_tolerance(OrcEM* h, double t) { return guarded([&] { h->
 int orc_em_set_maximum_steps(OrcEM* h, unsigned m) { return guarded([&] { h->em.set_maximum_steps(m); }); }
 int orc_em_set_maximise_first(OrcEM* h, int b) { return guarded([&] { h->em.set_maximise_first(b != 0); }); }
 // kind 0..2 as above, 3 = fixed centroids (d x K column-major in `fixed`).
+int orc_em_set_diagonal(OrcEM* h, int on)
+{
+    return guarded([&] { h->em.set_diagonal(on != 0); });
+}
 int orc_em_set_means_initialiser(OrcEM* h, int kind, const double* fixed, unsigned d)
 {
     return guarded([&] { h->em.set_means_initialiser(make_init(kind, fixed, d, h->em.K())); });

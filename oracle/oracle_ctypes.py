@@ -136,6 +136,12 @@ class EM:
     def set_maximum_steps(self, m): _check(lib.orc_em_set_maximum_steps(self._h, C.c_uint(m)))
     def set_maximise_first(self, b): _check(lib.orc_em_set_maximise_first(self._h, int(b)))
 
+    def set_covariance_type(self, kind):
+        """'full' (the reference) or 'diag' (extension: BASELINE.json configs[1]; see mlpp_oracle.hpp)."""
+        if kind not in ("full", "diag"):
+            raise ValueError("covariance type must be 'full' or 'diag'")
+        _check(lib.orc_em_set_diagonal(self._h, int(kind == "diag")))
+
     def set_means_initialiser(self, kind, fixed=None):
         """fixed: K x d array of initial means when kind == FIXED."""
         if kind == FIXED:

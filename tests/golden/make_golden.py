@@ -17,6 +17,9 @@ em_onestep_*.npz        one E+M iteration from explicit parameters (pi0, mu0, Si
                         of the E-step, responsibilities/labels under the initial parameters (scipy, independent
                         of sklearn), and sklearn's M-step outputs (weights_, means_, covariances_ with
                         reg_covar=1e-15 == the reference's ridge, ML/EM.cpp:252-256).
+em_onestep_diag_*.npz   the same for DIAGONAL covariances (BASELINE.json configs[1]; an extension -- the reference has no
+                        diagonal mode, ML/EM.hpp:175 -- so this third-party pin is the only one): scipy E-step under
+                        (pi0, mu0, var0) and sklearn covariance_type='diag' M-step outputs (variances K x d).
 kmeans_onestep_*.npz    one Lloyd step from explicit centroids: labels/inertia (numpy, direct squared
                         distances as in ML/KMeans.cpp:153-165) and sklearn's updated centres.
 """
@@ -116,6 +119,39 @@ def make_em_onestep(tag, seed, n, d, K, sep):
     print(f"em_onestep_{tag}: n={n} d={d} K={K} ll0={ll0:.12g} min label margin={margin:.3g}")
 
 
+def make_em_onestep_diag(tag, seed, n, d, K, sep):
+    rng = np.random.default_rng(seed)
+    means = sep * rng.standard_normal((K, d))
+    var = rng.uniform(0.5, 2.0, (K, d))
+    w = rng.uniform(0.5, 1.5, K)
+    w /= w.sum()
+    comp = rng.choice(K, size=n, p=w)
+    X = means[comp] + rng.standard_normal((n, d)) * np.sqrt(var[comp])
+    mu0 = means + 0.3 * rng.standard_normal((K, d))
+    var0 = var * rng.uniform(0.8, 1.3, (K, d)) + 0.05
+    pi0 = rng.uniform(0.5, 1.5, K)
+    pi0 /= pi0.sum()
+
+    logw = np.stack([scipy.stats.multivariate_normal(mu0[k], np.diag(var0[k])).logpdf(X) + np.log(pi0[k]) for k in range(K)], axis=1)
+    logw = logw.reshape(n, K)
+    lse = scipy.special.logsumexp(logw, axis=1)
+    R0 = np.exp(logw - lse[:, None])
+    ll0 = lse.mean()
+    labels0 = np.argmax(R0, axis=1).astype(np.uint32)
+    srt = np.sort(R0, axis=1)
+    margin = (srt[:, -1] - srt[:, -2]).min() if K > 1 else 1.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gmm = sklearn.mixture.GaussianMixture(K, covariance_type="diag", tol=0.0, max_iter=1, reg_covar=1e-15,
+                                              weights_init=pi0, means_init=mu0, precisions_init=1.0 / var0, random_state=0)
+        gmm.fit(X)
+    assert abs(gmm.lower_bound_ - ll0) < 1e-10 * max(1, abs(ll0)), (gmm.lower_bound_, ll0)
+    np.savez(os.path.join(HERE, f"em_onestep_diag_{tag}.npz"), X=X, pi0=pi0, mu0=mu0, var0=var0,
+             ll0=ll0, sklearn_lower_bound=gmm.lower_bound_, R0=R0, labels0=labels0, label_margin=margin,
+             pi1=gmm.weights_, mu1=gmm.means_, var1=gmm.covariances_)
+    print(f"em_onestep_diag_{tag}: n={n} d={d} K={K} ll0={ll0:.12g} min label margin={margin:.3g}")
+
+
 def make_kmeans_onestep(tag, seed, n, d, K, sep):
     rng = np.random.default_rng(seed)
     X, means, _, _ = synth_mixture(rng, n, d, K, sep)
@@ -144,7 +180,18 @@ def make_kmeans_onestep(tag, seed, n, d, K, sep):
     print(f"kmeans_onestep_{tag}: n={n} d={d} K={K} inertia0={inertia0:.12g} min margin={margin:.3g}")
 
 
+def make_diag_set():
+    make_em_onestep_diag("d4_K3", 31, 800, 4, 3, 2.5)
+    make_em_onestep_diag("d16_K16", 32, 1500, 16, 16, 2.0)     # the shape of BASELINE.json configs[1]
+    make_em_onestep_diag("d32_K8", 33, 1000, 32, 8, 1.5)
+    make_em_onestep_diag("d7_K40", 34, 1200, 7, 40, 2.5)
+
+
 if __name__ == "__main__":
+    import sys
+    if sys.argv[1:] == ["diag"]:       # only the diagonal fixtures (added in round 2; the others are left untouched)
+        make_diag_set()
+        sys.exit(0)
     make_mousie()
     make_em_onestep("d2_K3", 11, 500, 2, 3, 3.0)
     make_em_onestep("d3_K2", 12, 400, 3, 2, 3.0)
@@ -157,3 +204,4 @@ if __name__ == "__main__":
     make_kmeans_onestep("d2_K3", 21, 500, 2, 3, 3.0)
     make_kmeans_onestep("d8_K32", 22, 2000, 8, 32, 2.0)
     make_kmeans_onestep("d3_K1", 23, 200, 3, 1, 2.0)
+    make_diag_set()

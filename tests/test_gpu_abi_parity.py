@@ -13,7 +13,8 @@ from conftest import GOLDEN, load_golden
 
 pytestmark = pytest.mark.gpu
 
-EM_CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "em_onestep_*.npz")))
+EM_CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "em_onestep_*.npz"))
+                  if "_diag_" not in os.path.basename(p))          # the diagonal extension: tests/test_gpu_diag.py
 KM_CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "kmeans_onestep_*.npz")))
 
 

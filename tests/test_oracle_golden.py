@@ -8,7 +8,9 @@ import pytest
 
 from conftest import GOLDEN, load_golden
 
-EM_CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "em_onestep_*.npz")))
+DIAG_CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "em_onestep_diag_*.npz")))
+EM_CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "em_onestep_*.npz"))
+                  if os.path.basename(p) not in DIAG_CASES)
 KM_CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "kmeans_onestep_*.npz")))
 
 # Tolerance policy (DESIGN.md "Tolerances"): per-step fixtures agree to 1e-12 relative.
@@ -38,6 +40,52 @@ def test_em_one_step_matches_sklearn(oracle, case):
     assert relerr(em.means, g["mu1"]) < RTOL
     # sklearn's covariances are exactly symmetric products; ours accumulate rank-1 updates.
     assert relerr(em.covariances, g["Sigma1"]) < 1e-11
+
+
+@pytest.mark.parametrize("case", DIAG_CASES)
+def test_diagonal_em_one_step_matches_sklearn(oracle, case):
+    """The diagonal-covariance extension of the oracle (BASELINE.json configs[1]; no reference counterpart) against
+    scikit-learn covariance_type='diag' / scipy."""
+    g = load_golden(case)
+    X = g["X"]
+    K, d = g["mu0"].shape
+    em = oracle.EM(K)
+    em.set_covariance_type("diag")
+    em.set_parameters(g["mu0"], np.stack([np.diag(v) for v in g["var0"]]), g["pi0"])
+    em.expectation_step(X)
+    assert abs(em.log_likelihood - float(g["ll0"])) <= RTOL * abs(float(g["ll0"]))
+    assert np.max(np.abs(em.responsibilities - g["R0"])) < 1e-12
+    em.calculate_labels()
+    assert np.array_equal(em.labels, g["labels0"])
+    em.maximisation_step(X)
+    assert relerr(em.mixing_probabilities, g["pi1"]) < RTOL
+    assert relerr(em.means, g["mu1"]) < RTOL
+    S = em.covariances
+    assert relerr(np.stack([np.diag(S[k]) for k in range(K)]), g["var1"]) < 1e-11
+    off = S - np.stack([np.diag(np.diag(S[k])) for k in range(K)])
+    assert np.all(off == 0)                                  # off-diagonal entries stay exactly 0
+
+
+def test_diagonal_em_fit_converges_to_the_diagonal_of_its_own_fixed_point(oracle):
+    """A full fit in diagonal mode: monotone log-likelihood is implied by convergence; parameters are a fixed point of
+    one more diagonal E+M step to the fit's tolerance."""
+    g = load_golden("em_onestep_diag_d4_K3.npz")
+    X = g["X"]
+    K, d = g["mu0"].shape
+    em = oracle.EM(K)
+    em.set_covariance_type("diag")
+    em.set_means_initialiser(oracle.FIXED, g["mu0"])
+    em.set_absolute_tolerance(1e-12)
+    em.set_relative_tolerance(1e-12)
+    assert em.fit(X)
+    mu, S, pi, ll = em.means.copy(), em.covariances.copy(), em.mixing_probabilities.copy(), em.log_likelihood
+    again = oracle.EM(K)
+    again.set_covariance_type("diag")
+    again.set_parameters(mu, S, pi)
+    again.expectation_step(X)
+    again.maximisation_step(X)
+    assert abs(again.log_likelihood - ll) < 1e-8 * abs(ll)
+    assert relerr(again.means, mu) < 1e-5 and relerr(again.covariances, S) < 1e-5
 
 
 @pytest.mark.parametrize("case", KM_CASES)
