@@ -42,6 +42,44 @@ public:
     DLL_DECLSPEC virtual void init(ConstMatrixRef data, std::default_random_engine& prng, unsigned int number_components, MatrixRef responsibilities) const = 0;
 };
 
+#ifdef MLHIP_HAVE_EIGEN
+/** Base class for user initialisers written against the REFERENCE signature (reference ML/Clustering.hpp:71): derive from
+this instead of CentroidsInitialiser and keep the Eigen-typed `init` as it is. (The library itself is built without Eigen,
+so its own virtual takes the views of Dense.hpp; this adapter, emitted entirely in the user's translation unit, forwards.) */
+class EigenCentroidsInitialiser : public CentroidsInitialiser {
+public:
+    virtual void init(Eigen::Ref<const Eigen::MatrixXd> data, std::default_random_engine& prng, unsigned int number_components,
+                      Eigen::Ref<Eigen::MatrixXd> centroids) const = 0;
+    void init(ConstMatrixRef data, std::default_random_engine& prng, unsigned int number_components, MatrixRef centroids) const final
+    {
+        using Stride = Eigen::OuterStride<>;
+        const Eigen::Map<const Eigen::MatrixXd, 0, Stride> in(data.data(), data.rows(), data.cols(), Stride(data.outerStride()));
+        const Eigen::Map<Eigen::MatrixXd, 0, Stride> out(centroids.data(), centroids.rows(), centroids.cols(), Stride(centroids.outerStride()));
+        // exact argument types: a Map would convert to the views of the other overload just as well
+        const Eigen::Ref<const Eigen::MatrixXd> in_ref(in);
+        const Eigen::Ref<Eigen::MatrixXd> out_ref(out);
+        init(in_ref, prng, number_components, out_ref);
+    }
+};
+
+/** The same for responsibilities initialisers (reference ML/Clustering.hpp:88). */
+class EigenResponsibilitiesInitialiser : public ResponsibilitiesInitialiser {
+public:
+    virtual void init(Eigen::Ref<const Eigen::MatrixXd> data, std::default_random_engine& prng, unsigned int number_components,
+                      Eigen::Ref<Eigen::MatrixXd> responsibilities) const = 0;
+    void init(ConstMatrixRef data, std::default_random_engine& prng, unsigned int number_components, MatrixRef responsibilities) const final
+    {
+        using Stride = Eigen::OuterStride<>;
+        const Eigen::Map<const Eigen::MatrixXd, 0, Stride> in(data.data(), data.rows(), data.cols(), Stride(data.outerStride()));
+        const Eigen::Map<Eigen::MatrixXd, 0, Stride> out(responsibilities.data(), responsibilities.rows(), responsibilities.cols(),
+                                                         Stride(responsibilities.outerStride()));
+        const Eigen::Ref<const Eigen::MatrixXd> in_ref(in);
+        const Eigen::Ref<Eigen::MatrixXd> out_ref(out);
+        init(in_ref, prng, number_components, out_ref);
+    }
+};
+#endif
+
 /** K distinct samples, picked uniformly (selection sampling: ascending sample indices). */
 class Forgy : public CentroidsInitialiser {
 public:

@@ -342,6 +342,12 @@ class Data:
         check(lib.mlhip_kmeans_labels(self.ctx.handle, self._h, u32ptr(out)))
         return out
 
+    def kmeans_distances(self):
+        """Per-sample squared distance to the assigned centroid from the last assignment."""
+        out = np.empty(self.n)
+        check(lib.mlhip_kmeans_distances(self.ctx.handle, self._h, dptr(out)))
+        return out
+
     def min_squared_distances(self, centroids):
         centroids = np.ascontiguousarray(centroids, dtype=np.float64)
         out = np.empty(self.n)

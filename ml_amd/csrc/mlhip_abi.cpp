@@ -32,6 +32,7 @@ thread_local std::string g_error;
 struct InvalidArgument : std::runtime_error { using std::runtime_error::runtime_error; };
 struct NoDevice : std::runtime_error { using std::runtime_error::runtime_error; };
 struct Unsupported : std::runtime_error { using std::runtime_error::runtime_error; };
+struct DomainError : std::runtime_error { using std::runtime_error::runtime_error; };
 
 #define HIP_CHECK(expr)                                                                                   \
     do {                                                                                                  \
@@ -44,6 +45,7 @@ template <class F> int guarded(F&& f)
 {
     try { f(); return MLHIP_OK; }
     catch (const InvalidArgument& e) { g_error = e.what(); return MLHIP_E_INVALID_ARGUMENT; }
+    catch (const DomainError& e) { g_error = e.what(); return MLHIP_E_DOMAIN; }
     catch (const NoDevice& e) { g_error = e.what(); return MLHIP_E_NO_DEVICE; }
     catch (const Unsupported& e) { g_error = e.what(); return MLHIP_E_UNSUPPORTED; }
     catch (const std::exception& e) { g_error = e.what(); return MLHIP_E_RUNTIME; }
@@ -215,7 +217,7 @@ struct mlhip_data {
     DevBuf refine_shift, refine_stats;
     uint64_t refined_components = 0;   // diagnostic counter
     // K-means workspace
-    DevBuf km_labels[2], km_cent, km_partials, km_out, km_mind, km_scale, km_cnorm, km_xt_pad;
+    DevBuf km_labels[2], km_cent, km_partials, km_out, km_mind, km_probe, km_scale, km_cnorm, km_xt_pad;
     PinnedBuf km_host;
     int km_cur = 0;
     bool km_have_old = false;
@@ -223,7 +225,7 @@ struct mlhip_data {
     ~mlhip_data()
     {
         for (DevBuf* b : {&xt, &shift_dev, &lw, &lse, &ll_partials, &params_dev, &partials, &stats_dev, &resp_dev,
-                          &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_partials, &km_out, &km_mind, &km_scale, &km_cnorm, &km_xt_pad,
+                          &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_partials, &km_out, &km_mind, &km_probe, &km_scale, &km_cnorm, &km_xt_pad,
                           &refine_shift, &refine_stats})
             b->release();
         params_host.release(); stats_host.release(); km_host.release();
@@ -730,9 +732,23 @@ void ensure_km_workspace(mlhip_data* dt, int K)
         HIP_CHECK(hipMemcpyAsync(m.data(), mx.p, sizeof(double) * dt->d, hipMemcpyDeviceToHost, ctx->stream));
         ctx->sync();
         scratch.release(); mx.release();
+        // Every rank must cut its coordinates on the SAME fixed-point grid (the limb sums are added across ranks): the
+        // column maxima are exchanged through the sum hook, one slot per rank, and every rank takes the maximum.
+        if (ctx->world_size > 1) {
+            std::vector<double> all((size_t)ctx->world_size * dt->d, 0.0);
+            for (int j = 0; j < dt->d; ++j) all[(size_t)ctx->rank * dt->d + j] = m[j];
+            ctx->allreduce_host(all.data(), all.size());
+            for (int r = 0; r < ctx->world_size; ++r)
+                for (int j = 0; j < dt->d; ++j) {
+                    const double v = all[(size_t)r * dt->d + j];
+                    if (!(v <= m[j])) m[j] = v;                            // (keeps a NaN / inf of any rank)
+                }
+        }
         for (int j = 0; j < dt->d; ++j) {
+            if (!std::isfinite(m[j]))
+                throw DomainError("K-means: the data contain non-finite values (the exact fixed-point update sums need finite coordinates)");
             int e = 0;
-            if (m[j] > 0 && std::isfinite(m[j])) (void)std::frexp(m[j], &e);   // m < 2^e
+            if (m[j] > 0) (void)std::frexp(m[j], &e);   // m < 2^e
             m[j] = std::ldexp(1.0, 94 - e);
         }
         dt->km_scale.reserve(sizeof(double) * dt->d);
@@ -750,7 +766,7 @@ void ensure_km_workspace(mlhip_data* dt, int K)
 }
 
 /// Assignment (+ optional accumulation); leaves all-reduced [inertia, changed, counts, sums] in km_host.
-void run_kmeans(mlhip_data* dt, int K, const double* centroids, bool accumulate)
+void run_kmeans(mlhip_data* dt, int K, const double* centroids, bool accumulate, double* min_dist_out = nullptr)
 {
     mlhip_ctx* ctx = dt->ctx;
     ensure_km_workspace(dt, K);
@@ -782,7 +798,7 @@ void run_kmeans(mlhip_data* dt, int K, const double* centroids, bool accumulate)
     a.labels = dt->km_labels[nxt].as<uint32_t>();
     a.old_labels = dt->km_labels[dt->km_cur].as<uint32_t>();
     a.have_old = dt->km_have_old ? 1 : 0;
-    a.min_dist = dt->km_mind.as<double>();
+    a.min_dist = min_dist_out ? min_dist_out : dt->km_mind.as<double>();   // a distance-only probe writes elsewhere
     a.accumulate = accumulate ? 1 : 0;
     a.partials = dt->km_partials.as<double>(); a.partials_capacity = dt->km_partials.bytes / sizeof(double);
     a.cnorm = dt->km_cnorm.as<double>();
@@ -1401,17 +1417,19 @@ int mlhip_min_squared_distances(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, co
     return guarded([&] {
         check_em_args(ctx, data, K);
         require(centroids && (dist2 || data->n == 0), "null argument");
-        // Must not disturb the label history used for n_changed: run on a scratch copy of the state.
+        // Must disturb neither the label history used for n_changed nor the per-sample distances of the last assignment
+        // (mlhip_kmeans_distances): the labels go to the spare buffer, the distances to a buffer of their own.
         const int cur = data->km_cur;
         const bool have = data->km_have_old;
-        run_kmeans(data, (int)K, centroids, false);
+        data->km_probe.reserve(sizeof(double) * data->n_pad);
+        run_kmeans(data, (int)K, centroids, false, data->km_probe.as<double>());
         if (have) {
             // The assignment wrote labels into the *other* buffer; keep the previous labels current.
             data->km_cur = cur;
         }
         data->km_have_old = have;
         ctx->sync();
-        download_columns(ctx, reinterpret_cast<char*>(dist2), 0, data->km_mind.as<char>(), 0, sizeof(double) * data->n, 1);
+        download_columns(ctx, reinterpret_cast<char*>(dist2), 0, data->km_probe.as<char>(), 0, sizeof(double) * data->n, 1);
     });
 }
 

@@ -200,9 +200,11 @@ int mlpp_calculate_XXt_beta(const double* X, uint64_t n, uint32_t q, const doubl
 {
     return guarded([&] {
         need(X); need(y); need(lambda); need(XXt); need(beta);
+        LDLT decomposition;
         const VectorXd b = LinearRegression::calculate_XXt_beta(ConstMatrixRef(X, q, static_cast<Index>(n)),
                                                                 ConstVectorRef(y, static_cast<Index>(ylen)),
-                                                                MatrixRef(XXt, q, q, q), ConstVectorRef(lambda, lambda_len));
+                                                                MatrixRef(XXt, q, q, q), decomposition,
+                                                                ConstVectorRef(lambda, lambda_len));
         std::copy_n(b.data(), b.size(), beta);
     });
 }

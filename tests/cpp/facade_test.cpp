@@ -13,6 +13,7 @@
 #include "ML/EM.hpp"
 #include "ML/KMeans.hpp"
 #include "ML/LinearAlgebra.hpp"
+#include "ML/LinearRegression.hpp"
 
 static int failures = 0;
 #define CHECK(cond) do { if (!(cond)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); ++failures; } } while (0)
@@ -91,6 +92,70 @@ static void host_checks()
     CHECK_THROWS(ml::LinearAlgebra::add_a_xxT(x2, A33, 0.6), std::invalid_argument);
 }
 
+// User-defined extension points (reference ML/Clustering.hpp:58-89): subclasses written by the library's user.
+struct EveryOtherSample : ml::Clustering::CentroidsInitialiser {
+    void init(ml::ConstMatrixRef data, std::default_random_engine&, unsigned int number_components, ml::MatrixRef centroids) const override
+    {
+        for (unsigned k = 0; k < number_components; ++k)
+            for (ml::Index j = 0; j < data.rows(); ++j) centroids(j, k) = data(j, 2 * k);
+    }
+};
+struct SoftByFirstCoordinate : ml::Clustering::ResponsibilitiesInitialiser {
+    mutable unsigned calls = 0;
+    void init(ml::ConstMatrixRef data, std::default_random_engine& prng, unsigned int number_components, ml::MatrixRef r) const override
+    {
+        ++calls;
+        std::uniform_real_distribution<double> u(0.05, 0.15);
+        for (ml::Index i = 0; i < data.cols(); ++i) {
+            const unsigned home = data(0, i) > -0.4 ? 0u : 1u;         // the two true clusters of gpu_checks()
+            const double leak = u(prng);
+            for (unsigned k = 0; k < number_components; ++k)
+                r(i, k) = k == home ? 1.0 - leak * (number_components - 1) : leak;
+        }
+    }
+};
+
+// ml::LDLT (stands in for Eigen::LDLT in calculate_XXt_beta's signature): positive definite, semi-definite and negative cases
+static void ldlt_checks()
+{
+    std::default_random_engine rng(9);
+    std::normal_distribution<double> nrm;
+    const int n = 7;
+    MatrixXd B(n, n), A(n, n);
+    for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) B(i, j) = nrm(rng);
+    for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) { double t = 0; for (int l = 0; l < n; ++l) t += B(i, l) * B(j, l); A(i, j) = t; }
+    ml::LDLT ldlt(A);
+    CHECK(ldlt.isPositive() && !ldlt.isNegative());
+    const MatrixXd R = ldlt.reconstructedMatrix();
+    double err = 0, norm = 0;
+    for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) { err += std::pow(R(i, j) - A(i, j), 2); norm += A(i, j) * A(i, j); }
+    CHECK(std::sqrt(err) <= 1e-13 * std::sqrt(norm));
+    VectorXd x0(n), b(n);
+    for (int i = 0; i < n; ++i) x0[i] = i - 2.5;
+    for (int i = 0; i < n; ++i) { double t = 0; for (int j = 0; j < n; ++j) t += A(i, j) * x0[j]; b[i] = t; }
+    const VectorXd x = ldlt.solve(b);
+    for (int i = 0; i < n; ++i) CHECK(std::abs(x[i] - x0[i]) <= 1e-9);
+    // the largest diagonal entry is pivoted to the front
+    double biggest = 0;
+    for (int i = 0; i < n; ++i) biggest = std::max(biggest, A(i, i));
+    CHECK(A(ldlt.transpositions()[0], ldlt.transpositions()[0]) == biggest);
+    // rank-deficient (two identical features, no ridge): still a solution of the normal equations
+    MatrixXd S(3, 3);
+    const double sv[9] = {2, 2, 1, 2, 2, 1, 1, 1, 3};
+    std::memcpy(S.data(), sv, sizeof(sv));
+    ml::LDLT semi(S);
+    CHECK(semi.isPositive());
+    VectorXd rhs(3);
+    rhs[0] = 4; rhs[1] = 4; rhs[2] = 5;                              // = S * (1, 1, 1)
+    const VectorXd z = semi.solve(rhs);
+    for (int i = 0; i < 3; ++i) { double t = 0; for (int j = 0; j < 3; ++j) t += S(i, j) * z[j]; CHECK(std::abs(t - rhs[i]) <= 1e-12); }
+    MatrixXd N(A);
+    for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) N(i, j) = -A(i, j);
+    CHECK(ml::LDLT(N).isNegative());
+    CHECK_THROWS(ml::LDLT(MatrixXd(2, 3)), std::invalid_argument);
+    CHECK_THROWS(ldlt.solve(VectorXd(n + 1)), std::invalid_argument);
+}
+
 // Tests/test_EM.cpp:8-104 and Tests/test_KMeans.cpp:8-106 (same libstdc++ draws, same invariants)
 static void gpu_checks()
 {
@@ -157,6 +222,66 @@ static void gpu_checks()
     km.set_number_initialisations(3);
     CHECK(km.fit(data));
     CHECK(km.inertia() <= inertia);
+
+    // user-defined initialisers through both start modes of EM::fit (reference ML/EM.cpp:120-135) and through KMeans
+    auto soft = std::make_shared<SoftByFirstCoordinate>();
+    ml::EM em_user(K);
+    em_user.set_absolute_tolerance(1e-8);
+    em_user.set_relative_tolerance(1e-8);
+    em_user.set_maximum_steps(100);
+    em_user.set_responsibilities_initialiser(soft);
+    em_user.set_maximise_first(true);
+    CHECK(em_user.fit(data));
+    CHECK(soft->calls == 1);
+    CHECK(std::abs(em_user.log_likelihood() - em.log_likelihood()) <= 1e-6 * std::abs(em.log_likelihood()));
+    for (unsigned i = 0; i < n; ++i) CHECK((em_user.labels()[i] == em_user.labels()[0]) == (truth[i] == truth[0]));
+    ml::EM em_means(K);
+    em_means.set_absolute_tolerance(1e-8);
+    em_means.set_relative_tolerance(1e-8);
+    em_means.set_maximum_steps(100);
+    em_means.set_means_initialiser(std::make_shared<EveryOtherSample>());
+    CHECK(em_means.fit(data));
+    CHECK(std::abs(em_means.log_likelihood() - em.log_likelihood()) <= 1e-6 * std::abs(em.log_likelihood()));
+    ml::Clustering::KMeans km_user(K);
+    km_user.set_centroids_initialiser(std::make_shared<EveryOtherSample>());
+    CHECK(km_user.fit(data));
+    CHECK(std::abs(km_user.inertia() - inertia) <= 1e-12 * inertia);
+
+    // calculate_XXt_beta in the reference's 5-argument shape (reference ML/LinearRegression.cpp:201-230)
+    const unsigned q = 5, N = 2000;
+    MatrixXd X(q, N);
+    VectorXd y(N), lambda(q), beta_true(q);
+    for (unsigned j = 0; j < q; ++j) { beta_true[j] = 0.5 * j - 1.0; lambda[j] = 0.0; }
+    for (unsigned i = 0; i < N; ++i) {
+        double t = 0;
+        for (unsigned j = 0; j < q; ++j) { X(j, i) = standard_normal(rng); t += beta_true[j] * X(j, i); }
+        y[i] = t + 1e-3 * standard_normal(rng);
+    }
+    MatrixXd XXt(q, q);
+    ml::LDLT decomposition;
+    const VectorXd beta = ml::LinearRegression::calculate_XXt_beta(X, y, XXt, decomposition, lambda);
+    for (unsigned j = 0; j < q; ++j) CHECK(std::abs(beta[j] - beta_true[j]) <= 1e-3);
+    CHECK(decomposition.rows() == q && decomposition.isPositive());
+    VectorXd e0(q);
+    e0.setZero();
+    e0[0] = 1;
+    const VectorXd inv_col = decomposition.solve(e0);               // what ols / ridge reuse it for: (X X^T)^-1 columns
+    double t0 = 0;
+    for (unsigned j = 0; j < q; ++j) t0 += XXt(0, j) * inv_col[j];
+    CHECK(std::abs(t0 - 1.0) <= 1e-10);
+    // collinear features, no ridge: the reference's pivoted LDLT still returns a least-squares solution
+    for (unsigned i = 0; i < N; ++i) X(1, i) = X(0, i);
+    const VectorXd beta2 = ml::LinearRegression::calculate_XXt_beta(X, y, XXt, decomposition, lambda);
+    double resid = 0, total = 0;
+    for (unsigned i = 0; i < N; ++i) {
+        double t = 0;
+        for (unsigned j = 0; j < q; ++j) t += beta2[j] * X(j, i);
+        resid += std::pow(y[i] - t, 2);
+        total += y[i] * y[i];
+    }
+    CHECK(std::isfinite(resid) && resid < total);
+    lambda[2] = -1;
+    CHECK_THROWS(ml::LinearRegression::calculate_XXt_beta(X, y, XXt, decomposition, lambda), std::domain_error);
 }
 
 int main(int argc, char** argv)
@@ -164,6 +289,7 @@ int main(int argc, char** argv)
     const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
     try {
         host_checks();
+        ldlt_checks();
         if (gpu) gpu_checks();
     } catch (const std::exception& e) {
         std::printf("FAIL unexpected exception: %s\n", e.what());

@@ -19,6 +19,34 @@ def _build():
                            "-Wl,-rpath," + os.path.join(ROOT, "ml_amd"), "-Wl,-rpath,/opt/rocm/lib"])
 
 
+ADAPTER = os.path.join(ROOT, "tests", "cpp", "eigen_adapter_test")
+
+
+def _build_adapter():
+    """The `#ifdef MLHIP_HAVE_EIGEN` branches of include/ML/*.hpp compiled against tests/cpp/eigen_shim (a stand-in: the real
+    Eigen is absent from this environment -- INTEGRATION.md says so plainly)."""
+    src = os.path.join(ROOT, "tests", "cpp", "eigen_adapter_test.cpp")
+    lib = os.path.join(ROOT, "ml_amd", "libmlhip.so")
+    if os.path.exists(ADAPTER) and os.path.getmtime(ADAPTER) > max(os.path.getmtime(src), os.path.getmtime(lib)):
+        return
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "tests", "cpp", "eigen_shim"),
+                           "-I", os.path.join(ROOT, "include"), src, "-o", ADAPTER, "-L", os.path.join(ROOT, "ml_amd"), "-lmlhip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "ml_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+
+
+def test_eigen_branches_of_the_headers_compile_and_run_host_paths():
+    _build_adapter()
+    out = subprocess.run([ADAPTER, "host"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_eigen_branches_full_fits():
+    _build_adapter()
+    out = subprocess.run([ADAPTER, "gpu"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
 def test_cpp_facade_host_paths():
     _build()
     out = subprocess.run([EXE, "host"], capture_output=True, text=True)

@@ -376,3 +376,30 @@ def test_fused_small_shape_step_agrees_with_two_kernel_path(ctx, oracle, d, K, n
     em.maximisation_step(X)
     assert relerr(a[1], em.mixing_probabilities) < 1e-11 and relerr(a[2], em.means) < 1e-11
     assert relerr(a[3], em.covariances) < 1e-9
+
+
+def test_distance_probe_leaves_the_last_assignment_alone(ctx):
+    """mlhip_min_squared_distances (the K-means++ weights pass) must not overwrite what mlhip_kmeans_distances / labels report
+    for the last assignment."""
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((5000, 8))
+    C = rng.standard_normal((6, 8))
+    dt = _data(ctx, X)
+    dt.kmeans_step(C)
+    before, labels = dt.kmeans_distances(), dt.kmeans_labels()
+    probe = dt.min_squared_distances(C[:1] + 3.0)
+    assert np.array_equal(probe, ((X - (C[:1] + 3.0)) ** 2).sum(axis=1)) or np.allclose(probe, ((X - (C[:1] + 3.0)) ** 2).sum(axis=1), rtol=1e-14)
+    assert np.array_equal(dt.kmeans_distances(), before)
+    assert np.array_equal(dt.kmeans_labels(), labels)
+    _, changed = dt.kmeans_assign(C)
+    assert changed == 0                                     # the label history is intact too
+    dt.close()
+
+
+def test_kmeans_refuses_non_finite_data(ctx):
+    X = np.random.default_rng(5).standard_normal((1000, 4))
+    X[17, 2] = np.inf
+    dt = _data(ctx, X)
+    with pytest.raises(ValueError):
+        dt.kmeans_step(np.zeros((3, 4)))
+    dt.close()
