@@ -26,6 +26,10 @@ struct EstepArgs {
     double* lw; size_t ldr;                                 // out: unnormalised log-responsibilities [K][ldr]
     double* lse;                                            // out: log sum_k exp(lw) per sample
     double* ll_partials; int n_ll_partials;                 // out: per-block sums of lse (grid size)
+    // em_estep_mfma4 only:
+    const double* shift;                                    // device, D doubles (zero-padded): the fold's centre
+    int fold;                                               // records carry -W (mu - shift) instead of the mean (d <= 32)
+    int with_lse;                                           // 0: write lw only (the statistics kernel normalises)
 };
 /// Returns the grid size used (= number of ll partials written), or <0 if D is not instantiated.
 int launch_em_estep(const EstepArgs& a, hipStream_t stream);
@@ -38,7 +42,9 @@ int launch_em_estep_mfma4(const EstepArgs& a, int num_cus, hipStream_t stream);
 
 enum MstatsMode : int {
     kFromLogResp = 0,   // r = exp(lw - lse)          (after an E-step)
-    kFromResp = 1       // r = lw                     (plain responsibilities: caller-given, one-hot, or all ones)
+    kFromResp = 1,      // r = lw                     (plain responsibilities: caller-given, one-hot, or all ones)
+    kFromLogRespSelfNorm = 2   // r = e_k / sum_k e_k with the normalisation done by the statistics kernel itself (wide kernel, one
+                               // row-block group); launch_em_reduce then also finishes lse = max + log(sum) and the ll partials
 };
 struct MstatsArgs {
     const double* xt; size_t ldx; uint32_t n; int d;        // d = true dimension
@@ -47,7 +53,11 @@ struct MstatsArgs {
     double* partials; size_t partials_capacity;              // scratch (doubles)
     const double* ll_partials; int n_ll_partials;            // summed into stats[K*F] (may be null/0)
     double* stats;                                           // out: device, K*F + 1 doubles
+    double* ll_scratch;                                      // kFromLogRespSelfNorm: >= 1024 doubles for the ll partials
+    double* lse_out; double* ll_out;                         // kFromLogRespSelfNorm: per-sample max (-> lse) and exp-sum (n_pad each)
 };
+/// Whether the statistics kernel chosen for (d, K) can normalise log-responsibilities itself (mode kFromLogRespSelfNorm).
+bool em_mstats_self_norm_supported(int d, int K, int num_cus);
 /// Fused E-step + statistics for small shapes (em_fused_small.hip): params are the estep_param_stride(D) records.
 struct FusedArgs {
     const double* xt; size_t ldx; uint32_t n; int d;

@@ -15,6 +15,7 @@
 // running sum folded once at the end. No atomics; per-workgroup partials are combined in fixed order by em_reduce_kernel.
 // Bound: ~3d VALU + one exp per (sample, component) against 8d bytes per sample -- VALU/latency-bound at d = K = 16, not HBM.
 #include "em_mstats_common.hpp"
+#include "exp_nonpos.hpp"
 
 namespace mlhip {
 namespace mstats {
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256, (D <= 16 && RBT <= 2) ? 2 : 1) void em_diag_ke
                 if (k4 < Kt) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const double e = exp(lwv[s][k4 + u] - m[s]);       // exp(-inf) = 0 for the neutral tail
+                        const double e = exp_nonpos(lwv[s][k4 + u] - m[s]);       // exp(-inf) = 0 for the neutral tail
                         lwv[s][k4 + u] = e;
                         sum += e;
                     }

@@ -13,6 +13,7 @@
 // The row normalisation r_ik = exp(lw_ik - lse_i) (:214-218) is applied by the consumers
 // (em_mstats.hip, em_post.hip), so the N x K block is written once here and read once there.
 #include "device.hpp"
+#include "exp_nonpos.hpp"
 
 namespace mlhip {
 namespace {
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256) void em_estep_kernel(const double* __restrict_
             const double lw = __builtin_fma(-0.5, q, p[PS - 1]);
             lw_out[(size_t)k * ldr + i] = lw;
             // online log-sum-exp with a single exp per component
-            const double e = exp(-fabs(lw - m));
+            const double e = exp_nonpos(-fabs(lw - m));
             const bool up = lw > m;
             s = up ? __builtin_fma(s, e, 1.0) : s + e;
             m = up ? lw : m;

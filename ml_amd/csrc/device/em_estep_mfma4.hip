@@ -14,9 +14,20 @@
 // With j + 4b = sample-in-16 this is the B / D layout of the 16x16x4 kernel (lane & 15 = sample, lane >> 4 = k or row),
 // so the coordinates stay in VGPRs as xb[column quad][sample block], every accumulator is ONE double per lane
 // (acc[sample block][row quad]) and the |y|^2 reduce-scatter / log-domain epilogue are unchanged.
+//
+// Two compile-time options take VALU work off the fp64 pipe the MFMAs share (round 1: ~118 VALU operations per 64 samples
+// and component next to 144 MFMAs):
+//   FOLD  y = W (x - s) - W (mu - s) with the second term as the accumulator initialiser (s = the data's shift, x - s formed
+//         once per sample group): no per-component subtraction of the mean (32 operations). It costs log2(|W (mu - s)|) bits
+//         of y, so the host only selects it while every |W_k (mu_k - s)| entry is below a limit (layout.hpp
+//         kEstepFoldLimit); beyond that the exact form (x - mu_k first) runs.
+//   !LSE  no online log-sum-exp, only lw is written: the statistics kernel normalises a sample's K log-responsibilities
+//         itself while staging its tile (em_mstats_wide.hip, one exp per (sample, component) instead of one in each
+//         kernel) and produces lse and the log-likelihood sum. Used whenever K fits one row-block group of that kernel.
 #include <cstdlib>
 
 #include "device.hpp"
+#include "exp_nonpos.hpp"
 
 namespace mlhip {
 namespace {
@@ -71,10 +82,11 @@ __device__ __forceinline__ double reduce_scatter_groups(double v0, double v1, do
 /// per component sweep for SB = 4 and 2 (128 for SB = 1); the component record is staged once per sweep.
 template <int SB> constexpr int default_waves() { return SB == 1 ? 8 : 16 / SB; }
 
-template <int D, int SB, int NW = default_waves<SB>()>
+template <int D, int SB, bool FOLD, bool LSE, int NW = default_waves<SB>()>
 __global__ __launch_bounds__(64 * NW, D <= 32 ? 8 / SB : 2) void em_estep_mfma4_kernel(
     const double* __restrict__ xt, size_t ldx, uint32_t n, uint32_t n_groups, const double* __restrict__ params, int K,
-    double* __restrict__ lw_out, size_t ldr, double* __restrict__ lse_out, double* __restrict__ ll_partials)
+    const double* __restrict__ shift, double* __restrict__ lw_out, size_t ldr, double* __restrict__ lse_out,
+    double* __restrict__ ll_partials)
 {
     using B = Blocks<D>;
     constexpr int Q = B::Q, NB = B::NB, PS = B::PS;
@@ -101,6 +113,14 @@ __global__ __launch_bounds__(64 * NW, D <= 32 ? 8 / SB : 2) void em_estep_mfma4_
         for (int C = 0; C < Q; ++C)
 #pragma unroll
             for (int sb = 0; sb < SB; ++sb) xb[C][sb] = xt[(size_t)(4 * C + g) * ldx + base + 16 * sb + s];
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int C = 0; C < Q; ++C) {
+                const double sh = shift[4 * C + g];       // zero-padded to D entries
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb) xb[C][sb] -= sh;
+            }
+        }
 
         double m = -__builtin_inf(), ssum = 0.0;
 
@@ -128,19 +148,22 @@ __global__ __launch_bounds__(64 * NW, D <= 32 ? 8 / SB : 2) void em_estep_mfma4_
             // after unrolling, so the accumulators and the window stay in registers.
 #pragma unroll
             for (int C = 0; C < Q; ++C) {
-                const double mu = rec[NB * 16 + 4 * C + g];
+                // the record's vector slot: the mean (exact form) or -W (mu - shift) (FOLD: the accumulator initialiser)
+                const double mu = FOLD ? 0.0 : rec[NB * 16 + 4 * C + g];
 #pragma unroll
                 for (int R = C; R < Q; ++R) {
                     const int t = C * Q - C * (C - 1) / 2 + (R - C);     // step index in column-quad-major order
                     const double a = aw[t % W];
                     if (R == C) {
 #pragma unroll
-                        for (int sb = 0; sb < SB; ++sb) z[sb] = xb[C][sb] - mu;
+                        for (int sb = 0; sb < SB; ++sb) z[sb] = FOLD ? xb[C][sb] : xb[C][sb] - mu;
                     }
                     if (t + W < NB) aw[t % W] = rec[(t + W) * 16 + aoff];   // refill the slot (LDS broadcast read)
+                    double init = 0.0;
+                    if constexpr (FOLD) { if (C == 0) init = rec[NB * 16 + 4 * R + g]; }
 #pragma unroll
                     for (int sb = 0; sb < SB; ++sb)
-                        acc[sb][R] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, z[sb], C == 0 ? 0.0 : acc[sb][R], 0, 0, 0);
+                        acc[sb][R] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, z[sb], C == 0 ? init : acc[sb][R], 0, 0, 0);
                     // Pin the block order (column-quad major, the sample blocks back to back); see em_estep_mfma.hip.
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -174,37 +197,43 @@ __global__ __launch_bounds__(64 * NW, D <= 32 ? 8 / SB : 2) void em_estep_mfma4_
             }
             const double lw = __builtin_fma(-0.5, q, coef);
             if (owner) lw_out[(size_t)k * ldr + base + lane] = lw;
-            // exp(t) is exactly 0 in fp64 for t < -745.2: when that holds for the whole wave the update would add 0 to
-            // every ssum and leave every m unchanged, so it is skipped (bit-identical result, one exp saved).
-            if (!__all(lw - m < -746.0)) {
-                const double e = exp(-fabs(lw - m));
-                const bool up = lw > m;
-                ssum = up ? __builtin_fma(ssum, e, 1.0) : ssum + e;
-                m = up ? lw : m;
+            if constexpr (LSE) {
+                // exp(t) is exactly 0 in fp64 for t < -745.2: when that holds for the whole wave the update would add 0 to
+                // every ssum and leave every m unchanged, so it is skipped (bit-identical result, one exp saved).
+                if (!__all(lw - m < -746.0)) {
+                    const double e = exp_nonpos(-fabs(lw - m));
+                    const bool up = lw > m;
+                    ssum = up ? __builtin_fma(ssum, e, 1.0) : ssum + e;
+                    m = up ? lw : m;
+                }
             }
             // publish record k+1 in the other buffer: nobody reads it now (last read during k-1, before this
             // iteration's barrier), the next iteration's barrier makes it visible.
 #pragma unroll
             for (int it = 0; it < NLD; ++it) recs[(k + 1) & 1][tid + NT * it] = stage[it];
         }
-        const double lse = m + log(ssum);
-        if (owner) {
-            lse_out[base + lane] = lse;
-            if (base + lane < n) ll_acc += lse;
+        if constexpr (LSE) {
+            const double lse = m + log(ssum);
+            if (owner) {
+                lse_out[base + lane] = lse;
+                if (base + lane < n) ll_acc += lse;
+            }
         }
     }
-    ll_acc = wave_sum(ll_acc);
-    if (lane == 0) red[wave] = ll_acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
+    if constexpr (LSE) {
+        ll_acc = wave_sum(ll_acc);
+        if (lane == 0) red[wave] = ll_acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
 #pragma unroll
-        for (int w = 0; w < NWV; ++w) t += red[w];
-        ll_partials[blockIdx.x] = t;
+            for (int w = 0; w < NWV; ++w) t += red[w];
+            ll_partials[blockIdx.x] = t;
+        }
     }
 }
 
-template <int D, int SB, int NW = default_waves<SB>()>
+template <int D, int SB, bool FOLD, bool LSE, int NW = default_waves<SB>()>
 int launch_sb(const EstepArgs& a, int num_cus, hipStream_t stream)
 {
     // the waves of a workgroup share barriers inside the component loop: a workgroup sweep must cover a whole number of
@@ -220,24 +249,28 @@ int launch_sb(const EstepArgs& a, int num_cus, hipStream_t stream)
     const uint32_t cap = (uint32_t)num_cus * 2 * default_waves<SB>() / NW;   // the CU's resident waves, persistent
     if (grid > cap) grid = cap;
     if (grid > (uint32_t)a.n_ll_partials) grid = (uint32_t)a.n_ll_partials;
-    hipLaunchKernelGGL((em_estep_mfma4_kernel<D, SB, NW>), dim3(grid), dim3(NT), smem, stream, a.xt, a.ldx, a.n, n_groups, a.params,
-                       a.K, a.lw, a.ldr, a.lse, a.ll_partials);
+    hipLaunchKernelGGL((em_estep_mfma4_kernel<D, SB, FOLD, LSE, NW>), dim3(grid), dim3(NT), smem, stream, a.xt, a.ldx, a.n, n_groups,
+                       a.params, a.K, a.shift, a.lw, a.ldr, a.lse, a.ll_partials);
     return (int)grid;
+}
+
+template <int D, int SB>
+int launch_v(const EstepArgs& a, int num_cus, hipStream_t stream)
+{
+    if constexpr (D <= kRegDim) {
+        if (a.fold) return a.with_lse ? launch_sb<D, SB, true, true>(a, num_cus, stream) : launch_sb<D, SB, true, false>(a, num_cus, stream);
+    }
+    return a.with_lse ? launch_sb<D, SB, false, true>(a, num_cus, stream) : launch_sb<D, SB, false, false>(a, num_cus, stream);
 }
 
 template <int D>
 int launch_t(const EstepArgs& a, int num_cus, hipStream_t stream)
 {
-    // MLHIP_ESTEP_SB=2 selects the 32-samples-per-wave variant (A/B experiments); default 4.
-    static const int sb = [] { const char* e = std::getenv("MLHIP_ESTEP_SB"); return (e && e[0] == '2') ? 2 : 4; }();
-    if constexpr (D > 64) {
-        return launch_sb<D, 1>(a, num_cus, stream);     // one sample block per wave (16 samples): 2D doubles per lane
-    } else if constexpr (D > 32) {
-        // 2 sample blocks per wave: D coordinate + D accumulator doubles per lane pair do not fit otherwise
-        return launch_sb<D, 2>(a, num_cus, stream);
-    } else {
-        return sb == 2 ? launch_sb<D, 2>(a, num_cus, stream) : launch_sb<D, 4>(a, num_cus, stream);
-    }
+    // 64 < d: one sample block per wave (16 samples): 2D doubles per lane; 32 < d <= 64: two (D coordinate + D accumulator
+    // doubles per lane pair do not fit otherwise); d <= 32: four (64 samples per wave)
+    if constexpr (D > 64) return launch_v<D, 1>(a, num_cus, stream);
+    else if constexpr (D > 32) return launch_v<D, 2>(a, num_cus, stream);
+    else return launch_v<D, 4>(a, num_cus, stream);
 }
 
 static_assert(Blocks<32>::NB == 36 && Blocks<12>::NB == 6, "block count");

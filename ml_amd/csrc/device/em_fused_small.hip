@@ -15,6 +15,7 @@
 // HBM traffic per iteration: X once, LSE once. The log-responsibility block is produced on demand (labels /
 // responsibilities after the fit) by the ordinary E-step kernel from the same parameter records.
 #include "em_mstats_common.hpp"
+#include "exp_nonpos.hpp"
 
 namespace mlhip {
 namespace mstats {
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256, (D <= 4 && RBW <= 2) ? 3 : 2) void em_fused_sm
             if (k4 < K) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const double e = exp(lwv[k4 + u] - m);       // exp(-inf) = 0 for the clamped tail
+                    const double e = exp_nonpos(lwv[k4 + u] - m);       // exp(-inf) = 0 for the clamped tail
                     lwv[k4 + u] = e;
                     s += e;
                     __builtin_amdgcn_sched_barrier(0);

@@ -77,6 +77,28 @@ __global__ __launch_bounds__(256) void em_reduce_kernel(const double* __restrict
 }
 
 
+/// After a self-normalising statistics pass: lse[i] holds max_k lw_ik, esum[i] the sum of exp(lw_ik - max). Finishes
+/// lse[i] = max + log(esum) in place and leaves one log-likelihood partial per block (fixed-order tree: reproducible).
+__global__ __launch_bounds__(256) void em_lse_finish_kernel(double* __restrict__ lse, const double* __restrict__ esum, uint32_t n,
+                                                              uint32_t n_pad, double* __restrict__ ll_partials)
+{
+    __shared__ double red[256];
+    double acc = 0.0;
+    (void)n_pad;                                    // (only the live samples were written by the statistics kernel's tiles)
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const double l = lse[i] + log(esum[i]);
+        lse[i] = l;
+        acc += l;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ll_partials[blockIdx.x] = red[0];
+}
+
 }  // namespace
 
 namespace mstats {
@@ -131,6 +153,12 @@ Plan make_plan(int d, int K, int num_cus)
 
 }  // namespace mstats
 
+bool em_mstats_self_norm_supported(int d, int K, int num_cus)
+{
+    const Plan p = make_plan(d, K, num_cus);
+    return p.wide && p.n_rbg == 1;      // all K components in one workgroup (K <= 16 RBW): see em_mstats_wide.hip, EXP == 2
+}
+
 size_t em_mstats_scratch_doubles(int d, int K, int num_cus)
 {
     const Plan p = make_plan(d, K, num_cus);
@@ -153,6 +181,7 @@ int launch_em_mstats(const MstatsArgs& a, int num_cus, hipStream_t stream)
     int grid_x = p.grid_x;
     if ((uint32_t)grid_x > n_tiles) grid_x = (int)(n_tiles ? n_tiles : 1);
     if ((size_t)grid_x * p.KP * p.FP > a.partials_capacity) return -2;
+    if (a.mode == kFromLogRespSelfNorm && !(p.wide && p.n_rbg == 1)) return -3;
     if (p.wide) return launch_wide(a, p, grid_x, stream);
     if (p.small) return launch_small(a, p, grid_x, stream);
 #ifdef MLHIP_EXPERIMENTS
@@ -177,8 +206,17 @@ void launch_em_reduce(const MstatsArgs& a, int num_cus, int grid_x, hipStream_t 
     const int F = stats_count(a.d);
     const int total = a.K * F;
     const int red_blocks = (total + 255) / 256 + 1;
+    // a self-normalising pass left (max, exp-sum) per sample: finish lse and produce the log-likelihood partials first
+    const double* ll = a.ll_partials;
+    int n_ll = a.n_ll_partials;
+    if (a.mode == kFromLogRespSelfNorm) {
+        const uint32_t n_pad = padded_samples(a.n);
+        n_ll = (int)((n_pad / 256 < 1024u) ? n_pad / 256 : 1024u);
+        hipLaunchKernelGGL(em_lse_finish_kernel, dim3(n_ll), dim3(256), 0, stream, a.lse_out, a.ll_out, a.n, n_pad, a.ll_scratch);
+        ll = a.ll_scratch;
+    }
     hipLaunchKernelGGL(em_reduce_kernel, dim3(red_blocks), dim3(256), 0, stream, a.partials, grid_x, p.KP, p.FP, a.K, F,
-                       a.ll_partials, a.n_ll_partials, a.stats);
+                       ll, n_ll, a.stats);
 }
 
 void launch_em_reduce_blocks(const double* partials, int n_partials, int KP, int FP, int K, int F, const double* ll_partials,

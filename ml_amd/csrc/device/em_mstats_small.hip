@@ -10,6 +10,7 @@
 // The four waves of a workgroup fold their accumulators into the workgroup's partial block one after the other (fixed
 // order: the result is bit-reproducible).
 #include "em_mstats_common.hpp"
+#include "exp_nonpos.hpp"
 
 namespace mlhip {
 namespace mstats {
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void em_mstats_small_kernel(
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         double r = rv[it4 + u];
-                        if (EXP) r = exp(r - lcur);
+                        if (EXP) r = exp_nonpos(r - lcur);
                         Rw[lane * RSS + it4 + u] = (live && (rb0 + rb) * 16 + it4 + u < K) ? r : 0.0;
                     }
                 } else {

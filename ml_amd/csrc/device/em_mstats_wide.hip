@@ -9,8 +9,17 @@
 //     RBW x CBW <= 4 x 5 accumulator tiles, so every generated B operand (one multiply, two LDS reads) feeds 4 MFMAs;
 //   * software pipeline over tiles: global loads of tile t+1 are issued (unconditionally, clamped addresses) right after
 //     the barrier and stay in flight during the MFMA phase of tile t; LDS tiles are double-buffered -> one barrier per
-//     tile.
+//     tile;
+//   * responsibilities come in one of three forms (template EXP): 0 = plain r (caller-given, one-hot, all ones), 1 = log-
+//     responsibilities with the per-sample log-sum-exp given (r = exp(lw - lse)), 2 = log-responsibilities only: the kernel
+//     NORMALISES THEM ITSELF while staging (the E-step then needs no exp at all: one exp per (sample, component) in the whole
+//     iteration instead of two). For that the staging roles are laid out so that the K values of one sample sit in ONE wave
+//     (lane = sample-in-8 + 8 * component group, each thread 2 RBW consecutive components): max and sum over them are three
+//     xor-shuffle steps inside the wave, no extra barrier; lanes of component group 0 write the sample's maximum and the sum of
+//     its exponentials, which a small follow-up kernel (em_lse_finish_kernel, em_mstats.hip) turns into lse and the log-
+//     likelihood partials. Needs all K components in this workgroup (a single row-block group, K <= 64).
 #include "em_mstats_common.hpp"
+#include "exp_nonpos.hpp"
 
 namespace mlhip {
 namespace mstats {
@@ -18,11 +27,11 @@ namespace {
 
 constexpr int NW = 8;   // waves per workgroup
 
-template <int RBW, int CBW, bool EXP, int DM>
+template <int RBW, int CBW, int EXP, int DM>
 __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
     const double* __restrict__ xt, size_t ldx, uint32_t n, int d, int D, const double* __restrict__ shift,
     const double* __restrict__ lw, size_t ldr, const double* __restrict__ lse, int K, int n_rbg, int CB_total,
-    double* __restrict__ partials, int KP, int FP)
+    double* __restrict__ partials, int KP, int FP, double* __restrict__ lse_out, double* __restrict__ ll_out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int RS = RBW * 16 + 1;     // odd row stride of the responsibility tile
@@ -58,25 +67,68 @@ __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
 #pragma unroll
         for (int c = 0; c < CBW; ++c) acc[r][c] = d4{0.0, 0.0, 0.0, 0.0};
 
-    // staging role: sample sS of the tile, rows wave, wave+8, ...
+    // staging role: sample sS of the tile, rows wave, wave+8, ... For EXP == 2 the responsibilities have their own role:
+    // sample sR = 8 wave + (lane & 7), components NRV cg + it with cg = lane >> 3 -- one wave holds all K values of its 8 samples
+    // (contiguous components per thread: with the odd row stride RS the 16 lanes of an LDS write phase then hit 16 different
+    // bank pairs; the interleaved assignment cg + 8 it collides up to 8-fold and cost 1 ms at the headline shape).
     const int sS = lane;
+    const int sR = EXP == 2 ? 8 * wave + (lane & 7) : lane;
+    const int cg = lane >> 3;
     double xv[NXV], rv[NRV], lv = 0.0;
     auto prefetch = [&](uint32_t tile) {
         const uint32_t i = tile * TS + sS;           // < n_pad: always inside the allocation
 #pragma unroll
         for (int it = 0; it < NXV; ++it) xv[it] = xt[(size_t)min(wave + NW * it, D - 1) * ldx + i];
+        if constexpr (EXP == 2) {
 #pragma unroll
-        for (int it = 0; it < NRV; ++it) rv[it] = lw[(size_t)min(rb0 * 16 + wave + NW * it, K - 1) * ldr + i];
-        if (EXP) lv = lse[i];
+            for (int it = 0; it < NRV; ++it) rv[it] = lw[(size_t)min(cg * NRV + it, K - 1) * ldr + tile * TS + sR];
+        } else {
+#pragma unroll
+            for (int it = 0; it < NRV; ++it) rv[it] = lw[(size_t)min(rb0 * 16 + wave + NW * it, K - 1) * ldr + i];
+            if (EXP) lv = lse[i];
+        }
     };
     auto stage = [&](double* Xb, double* Rb, uint32_t tile) {
+        if constexpr (EXP == 2) {
+            const uint32_t i = tile * TS + sR;
+            const bool live = i < n;
+            double m = -__builtin_inf();
+#pragma unroll
+            for (int it = 0; it < NRV; ++it) {
+                if (cg * NRV + it >= K) rv[it] = -__builtin_inf();          // components beyond K: exp(-inf) = 0
+                m = fmax(m, rv[it]);
+            }
+            m = fmax(m, __shfl_xor(m, 8, 64));
+            m = fmax(m, __shfl_xor(m, 16, 64));
+            m = fmax(m, __shfl_xor(m, 32, 64));
+            double sum = 0.0;
+#pragma unroll
+            for (int it = 0; it < NRV; ++it) {
+                rv[it] = exp_nonpos(rv[it] - m);
+                sum += rv[it];
+                __builtin_amdgcn_sched_barrier(0);          // one exp at a time: interleaved they spill next to 160 accumulator registers
+            }
+            sum += __shfl_xor(sum, 8, 64);
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const double inv = live ? 1.0 / sum : 0.0;                      // padding samples contribute nothing
+#pragma unroll
+            for (int it = 0; it < NRV; ++it) Rb[sR * RS + cg * NRV + it] = rv[it] * inv;
+            // lse = m + log(sum) is finished by a separate pass over these two N-vectors (em_lse_finish_kernel): a log in
+            // this loop, next to 160 accumulator registers, cost 0.8 ms at the headline shape in spills and scheduling
+            if (cg == 0 && blockIdx.y == 0) {
+                lse_out[i] = m;
+                ll_out[i] = sum;
+            }
+        } else {
         const bool live = tile * TS + sS < n;
 #pragma unroll
         for (int it = 0; it < NRV; ++it) {
             double r = rv[it];
-            if (EXP) r = exp(r - lv);
+            if (EXP) r = exp_nonpos(r - lv);
             const bool valid = live && (rb0 * 16 + wave + NW * it < K);
             Rb[sS * RS + wave + NW * it] = valid ? r : 0.0;
+        }
         }
 #pragma unroll
         for (int it = 0; it < NXV; ++it) {
@@ -154,12 +206,18 @@ void launch_t(const MstatsArgs& a, const Plan& p, int grid_x, hipStream_t stream
     constexpr int XSD = tile_stride<DM>();
     const size_t smem = (DM <= kMidDim ? 2 : 1) * sizeof(double) * ((size_t)TS * XSD + (size_t)TS * (RBW * 16 + 1));
     const dim3 grid(grid_x, p.n_rbg * p.n_cbg);
-    if (a.mode == kFromLogResp)
-        hipLaunchKernelGGL((em_mstats_wide_kernel<RBW, CBW, true, DM>), grid, dim3(512), smem, stream, a.xt, a.ldx, a.n, a.d,
-                           padded_dim(a.d), a.shift, a.lw, a.ldr, a.lse, a.K, p.n_rbg, p.CB, a.partials, p.KP, p.FP);
+    if (a.mode == kFromLogRespSelfNorm)
+        hipLaunchKernelGGL((em_mstats_wide_kernel<RBW, CBW, 2, DM>), grid, dim3(512), smem, stream, a.xt, a.ldx, a.n, a.d,
+                           padded_dim(a.d), a.shift, a.lw, a.ldr, a.lse, a.K, p.n_rbg, p.CB, a.partials, p.KP, p.FP,
+                           a.lse_out, a.ll_out);
+    else if (a.mode == kFromLogResp)
+        hipLaunchKernelGGL((em_mstats_wide_kernel<RBW, CBW, 1, DM>), grid, dim3(512), smem, stream, a.xt, a.ldx, a.n, a.d,
+                           padded_dim(a.d), a.shift, a.lw, a.ldr, a.lse, a.K, p.n_rbg, p.CB, a.partials, p.KP, p.FP,
+                           nullptr, nullptr);
     else
-        hipLaunchKernelGGL((em_mstats_wide_kernel<RBW, CBW, false, DM>), grid, dim3(512), smem, stream, a.xt, a.ldx, a.n, a.d,
-                           padded_dim(a.d), a.shift, a.lw, a.ldr, a.lse, a.K, p.n_rbg, p.CB, a.partials, p.KP, p.FP);
+        hipLaunchKernelGGL((em_mstats_wide_kernel<RBW, CBW, 0, DM>), grid, dim3(512), smem, stream, a.xt, a.ldx, a.n, a.d,
+                           padded_dim(a.d), a.shift, a.lw, a.ldr, a.lse, a.K, p.n_rbg, p.CB, a.partials, p.KP, p.FP,
+                           nullptr, nullptr);
 }
 
 }  // namespace

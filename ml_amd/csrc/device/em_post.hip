@@ -3,6 +3,7 @@
 // EM::calculate_labels (ML/EM.cpp:289-304: strict '>', components scanned in ascending order, so the
 // first maximum wins). Labels are taken from the very r values that are stored, like the reference does.
 #include "device.hpp"
+#include "exp_nonpos.hpp"
 
 namespace mlhip {
 namespace {
@@ -17,7 +18,7 @@ __global__ __launch_bounds__(256) void em_resp_kernel(const double* __restrict__
         double best = -1.0;
         uint32_t arg = 0xffffffffu;   // ML/EM.cpp:294 starts from label -1
         for (int k = 0; k < K; ++k) {
-            const double r = exp(lw[(size_t)k * ldr + i] - l);
+            const double r = exp_nonpos(lw[(size_t)k * ldr + i] - l);
             if (resp) resp[(size_t)k * ldo + i] = r;
             if (r > best) { best = r; arg = (uint32_t)k; }
         }

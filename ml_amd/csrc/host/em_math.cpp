@@ -126,16 +126,18 @@ void build_estep_params_mfma(int d, int D, int K, const double* mixing, const do
 
 #endif
 
-void build_estep_params_mfma4(int d, int D, int K, const double* mixing, const double* means, const double* covariances,
-                              double* records)
+bool build_estep_params_mfma4(int d, int D, int K, const double* mixing, const double* means, const double* covariances,
+                              const double* shift, double fold_limit, double* records)
 {
     const int PS = estep_mfma4_param_stride(D);
     const int NB = estep_mfma4_block_count(D);
     const int Q = D / 4;
+    std::vector<double> folded(shift ? (size_t)K * d : 0);     // c_k = W_k (mu_k - shift)
+    double biggest = 0.0;
 #pragma omp parallel num_threads(host_threads()) if (worth_threads(K, d))
     {
     std::vector<double> L((size_t)d * d), W((size_t)d * d);
-#pragma omp for schedule(static)
+#pragma omp for schedule(static) reduction(max : biggest)
     for (int k = 0; k < K; ++k) {
         double* rec = records + (size_t)k * PS;
         for (int i = 0; i < PS; ++i) rec[i] = 0.0;
@@ -150,8 +152,24 @@ void build_estep_params_mfma4(int d, int D, int K, const double* mixing, const d
                     }
         for (int j = 0; j < d; ++j) rec[NB * 16 + j] = means[(size_t)k * d + j];
         rec[NB * 16 + D] = std::log(mixing[k]) - log_det_half;
+        if (shift) {
+            for (int row = 0; row < d; ++row) {
+                double c = 0.0;
+                for (int col = 0; col <= row; ++col) c += W[col * d + row] * (means[(size_t)k * d + col] - shift[col]);
+                folded[(size_t)k * d + row] = c;
+                const double a = std::fabs(c);
+                if (a > biggest) biggest = a;
+            }
+        }
     }
     }
+    if (!shift || !(biggest <= fold_limit)) return false;
+    for (double c : folded)
+        if (!std::isfinite(c)) return false;               // broken parameters: leave them to the exact form (NaN in, NaN out)
+    // every |W (mu - shift)| entry is small: the kernel may fold it into the accumulator initialiser (with its sign flipped)
+    for (int k = 0; k < K; ++k)
+        for (int j = 0; j < d; ++j) records[(size_t)k * PS + NB * 16 + j] = -folded[(size_t)k * d + j];
+    return true;
 }
 
 void build_estep_params(int d, int D, int K, const double* mixing, const double* means, const double* covariances,

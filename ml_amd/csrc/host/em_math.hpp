@@ -25,9 +25,11 @@ void build_estep_params(int d, int D, int K, const double* mixing, const double*
 void build_estep_params_mfma(int d, int D, int K, const double* mixing, const double* means, const double* covariances,
                              double* records);
 
-/// Same for the 4x4-block matrix-core E-step kernel (layout: device/layout.hpp estep_mfma4_param_stride).
-void build_estep_params_mfma4(int d, int D, int K, const double* mixing, const double* means, const double* covariances,
-                              double* records);
+/// Same for the 4x4-block matrix-core E-step kernel (layout: device/layout.hpp estep_mfma4_param_stride). With a `shift`
+/// (the data's d-vector) the records are written in FOLD form -- vector slot = -W (mu - shift) instead of the mean -- provided
+/// every entry of every W_k (mu_k - shift) is at most `fold_limit` in magnitude; returns whether they were.
+bool build_estep_params_mfma4(int d, int D, int K, const double* mixing, const double* means, const double* covariances,
+                              const double* shift, double fold_limit, double* records);
 
 /// M-step closing arithmetic from the all-reduced shifted statistics (device/device.hpp stats_count):
 ///   mean_k = shift + S1'/S0 ; cov_k = (M2' - S1' (S1'/S0)^T) / S0 + 1e-15 I ; pi_k = S0 / N.

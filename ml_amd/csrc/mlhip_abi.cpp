@@ -201,12 +201,13 @@ struct mlhip_data {
     // EM workspace (sized for em_K)
     int em_K = 0;
     size_t ldr = 0;
-    DevBuf lw, lse, ll_partials, params_dev, partials, stats_dev, resp_dev, labels_dev;
+    DevBuf lw, lse, esum, ll_partials, params_dev, partials, stats_dev, resp_dev, labels_dev;
     PinnedBuf params_host, stats_host;
     int n_ll = 0;
     bool have_estep = false;
     bool lw_valid = false;        // false after a fused step: lw is rebuilt from params_dev on demand (ensure_lw)
     int estep_variant = 0;        // record layout currently in params_dev: 0 = valu, 1 = mfma16, 2 = mfma4
+    bool estep_fold = false;      // mfma4 records in FOLD form (vector slot = -W (mu - shift)): layout.hpp kEstepFoldLimit
     // diagonal-covariance extension: parameters of the last mlhip_em_step_diag (the N x K block is rebuilt from them on demand)
     bool diag_step = false;
     std::vector<double> diag_mixing, diag_means, diag_vars;
@@ -224,7 +225,7 @@ struct mlhip_data {
 
     ~mlhip_data()
     {
-        for (DevBuf* b : {&xt, &shift_dev, &lw, &lse, &ll_partials, &params_dev, &partials, &stats_dev, &resp_dev,
+        for (DevBuf* b : {&xt, &shift_dev, &lw, &lse, &esum, &ll_partials, &params_dev, &partials, &stats_dev, &resp_dev,
                           &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_partials, &km_out, &km_mind, &km_probe, &km_scale, &km_cnorm, &km_xt_pad,
                           &refine_shift, &refine_stats})
             b->release();
@@ -447,8 +448,14 @@ void prepare_estep(mlhip_data* dt, int K, const double* mixing, const double* me
 #endif
         }
     }
+    dt->estep_fold = false;
     if (use_mfma4) {
-        host::build_estep_params_mfma4(dt->d, dt->D, K, mixing, means, covs, dt->params_host.as<double>());
+        // FOLD form (no per-component mean subtraction in the kernel) while every |W_k (mu_k - shift)| is small enough for
+        // the parity tolerances; the exact form otherwise. Every rank decides from the same parameters. MLHIP_ESTEP_FOLD=0: off.
+        static const bool fold_allowed = [] { const char* e = std::getenv("MLHIP_ESTEP_FOLD"); return !(e && e[0] == '0'); }();
+        const bool try_fold = fold_allowed && dt->D <= kRegDim;
+        dt->estep_fold = host::build_estep_params_mfma4(dt->d, dt->D, K, mixing, means, covs, try_fold ? dt->shift.data() : nullptr,
+                                                        kEstepFoldLimit, dt->params_host.as<double>());
         HIP_CHECK(hipMemcpyAsync(dt->params_dev.p, dt->params_host.p, sizeof(double) * estep_mfma4_param_stride(dt->D) * K,
                                  hipMemcpyHostToDevice, ctx->stream));
 #ifdef MLHIP_EXPERIMENTS
@@ -465,8 +472,9 @@ void prepare_estep(mlhip_data* dt, int K, const double* mixing, const double* me
     dt->estep_variant = use_mfma4 ? 2 : (use_mfma ? 1 : 0);
 }
 
-/// E-step kernel on the records in params_dev: fills lw, lse and the log-likelihood partials.
-void launch_estep(mlhip_data* dt, int K)
+/// E-step kernel on the records in params_dev: fills lw and -- unless the statistics kernel is going to normalise the
+/// log-responsibilities itself (`with_lse` false, matrix-core kernel only) -- lse and the log-likelihood partials.
+void launch_estep(mlhip_data* dt, int K, bool with_lse = true)
 {
     mlhip_ctx* ctx = dt->ctx;
     EstepArgs a{};
@@ -474,6 +482,8 @@ void launch_estep(mlhip_data* dt, int K)
     a.params = dt->params_dev.as<double>(); a.K = K;
     a.lw = dt->lw.as<double>(); a.ldr = dt->ldr; a.lse = dt->lse.as<double>();
     a.ll_partials = dt->ll_partials.as<double>(); a.n_ll_partials = kMaxLlPartials;
+    a.shift = dt->shift_dev.as<double>(); a.fold = dt->estep_fold ? 1 : 0;
+    a.with_lse = (with_lse || dt->estep_variant != 2) ? 1 : 0;
     int grid = 0;
     ctx->timed("em_estep", [&] {
         if (dt->estep_variant == 2) grid = launch_em_estep_mfma4(a, ctx->num_cus, ctx->stream);
@@ -489,11 +499,11 @@ void launch_estep(mlhip_data* dt, int K)
     dt->lw_valid = true;
 }
 
-void run_estep(mlhip_data* dt, int K, const double* mixing, const double* means, const double* covs)
+void run_estep(mlhip_data* dt, int K, const double* mixing, const double* means, const double* covs, bool with_lse = true)
 {
     dt->diag_step = false;
     prepare_estep(dt, K, mixing, means, covs);
-    launch_estep(dt, K);
+    launch_estep(dt, K, with_lse);
 }
 
 /// After a fused step only lse exists on the device; whoever needs the log-responsibility block (labels,
@@ -579,7 +589,13 @@ void run_mstats(mlhip_data* dt, int K, int mode, const double* resp_dev, size_t 
     a.ll_partials = with_ll ? dt->ll_partials.as<double>() : nullptr;
     a.n_ll_partials = with_ll ? dt->n_ll : 0;
     a.stats = dt->stats_dev.as<double>();
-    dt->stats_mode = mode;
+    a.lse_out = dt->lse.as<double>(); a.ll_scratch = dt->ll_partials.as<double>();
+    if (mode == kFromLogRespSelfNorm) {
+        dt->esum.reserve(sizeof(double) * dt->n_pad);
+        a.ll_out = dt->esum.as<double>();
+    }
+    // after a self-normalising pass lse is in HBM like after an LSE-writing E-step: a refinement pass reads it
+    dt->stats_mode = mode == kFromLogRespSelfNorm ? (int)kFromLogResp : mode;
     dt->stats_resp = a.lw;
     dt->stats_ld = a.ldr;
     int rc = 0;
@@ -1127,9 +1143,15 @@ int mlhip_em_step(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* mi
         if (run_fused_step(data, (int)K, mixing, means, covariances)) {
             tr.mark("fused E+M launch+sync+D2H");
         } else {
-            run_estep(data, (int)K, mixing, means, covariances);
+            // K within one row-block group of the wide statistics kernel: the E-step writes the log-responsibilities only and
+            // the statistics kernel normalises them (one exp per pair in the iteration); otherwise the E-step keeps its
+            // online log-sum-exp. MLHIP_SELF_NORM=0 forces the latter (A/B runs).
+            static const bool self_norm_allowed = [] { const char* e = std::getenv("MLHIP_SELF_NORM"); return !(e && e[0] == '0'); }();
+            const bool self_norm = self_norm_allowed && estep_mfma4_supported(data->D) && !std::getenv("MLHIP_ESTEP") &&
+                                   em_mstats_self_norm_supported(data->d, (int)K, ctx->num_cus);
+            run_estep(data, (int)K, mixing, means, covariances, !self_norm);
             tr.mark("params+launch E");
-            run_mstats(data, (int)K, kFromLogResp, nullptr, 0, true);
+            run_mstats(data, (int)K, self_norm && data->estep_variant == 2 ? kFromLogRespSelfNorm : kFromLogResp, nullptr, 0, true);
             tr.mark("M launch+sync+D2H");
         }
         *log_likelihood = ll_from_stats(data, (int)K);
