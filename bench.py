@@ -188,24 +188,23 @@ class Job:
         self.dist.all_gather_object(box, obj)
         return box
 
-    def timed(self, step, steps, warmup):
-        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
-        for _ in range(warmup):
-            step()
+    def timed(self, run, steps, warmup):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks.
+        run(k) executes k steps."""
+        if warmup:
+            run(warmup)
         self.barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        run(steps)
         self.barrier()
         return self.max_over_ranks(time.perf_counter() - t0)
 
-    def kernel_ms(self, step, names, reps=3):
+    def kernel_ms(self, run, names, reps=3):
         """Per-kernel device time (HIP events on the kernels' own stream) in a separate pass, so that the event
         synchronisation does not perturb the timed region."""
         self.ctx.timing_enable(True)
         self.ctx.timing_reset()
-        for _ in range(reps):
-            step()
+        run(reps)
         out = {name: self.ctx.timing_get(name)[0] for name in names}
         self.ctx.timing_enable(False)
         return out
@@ -240,11 +239,12 @@ def kmeans_measure(job, n, d, K, steps, warmup, with_cpu, cpu_samples):
     del X
     state = {"C": mix.means + 0.3 * np.random.default_rng(1).standard_normal((K, d)), "inertia": None}
 
-    def step():
-        state["inertia"], _, _, state["C"] = data.kmeans_step(state["C"])
+    def run(k):
+        for _ in range(k):
+            state["inertia"], _, _, state["C"] = data.kmeans_step(state["C"])
 
-    elapsed = job.timed(step, steps, warmup)
-    k_ms = job.kernel_ms(step, ["kmeans_assign"])["kmeans_assign"]
+    elapsed = job.timed(run, steps, warmup)
+    k_ms = job.kernel_ms(run, ["kmeans_assign"])["kmeans_assign"]
     n_locals = job.gather(hi - lo)
     out = None
     if job.rank == 0:
@@ -293,17 +293,25 @@ def em_measure(job, n, d, K, steps, warmup, with_cpu, cpu_samples, diagonal=Fals
 
     # Start exactly like EM::fit without maximise_first (ML/EM.cpp:127-135): given means, shared sample covariance.
     _, cov = data.sample_covariance()
-    if diagonal:
-        cov = np.diag(np.diag(cov))
-    state = {"ll": None, "pi": np.full(K, 1.0 / K), "mu": mix.initial_means(), "S": np.stack([cov] * K)}
-    em_step = data.em_step_diag if diagonal else data.em_step
+    S0 = np.stack([np.diag(cov)] * K) if diagonal else np.stack([cov] * K)
+    state = {"ll": None, "pi": np.full(K, 1.0 / K), "mu": mix.initial_means(), "S": S0}
 
-    def step():
-        state["ll"], state["pi"], state["mu"], state["S"] = em_step(state["pi"], state["mu"], state["S"])
+    def run(k):
+        # k trips of the reference loop ML/EM.cpp:143-170 (E-step, M-step incl. the K Cholesky / inverse, all-reduce,
+        # convergence test) in one library call; tolerances 0 => exactly k iterations (`ll_change < 0` is never true, :163)
+        if job.args.per_step_calls:
+            for _ in range(k):
+                fn = data.em_step_diag if diagonal else data.em_step
+                state["ll"], state["pi"], state["mu"], state["S"] = fn(state["pi"], state["mu"], state["S"])
+            return
+        done, _, state["ll"], state["pi"], state["mu"], state["S"], _ = data.em_iterate(state["pi"], state["mu"], state["S"], k,
+                                                                                       0.0, 0.0, diagonal)
+        assert done == k
 
-    elapsed = job.timed(step, steps, warmup)
-    names = ["em_diag"] if diagonal else ["em_estep", "em_mstats", "em_fused", "em_fused_wide"]
-    ms = job.kernel_ms(step, names)
+    elapsed = job.timed(run, steps, warmup)
+    names = ["em_diag", "em_close"] if diagonal else ["em_estep", "em_mstats", "em_fused", "em_close"]
+    ms = job.kernel_ms(run, names)
+    ms.setdefault("em_fused_wide", 0.0)
     n_locals = job.gather(hi - lo)
     if job.rank != 0:
         data.close()
@@ -341,7 +349,8 @@ def em_measure(job, n, d, K, steps, warmup, with_cpu, cpu_samples, diagonal=Fals
         traffic, source = traffic_for(dom_name, headline and job.world == 1)
         roof = {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": source,
-                "kernel_ms": {"em_estep": e_ms, "em_mstats": m_ms}, "iteration_algorithmic_tflops": it_tflops}
+                "kernel_ms": {"em_estep": e_ms, "em_mstats": m_ms, "em_close": ms.get("em_close", 0.0)},
+                "iteration_algorithmic_tflops": it_tflops}
     kind = "diagonal covariance (extension; the reference is full-covariance only)" if diagonal else "full covariance"
     out = {
         "metric": f"GMM-EM iterations/sec at N={n} d={d} K={K} ({kind}, fp64)" if not headline
@@ -434,6 +443,9 @@ def main():
                     help="native: ncclAllReduce on the library's own RCCL communicator; torch: torch.distributed hook")
     ap.add_argument("--force-hook", action="store_true",
                     help="(diagnostic) single rank, but with the RCCL all-reduce installed (1-rank communicator)")
+    ap.add_argument("--per-step-calls", action="store_true",
+                    help="(A/B) one mlhip_em_step call per iteration with the closing arithmetic on the host, instead of "
+                         "mlhip_em_iterate (device-side closing)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="(test) start the ranks, join a gloo group, report the launch environment; no GPU work")
     args = ap.parse_args()

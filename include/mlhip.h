@@ -117,6 +117,22 @@ int mlhip_em_step_diag(mlhip_ctx* ctx, mlhip_data* data, uint32_t K,
                        const double* mixing, const double* means, const double* variances,
                        double* log_likelihood, double* mixing_out, double* means_out, double* variances_out);
 
+/* The iteration loop of EM::fit (ML/EM.cpp:143-170) in ONE call: up to max_steps trips of E-step + M-step, each followed by the
+ * reference's convergence test |ll - ll_old| < absolute_tolerance + relative_tolerance * max(|ll_old|, |ll|) from the second
+ * trip on (:161-168). Parameters are updated IN PLACE (covariances: K*d*d doubles, or K*d variances with
+ * MLHIP_COVARIANCE_DIAGONAL); *log_likelihood is that of the last E-step (i.e. under the parameters before the last M-step, like
+ * the reference). Between two tests everything stays on the device -- statistics, all-reduce, the M-step's closing arithmetic
+ * and the K Cholesky / inverse factorizations of EM::process_covariances (:274-287), the next E-step's records -- and the
+ * host reads back 1 + 2K doubles per iteration (d <= 64; above that, or with MLHIP_DEVICE_CLOSE=0, the loop runs through
+ * mlhip_em_step). Same results as calling mlhip_em_step in a loop, to the last bits of log().
+ * log_likelihood_history (max_steps doubles) may be NULL. Tolerances 0 run exactly max_steps iterations. */
+#define MLHIP_COVARIANCE_FULL 0
+#define MLHIP_COVARIANCE_DIAGONAL 1
+int mlhip_em_iterate(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, int covariance_type,
+                     double* mixing, double* means, double* covariances,
+                     uint32_t max_steps, double absolute_tolerance, double relative_tolerance,
+                     uint32_t* steps_done, int* converged, double* log_likelihood, double* log_likelihood_history);
+
 /* E-step only (ML/EM.cpp:190-219): leaves log-responsibilities on the device, returns the log-likelihood. */
 int mlhip_em_expectation(mlhip_ctx* ctx, mlhip_data* data, uint32_t K,
                          const double* mixing, const double* means, const double* covariances,

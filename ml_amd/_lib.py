@@ -278,6 +278,21 @@ class Data:
             v1 = np.stack([np.diag(row) for row in v1])
         return ll.value, pi1, mu1, v1
 
+    def em_iterate(self, mixing, means, covs, max_steps, atol=0.0, rtol=0.0, diagonal=False):
+        """The EM loop in one call (mlhip_em_iterate): up to max_steps iterations with the reference's convergence test, the
+        closing arithmetic on the device. covs: K x d x d (or K x d variances with diagonal=True).
+        Returns (steps_done, converged, log_likelihood, mixing, means, covs, log_likelihood_history)."""
+        K = len(mixing)
+        pi = np.array(mixing, dtype=np.float64, order="C")
+        mu = np.array(means, dtype=np.float64, order="C")
+        S = np.array(covs, dtype=np.float64, order="C")
+        assert mu.shape == (K, self.d) and S.shape == ((K, self.d) if diagonal else (K, self.d, self.d))
+        steps, conv, ll = C.c_uint32(), C.c_int(), C.c_double()
+        hist = np.full(int(max_steps), np.nan)
+        check(lib.mlhip_em_iterate(self.ctx.handle, self._h, K, int(bool(diagonal)), dptr(pi), dptr(mu), dptr(S), C.c_uint32(max_steps),
+                                   C.c_double(atol), C.c_double(rtol), C.byref(steps), C.byref(conv), C.byref(ll), dptr(hist)))
+        return steps.value, bool(conv.value), ll.value, pi, mu, S, hist[:steps.value]
+
     def em_expectation(self, mixing, means, covs):
         K = len(mixing)
         mixing = np.ascontiguousarray(mixing, dtype=np.float64)

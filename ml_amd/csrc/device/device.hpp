@@ -90,6 +90,20 @@ int em_diag_grid(int d, int K, uint32_t n, int num_cus);
 /// Returns the number of per-workgroup partial blocks written (stats and log-likelihood alike), or < 0.
 int launch_em_diag(const DiagArgs& a, int num_cus, hipStream_t stream);
 }
+/// M-step closing arithmetic + next E-step records on the device (em_close.hip): one workgroup per component.
+struct CloseArgs {
+    const double* stats; int K; int d; int D;                // all-reduced statistics [K][F] + ll sum (F: full or diagonal)
+    const double* shift; double n_global;                    // shift: D doubles, zero padded
+    int layout;                                              // full covariances: 0 = estep_param_stride records, 2 = mfma4 records
+    double refine_limit;                                     // <= 0: no refinement flags
+    double* mixing; double* means; double* covs;             // out (device): [K], [K*d], [K*d*d] (diagonal: [K*d] variances)
+    double* records;                                         // out (device): the next E-step's K records
+    double* info;                                            // out (device): [ll_sum | refine flag (K) | max |W (mu - shift)| (K)]
+};
+size_t em_close_info_doubles(int K);
+bool em_close_supported(int d);                              // d <= 64 (two d x d matrices in LDS)
+void launch_em_close(const CloseArgs& a, hipStream_t stream);
+void launch_em_close_diag(const CloseArgs& a, hipStream_t stream);
 /// Fixed-order combination of `n_partials` blocks [KP][FP] (and of the log-likelihood partials) into stats[K*F (+1)].
 void launch_em_reduce_blocks(const double* partials, int n_partials, int KP, int FP, int K, int F, const double* ll_partials,
                              int n_ll, double* stats, hipStream_t stream);

@@ -35,7 +35,7 @@ namespace {
 template <int D> struct Blocks {
     static constexpr int Q = D / 4;                   // 4-wide quads of rows / columns
     static constexpr int NB = Q * (Q + 1) / 2;        // blocks on or below the diagonal
-    static constexpr int PS = NB * 16 + D + 1;        // doubles per component record
+    static constexpr int PS = NB * 16 + 2 * D + 1;    // doubles per component record (layout.hpp estep_mfma4_param_stride)
     // step t (column-quad major): t -> (C, R), R = C..Q-1
     static constexpr int start_of(int C) { return C * Q - C * (C - 1) / 2; }
     static constexpr int C(int t) { int c = 0; while (c + 1 < Q && start_of(c + 1) <= t) ++c; return c; }
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64 * NW, D <= 32 ? 8 / SB : 2) void em_estep_mfma4_
 #pragma unroll
             for (int it = 0; it < NLD; ++it) stage[it] = nxt[min(tid + NT * it, PS - 1)];
 
-            const double coef = rec[NB * 16 + D];
+            const double coef = rec[NB * 16 + 2 * D];
             double aw[W], acc[SB][Q], z[SB];
 #pragma unroll
             for (int t = 0; t < W && t < NB; ++t) aw[t] = rec[t * 16 + aoff];
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64 * NW, D <= 32 ? 8 / SB : 2) void em_estep_mfma4_
             // after unrolling, so the accumulators and the window stay in registers.
 #pragma unroll
             for (int C = 0; C < Q; ++C) {
-                // the record's vector slot: the mean (exact form) or -W (mu - shift) (FOLD: the accumulator initialiser)
+                // the record's two vectors: the mean (exact form) / -W (mu - shift) (FOLD: the accumulator initialiser)
                 const double mu = FOLD ? 0.0 : rec[NB * 16 + 4 * C + g];
 #pragma unroll
                 for (int R = C; R < Q; ++R) {
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64 * NW, D <= 32 ? 8 / SB : 2) void em_estep_mfma4_
                     }
                     if (t + W < NB) aw[t % W] = rec[(t + W) * 16 + aoff];   // refill the slot (LDS broadcast read)
                     double init = 0.0;
-                    if constexpr (FOLD) { if (C == 0) init = rec[NB * 16 + 4 * R + g]; }
+                    if constexpr (FOLD) { if (C == 0) init = rec[NB * 16 + D + 4 * R + g]; }
 #pragma unroll
                     for (int sb = 0; sb < SB; ++sb)
                         acc[sb][R] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, z[sb], C == 0 ? init : acc[sb][R], 0, 0, 0);

@@ -47,8 +47,10 @@ inline bool estep_mfma_supported(int D) { return D >= 12 && D <= 32 && D % 4 == 
 
 /// 4x4-block E-step (v_mfma_f64_4x4x4_4b_f64; dimensions 12..128, multiples of 4): W is cut into 4x4 blocks (R, C); only
 /// blocks on or below the diagonal exist, ordered by column quad C, then row quad R. Record of one component,
-/// estep_mfma4_param_stride(D) doubles: [ block t: 16 doubles, entry [k][i] = W[4R + i][4C + k] | mean(D) | coef ].
-/// FOLD form of that kernel (y = W (x - s) - W (mu - s), the second term in the record's vector slot with its sign flipped):
+/// estep_mfma4_param_stride(D) doubles:
+///   [ block t: 16 doubles, entry [k][i] = W[4R + i][4C + k] | mean(D) | -W (mean - shift) (D) | coef ]
+/// (both vectors are always there: the exact form of the kernel reads the first, the FOLD form the second).
+/// FOLD form of that kernel (y = W (x - s) - W (mu - s), the second term from the record's second vector):
 /// selected by the host while max_k |W_k (mu_k - s)|_inf <= kEstepFoldLimit. Each entry of y then carries an absolute error of
 /// about 2^-53 * (|W (x - s)| + |W (mu - s)|) <= 2^-52 * limit = 1.4e-14 instead of a relative one, i.e. at most ~1e-13 in a
 /// log-responsibility that matters (|y| of a few units, d <= 32) -- inside the 1e-12 parity tolerances, labels unaffected
@@ -56,7 +58,7 @@ inline bool estep_mfma_supported(int D) { return D >= 12 && D <= 32 && D % 4 == 
 constexpr double kEstepFoldLimit = 64.0;
 inline bool estep_mfma4_supported(int D) { return D >= 12 && D <= kMaxDim && D % 4 == 0; }
 inline int estep_mfma4_block_count(int D) { const int q = D / 4; return q * (q + 1) / 2; }
-inline int estep_mfma4_param_stride(int D) { return estep_mfma4_block_count(D) * 16 + D + 1; }
+inline int estep_mfma4_param_stride(int D) { return estep_mfma4_block_count(D) * 16 + 2 * D + 1; }
 
 /// Sufficient statistics of one component: packed lower triangle (row-major) of sum_i r_i xt_i xt_i^T,
 /// xt = [x - shift ; 1] (length d+1). Entry (a,b), a >= b, sits at a(a+1)/2 + b; so

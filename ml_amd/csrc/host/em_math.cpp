@@ -151,7 +151,7 @@ bool build_estep_params_mfma4(int d, int D, int K, const double* mixing, const d
                         rec[t * 16 + kk * 4 + i] = (row < d && col <= row) ? W[col * d + row] : 0.0;
                     }
         for (int j = 0; j < d; ++j) rec[NB * 16 + j] = means[(size_t)k * d + j];
-        rec[NB * 16 + D] = std::log(mixing[k]) - log_det_half;
+        rec[NB * 16 + 2 * D] = std::log(mixing[k]) - log_det_half;
         if (shift) {
             for (int row = 0; row < d; ++row) {
                 double c = 0.0;
@@ -163,13 +163,15 @@ bool build_estep_params_mfma4(int d, int D, int K, const double* mixing, const d
         }
     }
     }
-    if (!shift || !(biggest <= fold_limit)) return false;
-    for (double c : folded)
-        if (!std::isfinite(c)) return false;               // broken parameters: leave them to the exact form (NaN in, NaN out)
-    // every |W (mu - shift)| entry is small: the kernel may fold it into the accumulator initialiser (with its sign flipped)
+    if (!shift) return false;
+    // the accumulator initialiser of the FOLD form (sign flipped); usable while every entry is small and finite
+    bool finite = true;
     for (int k = 0; k < K; ++k)
-        for (int j = 0; j < d; ++j) records[(size_t)k * PS + NB * 16 + j] = -folded[(size_t)k * d + j];
-    return true;
+        for (int j = 0; j < d; ++j) {
+            records[(size_t)k * PS + NB * 16 + D + j] = -folded[(size_t)k * d + j];
+            finite = finite && std::isfinite(folded[(size_t)k * d + j]);
+        }
+    return finite && biggest <= fold_limit;                // broken parameters: leave them to the exact form (NaN in, NaN out)
 }
 
 void build_estep_params(int d, int D, int K, const double* mixing, const double* means, const double* covariances,

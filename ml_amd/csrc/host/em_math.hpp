@@ -26,8 +26,8 @@ void build_estep_params_mfma(int d, int D, int K, const double* mixing, const do
                              double* records);
 
 /// Same for the 4x4-block matrix-core E-step kernel (layout: device/layout.hpp estep_mfma4_param_stride). With a `shift`
-/// (the data's d-vector) the records are written in FOLD form -- vector slot = -W (mu - shift) instead of the mean -- provided
-/// every entry of every W_k (mu_k - shift) is at most `fold_limit` in magnitude; returns whether they were.
+/// (the data's d-vector) the second vector of every record, -W (mu - shift), is filled too; returns whether the kernel's FOLD
+/// form may use it: every entry of every W_k (mu_k - shift) finite and at most `fold_limit` in magnitude.
 bool build_estep_params_mfma4(int d, int D, int K, const double* mixing, const double* means, const double* covariances,
                               const double* shift, double fold_limit, double* records);
 

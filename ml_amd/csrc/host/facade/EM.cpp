@@ -240,8 +240,23 @@ bool EM::fit(ConstMatrixRef data)
                 var_flat[static_cast<std::size_t>(k) * number_dimensions + j] = cov_flat[dd * k + static_cast<std::size_t>(j) * number_dimensions + j];
     }
 
+    if (!verbose_) {
+        // The whole loop below in one library call (same steps, same convergence test: ML/EM.cpp:143-170), with the M-step's
+        // closing arithmetic and the K covariance factorizations on the device between two tests.
+        uint32_t steps = 0;
+        int conv = 0;
+        check(mlhip_em_iterate(ctx, dev.h, K, diagonal ? MLHIP_COVARIANCE_DIAGONAL : MLHIP_COVARIANCE_FULL,
+                               mixing_probabilities_.data(), means_.data(), diagonal ? var_flat.data() : cov_flat.data(),
+                               maximum_steps_, absolute_tolerance_, relative_tolerance_, &steps, &conv, &log_likelihood_, nullptr));
+        steps_done_ = steps;
+        if (conv) {
+            check(mlhip_em_labels(ctx, dev.h, K, labels_.data()));   // EM::calculate_labels, on convergence only
+            converged_ = true;
+        }
+    }
+
     double old_log_likelihood = -std::numeric_limits<double>::infinity();
-    for (unsigned int step = 0; step < maximum_steps_; ++step) {
+    for (unsigned int step = 0; verbose_ && step < maximum_steps_; ++step) {
         // One E-step + M-step on the device; parameters are updated in place (ML/EM.cpp:145-147).
         if (diagonal)
             check(mlhip_em_step_diag(ctx, dev.h, K, mixing_probabilities_.data(), means_.data(), var_flat.data(), &log_likelihood_,

@@ -211,6 +211,9 @@ struct mlhip_data {
     // diagonal-covariance extension: parameters of the last mlhip_em_step_diag (the N x K block is rebuilt from them on demand)
     bool diag_step = false;
     std::vector<double> diag_mixing, diag_means, diag_vars;
+    // mlhip_em_iterate: parameters and the next E-step's records stay on the device between iterations
+    DevBuf params_next, it_mixing[2], it_means[2], it_covs[2], it_info;
+    PinnedBuf it_info_host;
     // source of the last statistics pass (for the per-component refinement pass)
     int stats_mode = 0;
     const double* stats_resp = nullptr;
@@ -227,8 +230,10 @@ struct mlhip_data {
     {
         for (DevBuf* b : {&xt, &shift_dev, &lw, &lse, &esum, &ll_partials, &params_dev, &partials, &stats_dev, &resp_dev,
                           &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_partials, &km_out, &km_mind, &km_probe, &km_scale, &km_cnorm, &km_xt_pad,
-                          &refine_shift, &refine_stats})
+                          &refine_shift, &refine_stats, &params_next, &it_mixing[0], &it_mixing[1], &it_means[0], &it_means[1],
+                          &it_covs[0], &it_covs[1], &it_info})
             b->release();
+        it_info_host.release();
         params_host.release(); stats_host.release(); km_host.release();
     }
 };
@@ -432,10 +437,20 @@ void ensure_em_workspace(mlhip_data* dt, int K)
 }
 
 /// Builds the per-component records for the E-step kernel that fits (d, env) and uploads them to params_dev.
-void prepare_estep(mlhip_data* dt, int K, const double* mixing, const double* means, const double* covs)
+void prepare_estep(mlhip_data* dt, int K, const double* mixing, const double* means, const double* covs, DevBuf* target = nullptr)
 {
     mlhip_ctx* ctx = dt->ctx;
     ensure_em_workspace(dt, K);
+    if (!target) target = &dt->params_dev;
+    {   // (params_dev / params_next are swapped by mlhip_em_iterate and may have been sized for diagonal records)
+        size_t ps = (size_t)estep_param_stride(dt->D) * K * sizeof(double);
+        if (estep_mfma4_supported(dt->D)) ps = std::max(ps, (size_t)estep_mfma4_param_stride(dt->D) * K * sizeof(double));
+#ifdef MLHIP_EXPERIMENTS
+        if (estep_mfma_supported(dt->D)) ps = std::max(ps, (size_t)estep_mfma_param_stride(dt->D) * K * sizeof(double));
+#endif
+        target->reserve(ps);
+        dt->params_host.reserve(ps);
+    }
     // d in 12..128: 4x4-block triangular matrix-core kernel (mfma4). For d <= 32, MLHIP_ESTEP=valu selects the scalar-fed
     // VALU kernel (the only one below d = 12) and, in a `make EXPERIMENTS=1` build, MLHIP_ESTEP=mfma16 the 16x16x4
     // block-triangular one, for A/B runs.
@@ -456,17 +471,17 @@ void prepare_estep(mlhip_data* dt, int K, const double* mixing, const double* me
         const bool try_fold = fold_allowed && dt->D <= kRegDim;
         dt->estep_fold = host::build_estep_params_mfma4(dt->d, dt->D, K, mixing, means, covs, try_fold ? dt->shift.data() : nullptr,
                                                         kEstepFoldLimit, dt->params_host.as<double>());
-        HIP_CHECK(hipMemcpyAsync(dt->params_dev.p, dt->params_host.p, sizeof(double) * estep_mfma4_param_stride(dt->D) * K,
+        HIP_CHECK(hipMemcpyAsync(target->p, dt->params_host.p, sizeof(double) * estep_mfma4_param_stride(dt->D) * K,
                                  hipMemcpyHostToDevice, ctx->stream));
 #ifdef MLHIP_EXPERIMENTS
     } else if (use_mfma) {
         host::build_estep_params_mfma(dt->d, dt->D, K, mixing, means, covs, dt->params_host.as<double>());
-        HIP_CHECK(hipMemcpyAsync(dt->params_dev.p, dt->params_host.p, sizeof(double) * estep_mfma_param_stride(dt->D) * K,
+        HIP_CHECK(hipMemcpyAsync(target->p, dt->params_host.p, sizeof(double) * estep_mfma_param_stride(dt->D) * K,
                                  hipMemcpyHostToDevice, ctx->stream));
 #endif
     } else {
         host::build_estep_params(dt->d, dt->D, K, mixing, means, covs, dt->params_host.as<double>());
-        HIP_CHECK(hipMemcpyAsync(dt->params_dev.p, dt->params_host.p, sizeof(double) * estep_param_stride(dt->D) * K,
+        HIP_CHECK(hipMemcpyAsync(target->p, dt->params_host.p, sizeof(double) * estep_param_stride(dt->D) * K,
                                  hipMemcpyHostToDevice, ctx->stream));
     }
     dt->estep_variant = use_mfma4 ? 2 : (use_mfma ? 1 : 0);
@@ -542,14 +557,17 @@ void collect_stats(mlhip_data* dt, int K, size_t count = 0)
 
 /// One EM iteration's device work in a single kernel where the shape allows (d <= 6, K <= 32 or d <= 4, K <= 64: em_fused_small.hip): no
 /// N x K block in HBM. MLHIP_FUSED=0 keeps the two-kernel path. Returns false when the shape is not covered.
-bool run_fused_step(mlhip_data* dt, int K, const double* mixing, const double* means, const double* covs)
+bool fused_step_applies(const mlhip_data* dt, int K)
 {
     const char* env = std::getenv("MLHIP_FUSED");
-    if ((env && env[0] == '0') || !mstats::em_fused_supported(dt->d, K)) return false;
+    return !(env && env[0] == '0') && mstats::em_fused_supported(dt->d, K);
+}
+
+/// The fused kernel + reduction on the records already in params_dev; statistics end in stats_dev (and, with `collect`, all-
+/// reduced in stats_host).
+void launch_fused_step(mlhip_data* dt, int K, bool collect)
+{
     mlhip_ctx* ctx = dt->ctx;
-    dt->diag_step = false;
-    prepare_estep(dt, K, mixing, means, covs);
-    if (dt->estep_variant != 0) return false;            // (cannot happen for d <= 8; the fused kernel reads VALU records)
     FusedArgs a{};
     a.xt = dt->xt.as<double>(); a.ldx = dt->ldx; a.n = dt->n; a.d = dt->d;
     a.shift = dt->shift_dev.as<double>(); a.params = dt->params_dev.as<double>(); a.K = K;
@@ -568,13 +586,22 @@ bool run_fused_step(mlhip_data* dt, int K, const double* mixing, const double* m
     dt->stats_mode = kFromLogResp;
     dt->stats_resp = dt->lw.as<double>();
     dt->stats_ld = dt->ldr;
-    collect_stats(dt, K);
+    if (collect) collect_stats(dt, K);
+}
+
+bool run_fused_step(mlhip_data* dt, int K, const double* mixing, const double* means, const double* covs)
+{
+    if (!fused_step_applies(dt, K)) return false;
+    dt->diag_step = false;
+    prepare_estep(dt, K, mixing, means, covs);
+    if (dt->estep_variant != 0) return false;            // (cannot happen for d <= 8; the fused kernel reads VALU records)
+    launch_fused_step(dt, K, true);
     return true;
 }
 
 /// Runs the statistics kernel on log-responsibilities (mode kFromLogResp: the E-step's lw/lse) or on plain
 /// responsibilities `resp_dev` ([K][ld_resp], ld_resp >= n_pad), all-reduces, leaves [K*F stats, ll_sum] in stats_host.
-void run_mstats(mlhip_data* dt, int K, int mode, const double* resp_dev, size_t ld_resp, bool with_ll)
+void run_mstats(mlhip_data* dt, int K, int mode, const double* resp_dev, size_t ld_resp, bool with_ll, bool collect = true)
 {
     mlhip_ctx* ctx = dt->ctx;
     ensure_em_workspace(dt, K);
@@ -603,7 +630,7 @@ void run_mstats(mlhip_data* dt, int K, int mode, const double* resp_dev, size_t 
     if (rc <= 0) throw std::runtime_error("statistics kernel launch failed (plan/scratch)");
     launch_em_reduce(a, ctx->num_cus, rc, ctx->stream);
     HIP_CHECK(hipGetLastError());
-    collect_stats(dt, K);
+    if (collect) collect_stats(dt, K);
 }
 
 double log_two_pi()
@@ -714,7 +741,7 @@ void finalize_out(mlhip_data* dt, int K, double* mixing_out, double* means_out, 
 
 /// One diagonal-covariance EM iteration's device work (em_diag.hip) with the statistics shift at `shift_dev`; leaves the
 /// all-reduced [K * (2d+1) statistics, ll_sum] in stats_host. The records must already be in params_dev.
-void run_diag_kernel(mlhip_data* dt, int K, const double* shift_dev)
+void run_diag_kernel(mlhip_data* dt, int K, const double* shift_dev, bool collect = true)
 {
     mlhip_ctx* ctx = dt->ctx;
     DiagArgs a{};
@@ -730,7 +757,7 @@ void run_diag_kernel(mlhip_data* dt, int K, const double* shift_dev)
                             diag_stats_count(dt->d), a.ll_partials, grid, dt->stats_dev.as<double>(), ctx->stream);
     HIP_CHECK(hipGetLastError());
     dt->n_ll = grid;
-    collect_stats(dt, K, (size_t)K * diag_stats_count(dt->d) + 1);
+    if (collect) collect_stats(dt, K, (size_t)K * diag_stats_count(dt->d) + 1);
 }
 
 void ensure_km_workspace(mlhip_data* dt, int K)
@@ -836,6 +863,282 @@ void run_kmeans(mlhip_data* dt, int K, const double* centroids, bool accumulate,
     ctx->sync();
     if (ctx->reduce_fn && !ctx->reduce_on_device) {
         if (ctx->reduce_fn(ctx->reduce_user, ch, count, 0, ctx->stream) != 0) throw std::runtime_error("all-reduce hook failed");
+    }
+}
+
+/// K within one row-block group of the wide statistics kernel: the matrix-core E-step writes the log-responsibilities only and
+/// the statistics kernel normalises them (one exp per pair in the iteration); otherwise the E-step keeps its online
+/// log-sum-exp. MLHIP_SELF_NORM=0 forces the latter (A/B runs).
+bool self_norm_applies(const mlhip_data* dt, int K)
+{
+    static const bool allowed = [] { const char* e = std::getenv("MLHIP_SELF_NORM"); return !(e && e[0] == '0'); }();
+    return allowed && estep_mfma4_supported(dt->D) && !std::getenv("MLHIP_ESTEP") &&
+           em_mstats_self_norm_supported(dt->d, K, dt->ctx->num_cus);
+}
+
+/// One full-covariance EM iteration with the closing arithmetic on the HOST (the body of mlhip_em_step).
+void em_step_full(mlhip_data* data, int K, const double* mixing, const double* means, const double* covariances,
+                  double* log_likelihood, double* mixing_out, double* means_out, double* covariances_out)
+{
+    PhaseTrace tr;
+    if (run_fused_step(data, K, mixing, means, covariances)) {
+        tr.mark("fused E+M launch+sync+D2H");
+    } else {
+        const bool self_norm = self_norm_applies(data, K);
+        run_estep(data, K, mixing, means, covariances, !self_norm);
+        tr.mark("params+launch E");
+        run_mstats(data, K, self_norm && data->estep_variant == 2 ? kFromLogRespSelfNorm : kFromLogResp, nullptr, 0, true);
+        tr.mark("M launch+sync+D2H");
+    }
+    *log_likelihood = ll_from_stats(data, K);
+    finalize_out(data, K, mixing_out, means_out, covariances_out);
+    tr.mark("closing arithmetic");
+}
+
+/// Sums `count` doubles at the head of stats_dev across ranks, whatever kind of hook is installed (device buffer on the
+/// stream, or a host buffer: down, hook, up). No-op on a single rank.
+void allreduce_stats_dev(mlhip_data* dt, size_t count)
+{
+    mlhip_ctx* ctx = dt->ctx;
+    if (!ctx->reduce_fn) return;
+    if (ctx->reduce_on_device) {
+        if (ctx->reduce_fn(ctx->reduce_user, dt->stats_dev.as<double>(), count, 1, ctx->stream) != 0)
+            throw std::runtime_error("all-reduce hook failed");
+        return;
+    }
+    HIP_CHECK(hipMemcpyAsync(dt->stats_host.p, dt->stats_dev.p, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+    if (ctx->reduce_fn(ctx->reduce_user, dt->stats_host.as<double>(), count, 0, ctx->stream) != 0)
+        throw std::runtime_error("all-reduce hook failed");
+    HIP_CHECK(hipMemcpyAsync(dt->stats_dev.p, dt->stats_host.p, sizeof(double) * count, hipMemcpyHostToDevice, ctx->stream));
+}
+
+/// Records of a diagonal-covariance parameter set -> `target` (padded to whole 16-component row blocks with neutral records).
+void upload_diag_records(mlhip_data* data, int K, const double* mixing, const double* means, const double* variances, DevBuf& target)
+{
+    mlhip_ctx* ctx = data->ctx;
+    const int KP = mstats::em_diag_partial_rows(K);
+    const size_t rec_bytes = sizeof(double) * diag_param_stride(data->D) * (size_t)KP;
+    target.reserve(rec_bytes);
+    data->params_host.reserve(rec_bytes);
+    host::build_diag_params(data->d, data->D, K, KP, mixing, means, variances, data->params_host.as<double>());
+    HIP_CHECK(hipMemcpyAsync(target.p, data->params_host.p, rec_bytes, hipMemcpyHostToDevice, ctx->stream));
+    ctx->sync();                                     // params_host may be rewritten right away by the caller's next upload
+}
+
+/// Same cancellation guard as the full-covariance path (refine_ratio): a component whose mean sits far from the shared shift,
+/// measured in its own standard deviations, gets its variances from a second pass with the shift at its new mean (the E part of
+/// that pass re-evaluates the SAME input parameters, still in params_dev).
+void refine_diag(mlhip_data* data, int K, const double* mixing_out, double* means_out, double* variances_out)
+{
+    mlhip_ctx* ctx = data->ctx;
+    const int d = data->d, F = diag_stats_count(d);
+    const double limit = refine_ratio();
+    if (!(limit > 0)) return;
+    for (int k = 0; k < K; ++k) {
+        if (!(mixing_out[k] > 0) || !std::isfinite(mixing_out[k])) continue;
+        bool flag = false;
+        for (int a = 0; a < d && !flag; ++a) {
+            const double off = means_out[(size_t)k * d + a] - data->shift[a], var = variances_out[(size_t)k * d + a];
+            if (!std::isfinite(off) || !std::isfinite(var)) { flag = false; break; }
+            flag = off * off > limit * var;
+        }
+        if (!flag) continue;
+        data->refine_shift.reserve(sizeof(double) * data->D);
+        HIP_CHECK(hipMemsetAsync(data->refine_shift.p, 0, sizeof(double) * data->D, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(data->refine_shift.p, means_out + (size_t)k * d, sizeof(double) * d, hipMemcpyHostToDevice, ctx->stream));
+        run_diag_kernel(data, K, data->refine_shift.as<double>());
+        const double* s = data->stats_host.as<double>() + (size_t)k * F;
+        const double s0 = s[2 * d];
+        for (int a = 0; a < d; ++a) {
+            const double m = s[a] / s0;                                      // ~0: the shift is the mean already
+            variances_out[(size_t)k * d + a] = (s[d + a] - s[a] * m) / s0 + 1e-15;
+            means_out[(size_t)k * d + a] += m;
+        }
+        data->refined_components += 1;
+    }
+}
+
+/// One diagonal-covariance EM iteration with the closing arithmetic on the HOST (the body of mlhip_em_step_diag).
+void em_step_diag(mlhip_data* data, int K, const double* mixing, const double* means, const double* variances,
+                  double* log_likelihood, double* mixing_out, double* means_out, double* variances_out)
+{
+    const int d = data->d;
+    ensure_em_workspace(data, K);
+    // keep the input parameters: labels / responsibilities are produced from them on demand (ensure_lw)
+    data->diag_mixing.assign(mixing, mixing + K);
+    data->diag_means.assign(means, means + (size_t)K * d);
+    data->diag_vars.assign(variances, variances + (size_t)K * d);
+    upload_diag_records(data, K, mixing, means, variances, data->params_dev);
+    run_diag_kernel(data, K, data->shift_dev.as<double>());
+    data->have_estep = true;
+    data->lw_valid = false;
+    data->diag_step = true;
+    const int F = diag_stats_count(d);
+    const double* st = data->stats_host.as<double>();
+    *log_likelihood = st[(size_t)K * F] / (double)data->n_global - (double)d * log_two_pi() / 2;   // ML/EM.cpp:197-198, 211
+    host::finalize_mstep_diag(d, K, st, data->shift.data(), (double)data->n_global, mixing_out, means_out, variances_out);
+    refine_diag(data, K, mixing_out, means_out, variances_out);
+}
+
+/// The loop of EM::fit (ML/EM.cpp:143-170) with everything between two convergence tests on the device: E-step, statistics,
+/// all-reduce, closing arithmetic + next records (em_close.hip); per iteration the host reads back 1 + 2K doubles (log-
+/// likelihood sum, refinement flags, FOLD criterion) and decides. A flagged component (far, tight cluster) sends that one
+/// iteration through the host closing with its refinement pass, exactly as mlhip_em_step would. MLHIP_DEVICE_CLOSE=0, or
+/// d > 64, runs the whole loop through the per-step functions.
+void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* means, double* covs, uint32_t max_steps, double atol,
+                double rtol, uint32_t* steps_done, int* converged, double* log_likelihood, double* history)
+{
+    mlhip_ctx* ctx = data->ctx;
+    const int d = data->d;
+    *steps_done = 0;
+    *converged = 0;
+    double old_ll = -HUGE_VAL;
+    auto test = [&](uint32_t step, double ll) {       // ML/EM.cpp:161-168
+        if (history) history[step] = ll;
+        *log_likelihood = ll;
+        *steps_done = step + 1;
+        if (step > 0) {
+            const double change = std::fabs(ll - old_ll);
+            if (change < atol + rtol * std::max(std::fabs(old_ll), std::fabs(ll))) { *converged = 1; return true; }
+        }
+        old_ll = ll;
+        return false;
+    };
+    static const bool device_close_allowed = [] { const char* e = std::getenv("MLHIP_DEVICE_CLOSE"); return !(e && e[0] == '0'); }();
+    ensure_em_workspace(data, K);
+    bool device_close = device_close_allowed && em_close_supported(d);
+    if (device_close && !diag) {
+        prepare_estep(data, K, mixing, means, covs);           // records of the caller's parameters -> params_dev
+        if (data->estep_variant == 1) device_close = false;    // (experimental record layout: host closing only)
+    }
+    if (!device_close) {
+        for (uint32_t step = 0; step < max_steps; ++step) {
+            double ll = 0;
+            if (diag) em_step_diag(data, K, mixing, means, covs, &ll, mixing, means, covs);
+            else em_step_full(data, K, mixing, means, covs, &ll, mixing, means, covs);
+            if (test(step, ll)) break;
+        }
+        return;
+    }
+
+    const size_t n_cov = diag ? (size_t)K * d : (size_t)K * d * d;
+    const size_t F = diag ? diag_stats_count(d) : stats_count(d);
+    const size_t n_info = em_close_info_doubles(K);
+    for (int b = 0; b < 2; ++b) {
+        data->it_mixing[b].reserve(sizeof(double) * K);
+        data->it_means[b].reserve(sizeof(double) * K * d);
+        data->it_covs[b].reserve(sizeof(double) * n_cov);
+    }
+    data->it_info.reserve(sizeof(double) * n_info);
+    data->it_info_host.reserve(sizeof(double) * (n_info + K + (size_t)K * d + n_cov));   // info, then a parameter set (diag shadow)
+    if (diag) {
+        upload_diag_records(data, K, mixing, means, covs, data->params_dev);
+        upload_diag_records(data, K, mixing, means, covs, data->params_next);          // (the neutral padding records live in both)
+        data->diag_mixing.assign(mixing, mixing + K);
+        data->diag_means.assign(means, means + (size_t)K * d);
+        data->diag_vars.assign(covs, covs + (size_t)K * d);
+    } else {
+        data->params_next.reserve(data->params_dev.bytes);
+    }
+    data->diag_step = diag;
+    const bool fused = !diag && data->estep_variant == 0 && fused_step_applies(data, K);
+    const bool self_norm = !diag && !fused && data->estep_variant == 2 && self_norm_applies(data, K);
+    static const bool fold_allowed = [] { const char* e = std::getenv("MLHIP_ESTEP_FOLD"); return !(e && e[0] == '0'); }();
+    const double limit = refine_ratio();
+    std::vector<double> prev_mixing, prev_means, prev_vars;     // diag: the inputs of the E-step before the newest parameters
+    int cur = 0;
+    bool latest_on_host = true;
+    double* info = data->it_info_host.as<double>();
+    double* shadow = info + n_info;
+
+    for (uint32_t step = 0; step < max_steps; ++step) {
+        PhaseTrace tr;
+        if (diag) {
+            run_diag_kernel(data, K, data->shift_dev.as<double>(), false);
+        } else if (fused) {
+            launch_fused_step(data, K, false);
+        } else {
+            launch_estep(data, K, !self_norm);
+            run_mstats(data, K, self_norm ? kFromLogRespSelfNorm : kFromLogResp, nullptr, 0, true, false);
+        }
+        data->have_estep = true;
+        data->lw_valid = !(diag || fused);
+        allreduce_stats_dev(data, (size_t)K * F + 1);
+        const int nxt = cur ^ 1;
+        CloseArgs ca{};
+        ca.stats = data->stats_dev.as<double>(); ca.K = K; ca.d = d; ca.D = data->D;
+        ca.shift = data->shift_dev.as<double>(); ca.n_global = (double)data->n_global;
+        ca.layout = data->estep_variant; ca.refine_limit = limit;
+        ca.mixing = data->it_mixing[nxt].as<double>(); ca.means = data->it_means[nxt].as<double>();
+        ca.covs = data->it_covs[nxt].as<double>(); ca.records = data->params_next.as<double>();
+        ca.info = data->it_info.as<double>();
+        ctx->timed("em_close", [&] { if (diag) launch_em_close_diag(ca, ctx->stream); else launch_em_close(ca, ctx->stream); });
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(info, data->it_info.p, sizeof(double) * n_info, hipMemcpyDeviceToHost, ctx->stream));
+        if (diag) {      // small: keep a host shadow of the newest parameters (ensure_lw needs the inputs of the last E-step)
+            HIP_CHECK(hipMemcpyAsync(shadow, ca.mixing, sizeof(double) * K, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_CHECK(hipMemcpyAsync(shadow + K, ca.means, sizeof(double) * K * d, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_CHECK(hipMemcpyAsync(shadow + K + (size_t)K * d, ca.covs, sizeof(double) * n_cov, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        ctx->sync();
+        tr.mark("iteration (device close)");
+        const double ll = info[0] / (double)data->n_global - (double)d * log_two_pi() / 2;   // ML/EM.cpp:197-198, 211
+        bool flagged = false;
+        double cmax = 0.0;
+        for (int k = 0; k < K; ++k) {
+            flagged = flagged || info[1 + k] != 0.0;
+            cmax = std::max(cmax, info[1 + K + k]);
+        }
+        bool fold_next = false;
+        if (flagged) {
+            // a far, tight component: this iteration is closed on the host, refinement pass included (the per-step arithmetic)
+            HIP_CHECK(hipMemcpyAsync(data->stats_host.p, data->stats_dev.p, sizeof(double) * ((size_t)K * F + 1),
+                                     hipMemcpyDeviceToHost, ctx->stream));
+            ctx->sync();
+            if (diag) {
+                host::finalize_mstep_diag(d, K, data->stats_host.as<double>(), data->shift.data(), (double)data->n_global, mixing, means, covs);
+                refine_diag(data, K, mixing, means, covs);
+                upload_diag_records(data, K, mixing, means, covs, data->params_next);
+                prev_mixing = data->diag_mixing; prev_means = data->diag_means; prev_vars = data->diag_vars;
+                data->diag_mixing.assign(mixing, mixing + K);
+                data->diag_means.assign(means, means + (size_t)K * d);
+                data->diag_vars.assign(covs, covs + (size_t)K * d);
+            } else {
+                finalize_out(data, K, mixing, means, covs);
+                const int variant = data->estep_variant;
+                const bool fold_now = data->estep_fold;
+                prepare_estep(data, K, mixing, means, covs, &data->params_next);
+                fold_next = data->estep_fold;
+                data->estep_fold = fold_now;                     // (still describes the records in params_dev)
+                if (data->estep_variant != variant) throw std::runtime_error("E-step record layout changed inside a fit");
+            }
+            latest_on_host = true;
+        } else {
+            latest_on_host = false;
+            cur = nxt;
+            fold_next = fold_allowed && data->estep_variant == 2 && data->D <= kRegDim && cmax <= kEstepFoldLimit;
+            if (diag) {
+                prev_mixing = data->diag_mixing; prev_means = data->diag_means; prev_vars = data->diag_vars;
+                data->diag_mixing.assign(shadow, shadow + K);
+                data->diag_means.assign(shadow + K, shadow + K + (size_t)K * d);
+                data->diag_vars.assign(shadow + K + (size_t)K * d, shadow + K + (size_t)K * d + n_cov);
+            }
+        }
+        const bool stop = test(step, ll);
+        if (stop || step + 1 == max_steps) break;
+        std::swap(data->params_dev, data->params_next);          // the new records become the next E-step's
+        data->estep_fold = fold_next;
+    }
+    // the caller's arrays receive the newest parameters; the device keeps the records of the LAST E-step in params_dev
+    if (!latest_on_host) {
+        HIP_CHECK(hipMemcpyAsync(mixing, data->it_mixing[cur].p, sizeof(double) * K, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(means, data->it_means[cur].p, sizeof(double) * K * d, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(covs, data->it_covs[cur].p, sizeof(double) * n_cov, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->sync();
+    }
+    if (diag && !prev_mixing.empty()) {   // ensure_lw rebuilds the block from the inputs of the last E-step
+        data->diag_mixing = prev_mixing; data->diag_means = prev_means; data->diag_vars = prev_vars;
     }
 }
 
@@ -1139,24 +1442,7 @@ int mlhip_em_step(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* mi
     return guarded([&] {
         check_em_args(ctx, data, K);
         require(mixing && means && covariances && log_likelihood && mixing_out && means_out && covariances_out, "null argument");
-        PhaseTrace tr;
-        if (run_fused_step(data, (int)K, mixing, means, covariances)) {
-            tr.mark("fused E+M launch+sync+D2H");
-        } else {
-            // K within one row-block group of the wide statistics kernel: the E-step writes the log-responsibilities only and
-            // the statistics kernel normalises them (one exp per pair in the iteration); otherwise the E-step keeps its
-            // online log-sum-exp. MLHIP_SELF_NORM=0 forces the latter (A/B runs).
-            static const bool self_norm_allowed = [] { const char* e = std::getenv("MLHIP_SELF_NORM"); return !(e && e[0] == '0'); }();
-            const bool self_norm = self_norm_allowed && estep_mfma4_supported(data->D) && !std::getenv("MLHIP_ESTEP") &&
-                                   em_mstats_self_norm_supported(data->d, (int)K, ctx->num_cus);
-            run_estep(data, (int)K, mixing, means, covariances, !self_norm);
-            tr.mark("params+launch E");
-            run_mstats(data, (int)K, self_norm && data->estep_variant == 2 ? kFromLogRespSelfNorm : kFromLogResp, nullptr, 0, true);
-            tr.mark("M launch+sync+D2H");
-        }
-        *log_likelihood = ll_from_stats(data, (int)K);
-        finalize_out(data, (int)K, mixing_out, means_out, covariances_out);
-        tr.mark("closing arithmetic");
+        em_step_full(data, (int)K, mixing, means, covariances, log_likelihood, mixing_out, means_out, covariances_out);
     });
 }
 
@@ -1167,56 +1453,27 @@ int mlhip_em_step_diag(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const doubl
     return guarded([&] {
         check_em_args(ctx, data, K);
         require(mixing && means && variances && log_likelihood && mixing_out && means_out && variances_out, "null argument");
-        const int d = data->d, Ki = (int)K;
-        if (!mstats::em_diag_supported(d, Ki))
+        if (!mstats::em_diag_supported(data->d, (int)K))
             throw Unsupported("diagonal-covariance EM is built for d <= 32 and K <= 64");
-        ensure_em_workspace(data, Ki);
-        // keep the input parameters: labels / responsibilities are produced from them on demand (ensure_lw)
-        data->diag_mixing.assign(mixing, mixing + K);
-        data->diag_means.assign(means, means + (size_t)K * d);
-        data->diag_vars.assign(variances, variances + (size_t)K * d);
-        const int KP = mstats::em_diag_partial_rows(Ki);          // records are padded to whole 16-component row blocks
-        const size_t rec_bytes = sizeof(double) * diag_param_stride(data->D) * (size_t)KP;
-        data->params_dev.reserve(rec_bytes);
-        data->params_host.reserve(rec_bytes);
-        host::build_diag_params(d, data->D, Ki, KP, mixing, means, variances, data->params_host.as<double>());
-        HIP_CHECK(hipMemcpyAsync(data->params_dev.p, data->params_host.p, rec_bytes, hipMemcpyHostToDevice, ctx->stream));
-        run_diag_kernel(data, Ki, data->shift_dev.as<double>());
-        data->have_estep = true;
-        data->lw_valid = false;
-        data->diag_step = true;
-        const int F = diag_stats_count(d);
-        const double* st = data->stats_host.as<double>();
-        *log_likelihood = st[(size_t)K * F] / (double)data->n_global - (double)d * log_two_pi() / 2;   // ML/EM.cpp:197-198, 211
-        host::finalize_mstep_diag(d, Ki, st, data->shift.data(), (double)data->n_global, mixing_out, means_out, variances_out);
-        // Same cancellation guard as the full-covariance path (refine_ratio): a component whose mean sits far from the
-        // shared shift, measured in its own standard deviations, gets its variances from a second pass with the shift at
-        // its new mean (the E part of that pass re-evaluates the SAME input parameters, still in params_dev).
-        const double limit = refine_ratio();
-        if (!(limit > 0)) return;
-        std::vector<double> st2;
-        for (int k = 0; k < Ki; ++k) {
-            if (!(mixing_out[k] > 0) || !std::isfinite(mixing_out[k])) continue;
-            bool flag = false;
-            for (int a = 0; a < d && !flag; ++a) {
-                const double off = means_out[(size_t)k * d + a] - data->shift[a], var = variances_out[(size_t)k * d + a];
-                if (!std::isfinite(off) || !std::isfinite(var)) { flag = false; break; }
-                flag = off * off > limit * var;
-            }
-            if (!flag) continue;
-            data->refine_shift.reserve(sizeof(double) * data->D);
-            HIP_CHECK(hipMemsetAsync(data->refine_shift.p, 0, sizeof(double) * data->D, ctx->stream));
-            HIP_CHECK(hipMemcpyAsync(data->refine_shift.p, means_out + (size_t)k * d, sizeof(double) * d, hipMemcpyHostToDevice, ctx->stream));
-            run_diag_kernel(data, Ki, data->refine_shift.as<double>());
-            const double* s = data->stats_host.as<double>() + (size_t)k * F;
-            const double s0 = s[2 * d];
-            for (int a = 0; a < d; ++a) {
-                const double m = s[a] / s0;                                      // ~0: the shift is the mean already
-                variances_out[(size_t)k * d + a] = (s[d + a] - s[a] * m) / s0 + 1e-15;
-                means_out[(size_t)k * d + a] += m;
-            }
-            data->refined_components += 1;
-        }
+        em_step_diag(data, (int)K, mixing, means, variances, log_likelihood, mixing_out, means_out, variances_out);
+    });
+}
+
+int mlhip_em_iterate(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, int covariance_type, double* mixing, double* means,
+                     double* covariances, uint32_t max_steps, double absolute_tolerance, double relative_tolerance,
+                     uint32_t* steps_done, int* converged, double* log_likelihood, double* log_likelihood_history)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, K);
+        require(mixing && means && covariances && steps_done && converged && log_likelihood, "null argument");
+        require(covariance_type == MLHIP_COVARIANCE_FULL || covariance_type == MLHIP_COVARIANCE_DIAGONAL, "bad covariance_type");
+        require(max_steps >= 1, "at least one step required");
+        if (absolute_tolerance < 0 || relative_tolerance < 0) throw DomainError("negative tolerance");
+        const bool diag = covariance_type == MLHIP_COVARIANCE_DIAGONAL;
+        if (diag && !mstats::em_diag_supported(data->d, (int)K))
+            throw Unsupported("diagonal-covariance EM is built for d <= 32 and K <= 64");
+        em_iterate(data, (int)K, diag, mixing, means, covariances, max_steps, absolute_tolerance, relative_tolerance, steps_done,
+                   converged, log_likelihood, log_likelihood_history);
     });
 }
 

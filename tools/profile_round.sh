@@ -17,7 +17,7 @@ echo "[profile] bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_stats" -- python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$O/${TAG}_stats.txt" 2>&1
 find "$O/${TAG}_stats" -name '*kernel_stats.csv' -exec cp {} "$O/${TAG}_bench_kernel_stats.csv" \;
 echo "[profile] kernel stats done"
-for pass in fetch:FETCH_SIZE write:WRITE_SIZE "sq:SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU"; do
+for pass in fetch:FETCH_SIZE write:WRITE_SIZE "sq:SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU" "stall:SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS"; do
     name=${pass%%:*}; counters=${pass#*:}
     rocprofv3 --kernel-trace --pmc $counters --output-format csv -d "$O/${TAG}_pmc_$name" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$O/${TAG}_pmc_$name.txt" 2>&1
     find "$O/${TAG}_pmc_$name" -name '*counter_collection.csv' -exec cp {} "$O/${TAG}_pmc_$name.csv" \;
@@ -29,5 +29,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_kmstats" -- p
 find "$O/${TAG}_kmstats" -name '*kernel_stats.csv' -exec cp {} "$O/${TAG}_kmeans_kernel_stats.csv" \;
 echo "[profile] kmeans done"
 rm -rf "$O/${TAG}_kmstats"
-rm -rf "$O/${TAG}_stats" "$O/${TAG}"_pmc_fetch "$O/${TAG}"_pmc_write "$O/${TAG}"_pmc_sq
+# third workload: diagonal-covariance EM (BASELINE.json configs[1]): bench line + kernel trace
+python3 "$R/bench.py" --workload em-diag --steps 50 --warmup 5 > "$O/${TAG}_diag_bench.json" 2> "$O/${TAG}_diag_bench.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_dgstats" -- python3 "$R/bench.py" --workload em-diag --steps 50 --warmup 5 --no-cpu-baseline > "$O/${TAG}_dgstats.txt" 2>&1
+find "$O/${TAG}_dgstats" -name '*kernel_stats.csv' -exec cp {} "$O/${TAG}_diag_kernel_stats.csv" \;
+echo "[profile] diag done"
+rm -rf "$O/${TAG}_dgstats"
+rm -rf "$O/${TAG}_stats" "$O/${TAG}"_pmc_fetch "$O/${TAG}"_pmc_write "$O/${TAG}"_pmc_sq "$O/${TAG}"_pmc_stall
 ls -la "$O" | grep "$TAG"

@@ -34,11 +34,14 @@ def condense(path):
 def main():
     tag = sys.argv[1]
     src, dst = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-    for name in ("bench.json", "bench_kernel_stats.csv", "kmeans_bench.json", "kmeans_kernel_stats.csv"):
+    for name in ("bench.json", "bench_kernel_stats.csv", "kmeans_bench.json", "kmeans_kernel_stats.csv", "diag_bench.json",
+                 "diag_kernel_stats.csv"):
         if os.path.exists(os.path.join(src, f"{tag}_{name}")):
             shutil.copy(os.path.join(src, f"{tag}_{name}"), os.path.join(dst, f"{tag}_{name}"))
     summary = {}
-    for p in ("fetch", "write", "sq"):
+    for p in ("fetch", "write", "sq", "stall"):
+        if not os.path.exists(os.path.join(src, f"{tag}_pmc_{p}.csv")):
+            continue
         c = condense(os.path.join(src, f"{tag}_pmc_{p}.csv"))
         summary[p] = c
         with open(os.path.join(dst, f"{tag}_pmc_{p}.csv"), "w") as f:
@@ -57,6 +60,7 @@ def main():
     e_f, e_w = pick(summary["fetch"], "em_estep", "FETCH_SIZE"), pick(summary["write"], "em_estep", "WRITE_SIZE")
     m_f, m_w = pick(summary["fetch"], "em_mstats_wide", "FETCH_SIZE"), pick(summary["write"], "em_mstats_wide", "WRITE_SIZE")
     traffic = {
+        "_tag": tag,
         "_comment": "HBM bytes per kernel launch at N=10M d=32 K=64 from rocprofv3 PMC (separate --pmc passes): FETCH_SIZE (KiB "
                     "units) doubled as MI355X_MICROARCH.md prescribes for gfx950 streaming reads, plus WRITE_SIZE (KiB, exact). "
                     f"Sources: profiles/{tag}_pmc_fetch.csv, profiles/{tag}_pmc_write.csv",
