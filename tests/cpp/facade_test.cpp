@@ -14,6 +14,10 @@
 #include "ML/KMeans.hpp"
 #include "ML/LinearAlgebra.hpp"
 #include "ML/LinearRegression.hpp"
+#include "ML/Device.hpp"
+#include "mlhip.h"
+#include <unistd.h>
+#include <string>
 
 static int failures = 0;
 #define CHECK(cond) do { if (!(cond)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); ++failures; } } while (0)
@@ -282,6 +286,32 @@ static void gpu_checks()
     CHECK(std::isfinite(resid) && resid < total);
     lambda[2] = -1;
     CHECK_THROWS(ml::LinearRegression::calculate_XXt_beta(X, y, XXt, decomposition, lambda), std::domain_error);
+
+    // Native RCCL from C++ (no Python, no hook): a context with the library's own communicator becomes the facade's context.
+    // (One GPU here: a 1-rank communicator -- RCCL refuses two ranks on one device; every step still goes through
+    // ncclAllReduce on the context's stream.)
+    mlhip_ctx* rccl_ctx = nullptr;
+    CHECK(mlhip_ctx_create(0, &rccl_ctx) == MLHIP_OK);
+    const std::string id_file = "/tmp/mlhip_rccl_id_" + std::to_string(static_cast<long>(getpid()));
+    const int rc = mlhip_ctx_init_rccl_file(rccl_ctx, id_file.c_str(), 1, 0);
+    if (rc != MLHIP_OK) std::printf("FAIL mlhip_ctx_init_rccl_file: %s\n", mlhip_last_error());
+    CHECK(rc == MLHIP_OK);
+    int ranks = 0;
+    CHECK(mlhip_ctx_rccl_ranks(rccl_ctx, &ranks) == MLHIP_OK && ranks == 1);
+    ml::device::set_context(rccl_ctx);
+    ml::EM em_rccl(K);
+    em_rccl.set_absolute_tolerance(1e-8);
+    em_rccl.set_relative_tolerance(1e-8);
+    em_rccl.set_maximum_steps(100);
+    em_rccl.set_means_initialiser(std::make_shared<ml::Clustering::KPP>());
+    em_rccl.set_seed(63413131);
+    CHECK(em_rccl.fit(data));
+    CHECK(em_rccl.log_likelihood() == em.log_likelihood());      // a sum over one rank is the identity: bit-identical
+    CHECK(em_rccl.steps_done() == em.steps_done());
+    em_rccl.release_device_data();                               // (its HBM block belongs to rccl_ctx)
+    ml::device::set_context(nullptr);
+    CHECK(mlhip_ctx_destroy(rccl_ctx) == MLHIP_OK);
+    unlink(id_file.c_str());
 }
 
 int main(int argc, char** argv)
