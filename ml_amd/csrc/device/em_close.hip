@@ -18,9 +18,14 @@ namespace {
 
 __device__ __forceinline__ int sidx(int a, int b) { return a * (a + 1) / 2 + b; }   // stats_index
 
+constexpr int NT = 64;    // ONE wave per component: the factorization is a chain of short dependent steps, and a wave-wide
+                          // barrier costs next to nothing where a 4-wave workgroup barrier per step cost 40 of 63 us (d = 32)
+
 /// LAYOUT: 0 = estep_param_stride records (VALU E-step / fused small kernel), 2 = estep_mfma4_param_stride records.
-template <int LAYOUT>
-__global__ __launch_bounds__(256) void em_close_kernel(const double* __restrict__ stats, int K, int d, int D,
+/// DT: the padded dimension when d <= 32 (the thread's column of W = L^-1 then lives in registers, loops fully unrolled),
+/// 0 = any d <= 64 (that column goes through LDS).
+template <int LAYOUT, int DT>
+__global__ __launch_bounds__(NT) void em_close_kernel(const double* __restrict__ stats, int K, int d, int D,
                                                         const double* __restrict__ shift, double n_global, double refine_limit,
                                                         double* __restrict__ mixing, double* __restrict__ means,
                                                         double* __restrict__ covs, double* __restrict__ records, int PS,
@@ -39,7 +44,7 @@ __global__ __launch_bounds__(256) void em_close_kernel(const double* __restrict_
     __shared__ int codes[128];
     const int k = blockIdx.x, tid = threadIdx.x;
 
-    for (int e = tid; e < F; e += 256) s[e] = stats[(size_t)k * F + e];
+    for (int e = tid; e < F; e += NT) s[e] = stats[(size_t)k * F + e];
     __syncthreads();
     const double s0 = s[sidx(d, d)];
     if (tid < d) {
@@ -49,7 +54,7 @@ __global__ __launch_bounds__(256) void em_close_kernel(const double* __restrict_
     }
     if (tid == 0) { s_mix = s0 / n_global; mixing[k] = s_mix; }                      // ML/EM.cpp:257
     __syncthreads();
-    for (int e = tid; e < d * d; e += 256) {
+    for (int e = tid; e < d * d; e += NT) {
         const int a = e % d, b = e / d;                                              // element (a, b), column-major
         const int hi = a > b ? a : b, lo = a > b ? b : a;
         double v = (s[sidx(hi, lo)] - s[sidx(d, hi)] * m[lo]) / s0;
@@ -87,8 +92,24 @@ __global__ __launch_bounds__(256) void em_close_kernel(const double* __restrict_
         if (tid >= j && tid < d) A[j * d + tid] = tid == j ? s_ljj : tcol[tid] / s_ljj;
         __syncthreads();
     }
-    // ---- W = L^-1, one thread per column (whitening_matrix)
-    if (tid < d) {
+    // ---- W = L^-1, one thread per column (whitening_matrix). Entries above the diagonal are exact zeros, so the host's sum
+    // over l = col .. i-1 may as well start at l = 0 (t - L * 0 == t): uniform loop bounds, same bits.
+    if constexpr (DT > 0) {
+        double w[DT];
+        const int col = tid < d ? tid : 0;
+#pragma unroll
+        for (int i = 0; i < DT; ++i) {
+            double t = (i == col) ? 1.0 : 0.0;
+#pragma unroll
+            for (int l = 0; l < i; ++l) t -= (i < d ? A[l * d + i] : 0.0) * w[l];
+            w[i] = (i < col || i >= d) ? 0.0 : t / A[i * d + i];
+        }
+        if (tid < d) {
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+                if (i < d) W[col * d + i] = w[i];
+        }
+    } else if (tid < d) {
         const int col = tid;
         for (int i = 0; i < d; ++i) {
             if (i < col) { W[col * d + i] = 0.0; continue; }
@@ -97,7 +118,7 @@ __global__ __launch_bounds__(256) void em_close_kernel(const double* __restrict_
             W[col * d + i] = t / A[i * d + i];
         }
     }
-    if (tid == 64) {                                                                 // (another wave than the column solvers)
+    if (tid == 0) {
         double ldh = 0.0;
         for (int j = 0; j < d; ++j) ldh += log(A[j * d + j]);
         s_ldh = ldh;
@@ -125,7 +146,7 @@ __global__ __launch_bounds__(256) void em_close_kernel(const double* __restrict_
     const double coef = log(s_mix) - s_ldh;
     if constexpr (LAYOUT == 2) {
         const int Q = D / 4, NB = Q * (Q + 1) / 2;
-        for (int e = tid; e < NB * 16; e += 256) {
+        for (int e = tid; e < NB * 16; e += NT) {
             const int t = e / 16, kk = (e % 16) / 4, i = e % 4;
             int C = 0;
             while (C + 1 < Q && (C + 1) * Q - (C + 1) * C / 2 <= t) ++C;             // column-quad-major block order
@@ -133,14 +154,14 @@ __global__ __launch_bounds__(256) void em_close_kernel(const double* __restrict_
             const int row = 4 * R + i, col = 4 * C + kk;
             rec[e] = (row < d && col <= row) ? W[col * d + row] : 0.0;
         }
-        for (int j = tid; j < D; j += 256) {
+        for (int j = tid; j < D; j += NT) {
             rec[NB * 16 + j] = j < d ? mean[j] : 0.0;
             rec[NB * 16 + D + j] = j < d ? -c[j] : 0.0;
         }
         if (tid == 0) rec[NB * 16 + 2 * D] = coef;
     } else {
-        for (int j = tid; j < D; j += 256) rec[j] = j < d ? mean[j] : 0.0;
-        for (int e = tid; e < D * (D + 1) / 2; e += 256) {
+        for (int j = tid; j < D; j += NT) rec[j] = j < d ? mean[j] : 0.0;
+        for (int e = tid; e < D * (D + 1) / 2; e += NT) {
             int j = 0;
             while ((j + 1) * (j + 2) / 2 <= e) ++j;                                  // packed lower triangle, row by row
             const int l = e - j * (j + 1) / 2;
@@ -206,12 +227,33 @@ void launch_em_close(const CloseArgs& a, hipStream_t stream)
 {
     const int d = a.d;
     const size_t smem = sizeof(double) * ((size_t)stats_count(d) + 2 * (size_t)d * d + 4 * (size_t)d);
-    if (a.layout == 2)
-        hipLaunchKernelGGL(em_close_kernel<2>, dim3(a.K), dim3(256), smem, stream, a.stats, a.K, d, a.D, a.shift, a.n_global,
-                           a.refine_limit, a.mixing, a.means, a.covs, a.records, estep_mfma4_param_stride(a.D), a.info);
-    else
-        hipLaunchKernelGGL(em_close_kernel<0>, dim3(a.K), dim3(256), smem, stream, a.stats, a.K, d, a.D, a.shift, a.n_global,
-                           a.refine_limit, a.mixing, a.means, a.covs, a.records, estep_param_stride(a.D), a.info);
+#define MLHIP_CLOSE(LAYOUT, DT, PS) \
+    hipLaunchKernelGGL((em_close_kernel<LAYOUT, DT>), dim3(a.K), dim3(NT), smem, stream, a.stats, a.K, d, a.D, a.shift, a.n_global, \
+                       a.refine_limit, a.mixing, a.means, a.covs, a.records, PS, a.info)
+    if (a.layout == 2) {
+        const int PS = estep_mfma4_param_stride(a.D);
+        switch (a.D) {
+        case 12: MLHIP_CLOSE(2, 12, PS); break;
+        case 16: MLHIP_CLOSE(2, 16, PS); break;
+        case 20: MLHIP_CLOSE(2, 20, PS); break;
+        case 24: MLHIP_CLOSE(2, 24, PS); break;
+        case 28: MLHIP_CLOSE(2, 28, PS); break;
+        case 32: MLHIP_CLOSE(2, 32, PS); break;
+        default: MLHIP_CLOSE(2, 0, PS); break;
+        }
+    } else {
+        const int PS = estep_param_stride(a.D);
+        switch (a.D) {
+        case 1: MLHIP_CLOSE(0, 1, PS); break;
+        case 2: MLHIP_CLOSE(0, 2, PS); break;
+        case 3: MLHIP_CLOSE(0, 3, PS); break;
+        case 4: MLHIP_CLOSE(0, 4, PS); break;
+        case 6: MLHIP_CLOSE(0, 6, PS); break;
+        case 8: MLHIP_CLOSE(0, 8, PS); break;
+        default: MLHIP_CLOSE(0, 0, PS); break;
+        }
+    }
+#undef MLHIP_CLOSE
 }
 
 void launch_em_close_diag(const CloseArgs& a, hipStream_t stream)

@@ -36,34 +36,42 @@ __global__ __launch_bounds__(256) void fill_resp_kernel(const uint32_t* __restri
     }
 }
 
-/// stats[k*F + f] = sum_b partials[b][k][f]  (b ascending: deterministic), stats[K*F] = sum of ll partials.
+/// stats[k*F + f] = sum_b partials[b][k][f], stats[K*F] = sum of the ll partials. Fixed order, hence reproducible run to run
+/// and identical on every rank: 32 outputs per workgroup, each summed by 8 threads over the block slices b = s, s + 8, ...
+/// (ascending), the 8 slice sums added in ascending s. (One thread per output walking all partial blocks, as in round 1, is
+/// latency-bound: 24 us for the 528 outputs of the diagonal configuration, a sixth of its iteration.)
+constexpr int kRedOut = 32, kRedSlices = 8;
 __global__ __launch_bounds__(256) void em_reduce_kernel(const double* __restrict__ partials, int n_blocks, int KP, int FP,
                                                          int K, int F, const double* __restrict__ ll_partials,
                                                          int n_ll, double* __restrict__ stats)
 {
+    __shared__ double red[256];
     const int total = K * F;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if ((int)blockIdx.x * 256 < total) {
+    if ((int)blockIdx.x * kRedOut < total) {
+        const int o = threadIdx.x & (kRedOut - 1), sl = threadIdx.x / kRedOut;
+        const int e = blockIdx.x * kRedOut + o;
+        double s = 0.0;
         if (e < total) {
             const int k = e / F, f = e - k * F;
             const double* p = partials + (size_t)k * FP + f;
-            // same left-to-right order as a plain loop, but 16 loads are issued before the adds consume them
-            // (a dependent load->add chain over 256 partials is latency-bound: ~80 us).
-            double s = 0.0;
-            int b = 0;
-            for (; b + 16 <= n_blocks; b += 16) {
-                double v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = p[(size_t)(b + u) * KP * FP];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) s += v[u];
+            int b = sl;
+            for (; b + 3 * kRedSlices < n_blocks; b += 4 * kRedSlices) {          // 4 loads in flight, consumed in order
+                const double v0 = p[(size_t)b * KP * FP], v1 = p[(size_t)(b + kRedSlices) * KP * FP];
+                const double v2 = p[(size_t)(b + 2 * kRedSlices) * KP * FP], v3 = p[(size_t)(b + 3 * kRedSlices) * KP * FP];
+                s += v0; s += v1; s += v2; s += v3;
             }
-            for (; b < n_blocks; ++b) s += p[(size_t)b * KP * FP];
-            stats[e] = s;
+            for (; b < n_blocks; b += kRedSlices) s += p[(size_t)b * KP * FP];
+        }
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (sl == 0 && e < total) {
+            double t = red[o];
+#pragma unroll
+            for (int q = 1; q < kRedSlices; ++q) t += red[q * kRedOut + o];
+            stats[e] = t;
         }
     } else {
         // one extra block: log-likelihood partials (fixed-order tree)
-        __shared__ double red[256];
         double s = 0.0;
         for (int b = threadIdx.x; b < n_ll; b += 256) s += ll_partials[b];
         red[threadIdx.x] = s;
@@ -205,7 +213,7 @@ void launch_em_reduce(const MstatsArgs& a, int num_cus, int grid_x, hipStream_t 
     const Plan p = make_plan(a.d, a.K, num_cus);
     const int F = stats_count(a.d);
     const int total = a.K * F;
-    const int red_blocks = (total + 255) / 256 + 1;
+    const int red_blocks = (total + kRedOut - 1) / kRedOut + 1;
     // a self-normalising pass left (max, exp-sum) per sample: finish lse and produce the log-likelihood partials first
     const double* ll = a.ll_partials;
     int n_ll = a.n_ll_partials;
@@ -222,7 +230,7 @@ void launch_em_reduce(const MstatsArgs& a, int num_cus, int grid_x, hipStream_t 
 void launch_em_reduce_blocks(const double* partials, int n_partials, int KP, int FP, int K, int F, const double* ll_partials,
                              int n_ll, double* stats, hipStream_t stream)
 {
-    const int red_blocks = (K * F + 255) / 256 + 1;
+    const int red_blocks = (K * F + kRedOut - 1) / kRedOut + 1;
     hipLaunchKernelGGL(em_reduce_kernel, dim3(red_blocks), dim3(256), 0, stream, partials, n_partials, KP, FP, K, F, ll_partials,
                        n_ll, stats);
 }

@@ -212,7 +212,7 @@ struct mlhip_data {
     bool diag_step = false;
     std::vector<double> diag_mixing, diag_means, diag_vars;
     // mlhip_em_iterate: parameters and the next E-step's records stay on the device between iterations
-    DevBuf params_next, it_mixing[2], it_means[2], it_covs[2], it_info;
+    DevBuf params_next, it_pack[2];      // it_pack: [info (1 + 2K) | mixing (K) | means (K d) | covariances], one D2H covers it
     PinnedBuf it_info_host;
     // source of the last statistics pass (for the per-component refinement pass)
     int stats_mode = 0;
@@ -230,8 +230,7 @@ struct mlhip_data {
     {
         for (DevBuf* b : {&xt, &shift_dev, &lw, &lse, &esum, &ll_partials, &params_dev, &partials, &stats_dev, &resp_dev,
                           &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_partials, &km_out, &km_mind, &km_probe, &km_scale, &km_cnorm, &km_xt_pad,
-                          &refine_shift, &refine_stats, &params_next, &it_mixing[0], &it_mixing[1], &it_means[0], &it_means[1],
-                          &it_covs[0], &it_covs[1], &it_info})
+                          &refine_shift, &refine_stats, &params_next, &it_pack[0], &it_pack[1]})
             b->release();
         it_info_host.release();
         params_host.release(); stats_host.release(); km_host.release();
@@ -1025,13 +1024,12 @@ void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* mean
     const size_t n_cov = diag ? (size_t)K * d : (size_t)K * d * d;
     const size_t F = diag ? diag_stats_count(d) : stats_count(d);
     const size_t n_info = em_close_info_doubles(K);
-    for (int b = 0; b < 2; ++b) {
-        data->it_mixing[b].reserve(sizeof(double) * K);
-        data->it_means[b].reserve(sizeof(double) * K * d);
-        data->it_covs[b].reserve(sizeof(double) * n_cov);
-    }
-    data->it_info.reserve(sizeof(double) * n_info);
-    data->it_info_host.reserve(sizeof(double) * (n_info + K + (size_t)K * d + n_cov));   // info, then a parameter set (diag shadow)
+    const size_t n_pack = n_info + K + (size_t)K * d + n_cov;
+    for (int b = 0; b < 2; ++b) data->it_pack[b].reserve(sizeof(double) * n_pack);
+    data->it_info_host.reserve(sizeof(double) * n_pack);          // info, then (diagonal mode) a shadow of the newest parameters
+    auto pack_mixing = [&](int b) { return data->it_pack[b].as<double>() + n_info; };
+    auto pack_means = [&](int b) { return pack_mixing(b) + K; };
+    auto pack_covs = [&](int b) { return pack_means(b) + (size_t)K * d; };
     if (diag) {
         upload_diag_records(data, K, mixing, means, covs, data->params_dev);
         upload_diag_records(data, K, mixing, means, covs, data->params_next);          // (the neutral padding records live in both)
@@ -1070,17 +1068,14 @@ void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* mean
         ca.stats = data->stats_dev.as<double>(); ca.K = K; ca.d = d; ca.D = data->D;
         ca.shift = data->shift_dev.as<double>(); ca.n_global = (double)data->n_global;
         ca.layout = data->estep_variant; ca.refine_limit = limit;
-        ca.mixing = data->it_mixing[nxt].as<double>(); ca.means = data->it_means[nxt].as<double>();
-        ca.covs = data->it_covs[nxt].as<double>(); ca.records = data->params_next.as<double>();
-        ca.info = data->it_info.as<double>();
+        ca.mixing = pack_mixing(nxt); ca.means = pack_means(nxt);
+        ca.covs = pack_covs(nxt); ca.records = data->params_next.as<double>();
+        ca.info = data->it_pack[nxt].as<double>();
         ctx->timed("em_close", [&] { if (diag) launch_em_close_diag(ca, ctx->stream); else launch_em_close(ca, ctx->stream); });
         HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipMemcpyAsync(info, data->it_info.p, sizeof(double) * n_info, hipMemcpyDeviceToHost, ctx->stream));
-        if (diag) {      // small: keep a host shadow of the newest parameters (ensure_lw needs the inputs of the last E-step)
-            HIP_CHECK(hipMemcpyAsync(shadow, ca.mixing, sizeof(double) * K, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_CHECK(hipMemcpyAsync(shadow + K, ca.means, sizeof(double) * K * d, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_CHECK(hipMemcpyAsync(shadow + K + (size_t)K * d, ca.covs, sizeof(double) * n_cov, hipMemcpyDeviceToHost, ctx->stream));
-        }
+        // one read-back: the info block and, in diagonal mode (small), a host shadow of the newest parameters right behind it
+        // (ensure_lw needs the inputs of the last E-step)
+        HIP_CHECK(hipMemcpyAsync(info, data->it_pack[nxt].p, sizeof(double) * (diag ? n_pack : n_info), hipMemcpyDeviceToHost, ctx->stream));
         ctx->sync();
         tr.mark("iteration (device close)");
         const double ll = info[0] / (double)data->n_global - (double)d * log_two_pi() / 2;   // ML/EM.cpp:197-198, 211
@@ -1132,9 +1127,9 @@ void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* mean
     }
     // the caller's arrays receive the newest parameters; the device keeps the records of the LAST E-step in params_dev
     if (!latest_on_host) {
-        HIP_CHECK(hipMemcpyAsync(mixing, data->it_mixing[cur].p, sizeof(double) * K, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_CHECK(hipMemcpyAsync(means, data->it_means[cur].p, sizeof(double) * K * d, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_CHECK(hipMemcpyAsync(covs, data->it_covs[cur].p, sizeof(double) * n_cov, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(mixing, pack_mixing(cur), sizeof(double) * K, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(means, pack_means(cur), sizeof(double) * K * d, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(covs, pack_covs(cur), sizeof(double) * n_cov, hipMemcpyDeviceToHost, ctx->stream));
         ctx->sync();
     }
     if (diag && !prev_mixing.empty()) {   // ensure_lw rebuilds the block from the inputs of the last E-step
