@@ -3,7 +3,7 @@
 // kernel's 160 accumulator registers, pushed it into spills. Cody-Waite reduction x = n ln2 + r, |r| <= ln2 / 2, degree-13
 // Taylor polynomial (truncation 0.3466^14 / 14! = 4e-18 relative), scaling by ldexp (correct gradual underflow; exactly 0
 // below -745.2 like the library function). Measured against the correctly rounded result: <= 1 ulp
-// (tests/test_host_facade.py::test_exp_nonpos). Plain C++: the same text compiles for the host in that test.
+// (tests/test_exp_nonpos.py). Plain C++: the same text compiles for the host in that test.
 #pragma once
 #include <cmath>
 
