@@ -159,7 +159,11 @@ class Job:
                     self.rccl_ranks = self.ctx.rccl_ranks
                 except Exception as e:                       # stay measurable: fall back to torch's communicator
                     print(f"[bench] native RCCL unavailable on rank {rank} ({e}); using torch.distributed", file=sys.stderr)
-            if self.allreduce == "none":
+            if self.allreduce == "none" and args.allreduce == "gloo":
+                mldist.install_allreduce(self.ctx, world, rank, on_device=False)
+                self.allreduce = "gloo on the host (single-GPU rehearsal of the multi-rank path)"
+                self.rccl_ranks = 0
+            elif self.allreduce == "none":
                 mldist.install_allreduce(self.ctx, world, rank)
                 self.allreduce = "torch.distributed nccl hook"
                 self.rccl_ranks = dist.get_world_size()
@@ -177,7 +181,7 @@ class Job:
     def max_over_ranks(self, seconds):
         if self.world == 1:
             return seconds
-        t = self.torch.tensor([seconds], dtype=self.torch.float64, device="cuda")
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device="cpu" if self.args.allreduce == "gloo" else "cuda")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -395,7 +399,9 @@ def launch_ranks(args):
     before this process has imported torch or opened a HIP context (a process that has touched the GPU is never
     re-executed). Rank 0 of the children prints the JSON line on the inherited stdout; their exit status is ours."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)]
+    # the launcher's argparse would claim `--n` as an abbreviation of its own options: hand the children the long form
+    cmd += ["--samples" if a == "--n" else ("--samples=" + a[4:] if a.startswith("--n=") else a) for a in sys.argv[1:]]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # this pool's driver only supports dmabuf IPC (RCCL needs it)
     env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // args.gpus)))
@@ -433,14 +439,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=None, help="total samples (default: the BASELINE.json configuration)")
+    # (option names must not be abbreviations of torch.distributed.run's own options: its argparse would claim them)
+    ap.add_argument("--samples", "--n", dest="n", type=int, default=None,
+                    help="total samples (default: the BASELINE.json configuration)")
     ap.add_argument("--dim", type=int, default=None)
     ap.add_argument("--components", type=int, default=None, help="mixture components / clusters")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the K-means `secondary` object of the N=1 EM line")
     ap.add_argument("--cpu-samples", type=int, default=200_000)
-    ap.add_argument("--allreduce", choices=("native", "torch"), default="native",
-                    help="native: ncclAllReduce on the library's own RCCL communicator; torch: torch.distributed hook")
+    ap.add_argument("--allreduce", choices=("native", "torch", "gloo"), default="native",
+                    help="native: ncclAllReduce on the library's own RCCL communicator; torch: torch.distributed nccl hook; "
+                         "gloo: (rehearsal on ONE GPU) process group and statistics all-reduce over gloo on the host, every "
+                         "rank on cuda:0 -- RCCL refuses two ranks on one device, this exercises everything else of the "
+                         "multi-rank path")
     ap.add_argument("--force-hook", action="store_true",
                     help="(diagnostic) single rank, but with the RCCL all-reduce installed (1-rank communicator)")
     ap.add_argument("--per-step-calls", action="store_true",
@@ -466,6 +477,9 @@ def main():
     import torch
     import torch.distributed as dist
 
+    rehearsal = args.allreduce == "gloo"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     # RCCL prints a version banner on the C-level stdout when its first communicator comes up; stdout is reserved for
     # the one JSON line, so fd 1 points at stderr until the communicators exist.
@@ -473,12 +487,14 @@ def main():
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
     try:
-        if world > 1:
+        if world > 1 and rehearsal:
+            dist.init_process_group("gloo")
+        elif world > 1:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         elif args.force_hook:
             dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1,
                                     device_id=torch.device("cuda", local_rank))
-        if world > 1 or args.force_hook:
+        if (world > 1 or args.force_hook) and not rehearsal:
             warm = torch.zeros(1, dtype=torch.float64, device="cuda")
             dist.all_reduce(warm)                      # creates torch's communicator (and its banner) now
             torch.cuda.synchronize()

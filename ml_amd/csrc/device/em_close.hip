@@ -79,43 +79,69 @@ __global__ __launch_bounds__(NT) void em_close_kernel(const double* __restrict__
         info[1 + k] = flag;
     }
 
-    // ---- Cholesky, column by column (host/em_math.cpp cholesky_lower): row i forms its own sequential dot product
-    for (int j = 0; j < d; ++j) {
-        if (tid >= j && tid < d) {
-            double t = A[j * d + tid];
-            for (int l = 0; l < j; ++l) t -= A[l * d + tid] * A[l * d + j];
-            tcol[tid] = t;
-        }
-        __syncthreads();
-        if (tid == 0) s_ljj = sqrt(tcol[j]);
-        __syncthreads();
-        if (tid >= j && tid < d) A[j * d + tid] = tid == j ? s_ljj : tcol[tid] / s_ljj;
-        __syncthreads();
-    }
-    // ---- W = L^-1, one thread per column (whitening_matrix). Entries above the diagonal are exact zeros, so the host's sum
-    // over l = col .. i-1 may as well start at l = 0 (t - L * 0 == t): uniform loop bounds, same bits.
+    // ---- Cholesky (host/em_math.cpp cholesky_lower) and W = L^-1 (whitening_matrix).
     if constexpr (DT > 0) {
+        // d <= 32: thread i keeps ROW i of the factor in registers; what another thread's row contributes arrives through
+        // v_readlane (wave-uniform lane index -> an SGPR pair, used directly as the multiplier). No LDS round trips and no
+        // barriers inside the factorization: the chain of dependent steps is the arithmetic itself. Every thread forms the
+        // very dot products of the host loops, term by term in their order.
+        auto lane_value = [](double v, int lane) {
+            return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+        };
+        double Li[DT];
+#pragma unroll
+        for (int c0 = 0; c0 < DT; ++c0) Li[c0] = (tid < d && c0 < d) ? A[c0 * d + tid] : 0.0;   // A(tid, c0)
+#pragma unroll
+        for (int jj = 0; jj < DT; ++jj) {
+            if (jj < d) {                                                                // (uniform)
+                double t = Li[jj];
+#pragma unroll
+                for (int l = 0; l < jj; ++l) t -= Li[l] * lane_value(Li[l], jj);         // L(i,l) * L(j,l)
+                const double ljj = sqrt(lane_value(t, jj));
+                Li[jj] = tid == jj ? ljj : t / ljj;                                      // rows above the diagonal: unused
+            }
+        }
+        // W, one thread per column `col`: w[i] = ((i == col) - sum_{l<i} L(i,l) w[l]) / L(i,i). Entries above the diagonal are
+        // exact zeros, so the host's sum over l = col .. i-1 may as well start at l = 0 (t - L * 0 == t): same bits.
         double w[DT];
-        const int col = tid < d ? tid : 0;
+        const int col = tid;
 #pragma unroll
-        for (int i = 0; i < DT; ++i) {
-            double t = (i == col) ? 1.0 : 0.0;
+        for (int ii = 0; ii < DT; ++ii) {
+            double t = (ii == col) ? 1.0 : 0.0;
 #pragma unroll
-            for (int l = 0; l < i; ++l) t -= (i < d ? A[l * d + i] : 0.0) * w[l];
-            w[i] = (i < col || i >= d) ? 0.0 : t / A[i * d + i];
+            for (int l = 0; l < ii; ++l) t -= lane_value(Li[l], ii < d ? ii : 0) * w[l];
+            w[ii] = (ii < col || ii >= d) ? 0.0 : t / lane_value(Li[ii], ii < d ? ii : 0);
         }
         if (tid < d) {
 #pragma unroll
-            for (int i = 0; i < DT; ++i)
-                if (i < d) W[col * d + i] = w[i];
+            for (int c0 = 0; c0 < DT; ++c0)
+                if (c0 < d) {
+                    A[c0 * d + tid] = Li[c0];                                            // L back to LDS (log det, generic readers)
+                    W[col * d + c0] = w[c0];
+                }
         }
-    } else if (tid < d) {
-        const int col = tid;
-        for (int i = 0; i < d; ++i) {
-            if (i < col) { W[col * d + i] = 0.0; continue; }
-            double t = (i == col) ? 1.0 : 0.0;
-            for (int l = col; l < i; ++l) t -= A[l * d + i] * W[col * d + l];
-            W[col * d + i] = t / A[i * d + i];
+        __syncthreads();
+    } else {
+        for (int jj = 0; jj < d; ++jj) {
+            if (tid >= jj && tid < d) {
+                double t = A[jj * d + tid];
+                for (int l = 0; l < jj; ++l) t -= A[l * d + tid] * A[l * d + jj];
+                tcol[tid] = t;
+            }
+            __syncthreads();
+            if (tid == 0) s_ljj = sqrt(tcol[jj]);
+            __syncthreads();
+            if (tid >= jj && tid < d) A[jj * d + tid] = tid == jj ? s_ljj : tcol[tid] / s_ljj;
+            __syncthreads();
+        }
+        if (tid < d) {
+            const int col = tid;
+            for (int ii = 0; ii < d; ++ii) {
+                if (ii < col) { W[col * d + ii] = 0.0; continue; }
+                double t = (ii == col) ? 1.0 : 0.0;
+                for (int l = col; l < ii; ++l) t -= A[l * d + ii] * W[col * d + l];
+                W[col * d + ii] = t / A[ii * d + ii];
+            }
         }
     }
     if (tid == 0) {
