@@ -27,6 +27,50 @@ namespace {
 
 constexpr int NW = 8;   // waves per workgroup
 
+/// Partner values for all-reductions over lane bits 3, 4, 5 without the LDS pipe (a __shfl_xor of a double is two
+/// ds_bpermute: ~100 cycles of latency each, six of them in a row in the staging phase where every wave of the CU waits):
+/// bit 3 by a DPP row rotation, bits 4 and 5 by v_permlane16_swap / v_permlane32_swap.
+__device__ __forceinline__ double partner_xor8(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x128, 0xf, 0xf, false);   // row_ror:8
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x128, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <bool BIT5> __device__ __forceinline__ void partners_swap(double v, double& a, double& b)
+{
+    // a = v, b = v; swap: afterwards (a, b) hold {own half-or-row value, partner's} such that op(a, b) is the pairwise result
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    if constexpr (BIT5) {
+        const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        a = __hiloint2double((int)h[0], (int)l[0]);
+        b = __hiloint2double((int)h[1], (int)l[1]);
+    } else {
+        const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        a = __hiloint2double((int)h[0], (int)l[0]);
+        b = __hiloint2double((int)h[1], (int)l[1]);
+    }
+}
+__device__ __forceinline__ double allreduce_max_bits345(double v)
+{
+    double a, b;
+    v = fmax(v, partner_xor8(v));
+    partners_swap<false>(v, a, b);
+    v = fmax(a, b);
+    partners_swap<true>(v, a, b);
+    return fmax(a, b);
+}
+__device__ __forceinline__ double allreduce_sum_bits345(double v)
+{
+    double a, b;
+    v += partner_xor8(v);
+    partners_swap<false>(v, a, b);
+    v = a + b;
+    partners_swap<true>(v, a, b);
+    return a + b;
+}
+
 template <int RBW, int CBW, int EXP, int DM>
 __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
     const double* __restrict__ xt, size_t ldx, uint32_t n, int d, int D, const double* __restrict__ shift,
@@ -98,9 +142,7 @@ __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
                 if (cg * NRV + it >= K) rv[it] = -__builtin_inf();          // components beyond K: exp(-inf) = 0
                 m = fmax(m, rv[it]);
             }
-            m = fmax(m, __shfl_xor(m, 8, 64));
-            m = fmax(m, __shfl_xor(m, 16, 64));
-            m = fmax(m, __shfl_xor(m, 32, 64));
+            m = allreduce_max_bits345(m);
             double sum = 0.0;
 #pragma unroll
             for (int it = 0; it < NRV; ++it) {
@@ -108,9 +150,7 @@ __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
                 sum += rv[it];
                 __builtin_amdgcn_sched_barrier(0);          // one exp at a time: interleaved they spill next to 160 accumulator registers
             }
-            sum += __shfl_xor(sum, 8, 64);
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
+            sum = allreduce_sum_bits345(sum);
             const double inv = live ? 1.0 / sum : 0.0;                      // padding samples contribute nothing
 #pragma unroll
             for (int it = 0; it < NRV; ++it) Rb[sR * RS + cg * NRV + it] = rv[it] * inv;
