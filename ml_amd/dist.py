@@ -68,7 +68,14 @@ def install_native_rccl(ctx, world_size, rank, group=None):
     torch.distributed (any backend) only carries its 128 bytes to the other ranks; the iterations never enter Python."""
     import torch.distributed as dist
     from . import _lib
-    box = [_lib.rccl_unique_id() if rank == 0 else None]
+    box = [None]
+    if rank == 0:
+        try:
+            box[0] = _lib.rccl_unique_id()
+        except Exception as e:      # e.g. librccl cannot be loaded: every rank must learn it, or the others wait forever
+            box[0] = ("error", str(e))
     if world_size > 1:
         dist.broadcast_object_list(box, src=0, group=group)
+    if isinstance(box[0], tuple):
+        raise RuntimeError("rank 0 could not create an RCCL unique id: " + box[0][1])
     ctx.init_rccl(box[0], world_size, rank)
