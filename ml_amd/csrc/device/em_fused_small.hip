@@ -21,6 +21,7 @@ namespace mlhip {
 namespace mstats {
 namespace {
 
+typedef __attribute__((address_space(3))) const double lds_cdouble;
 template <int D> constexpr int xss() { return D <= 4 ? 7 : 11; }   // LDS row stride of the sample tile (d + 2 doubles used), odd
 constexpr int RSS = 17;   // LDS row stride of one 16-component responsibility block, odd
 
@@ -39,9 +40,10 @@ __global__ __launch_bounds__(256, (D <= 4 && RBW <= 2) ? 3 : 2) void em_fused_sm
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double* Xw = smem + (size_t)wave * (TS * XSS + TS * RSS);
     double* Rw = Xw + TS * XSS;
-    double* recs = smem + 4 * (TS * XSS + TS * RSS);    // [K][PS]: all component records, staged once per workgroup
-    const int da = d + 1;
-    for (int e = tid; e < K * PS; e += 256) recs[e] = params[e];
+    double* recs = smem + 4 * (TS * XSS + TS * RSS);    // [KMAX][PS]: all component records, staged once per workgroup;
+    const int da = d + 1;                               // those beyond K are neutral (zeros, coef = -inf: log-density -inf)
+    for (int e = tid; e < KMAX * PS; e += 256)
+        recs[e] = e < K * PS ? params[e] : (e % PS == PS - 1 ? -__builtin_inf() : 0.0);
     __syncthreads();
 
     int offa[CB], offb[CB];
@@ -61,6 +63,13 @@ __global__ __launch_bounds__(256, (D <= 4 && RBW <= 2) ? 3 : 2) void em_fused_sm
     double ll_acc = 0.0;
 
     for (uint32_t tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += stride) {
+        // Loop-invariant values the compiler would otherwise keep in (spilled) SGPRs -- K (the guards below become scalar
+        // compares) and a constant LDS address per record read; the record base lives in ONE VGPR instead, every read is
+        // `ds_read base offset:imm` (see em_diag.hip: 191 SGPR spills at K = 64 before).
+        int Kt = K;
+        asm volatile("" : "+s"(Kt));
+        lds_cdouble* recv = (lds_cdouble*)recs;
+        asm volatile("" : "+v"(recv));
         const uint32_t i = tile * TS + lane;            // < n_pad: inside the allocation
         const bool live = i < n;
         double x[D];
@@ -71,19 +80,19 @@ __global__ __launch_bounds__(256, (D <= 4 && RBW <= 2) ? 3 : 2) void em_fused_sm
         double lwv[KMAX];
         double m = -__builtin_inf();
         // Guards are per group of 4 components (wave-uniform branches; per-component guards cost more in register copies
-        // at the joins than the arithmetic they save): inside a live group a record index beyond K is clamped and the
-        // value replaced by -inf, which the normalisation below turns into an exact 0.
+        // at the joins than the arithmetic they save): inside a live group a component beyond K reads a neutral record
+        // (coef = -inf), which the normalisation below turns into an exact 0.
 #pragma unroll
         for (int k4 = 0; k4 < KMAX; k4 += 4) {
-            if (k4 < K) {
+            if (k4 < Kt) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int k = k4 + u;
-                    const double* __restrict__ p = recs + min(k, K - 1) * PS;   // LDS broadcast reads
+                    lds_cdouble* p = recv + k * PS;                              // LDS broadcast reads
                     double z[D];
 #pragma unroll
                     for (int j = 0; j < D; ++j) z[j] = x[j] - p[j];
-                    const double* __restrict__ w = p + D;
+                    lds_cdouble* w = p + D;
                     double q = 0.0;
 #pragma unroll
                     for (int j = 0; j < D; ++j) {
@@ -92,7 +101,7 @@ __global__ __launch_bounds__(256, (D <= 4 && RBW <= 2) ? 3 : 2) void em_fused_sm
                         for (int l = 1; l <= j; ++l) y = __builtin_fma(w[j * (j + 1) / 2 + l], z[l], y);
                         q = __builtin_fma(y, y, q);
                     }
-                    const double lw = k < K ? __builtin_fma(-0.5, q, p[PS - 1]) : -__builtin_inf();
+                    const double lw = __builtin_fma(-0.5, q, p[PS - 1]);
                     lwv[k] = lw;
                     m = lw > m ? lw : m;
                 }
@@ -105,7 +114,7 @@ __global__ __launch_bounds__(256, (D <= 4 && RBW <= 2) ? 3 : 2) void em_fused_sm
         double s = 0.0;
 #pragma unroll
         for (int k4 = 0; k4 < KMAX; k4 += 4) {
-            if (k4 < K) {
+            if (k4 < Kt) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const double e = exp_nonpos(lwv[k4 + u] - m);       // exp(-inf) = 0 for the clamped tail
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(256, (D <= 4 && RBW <= 2) ? 3 : 2) void em_fused_sm
             for (int it = 0; it < 16; ++it) Rw[lane * RSS + it] = lwv[rb * 16 + it] * inv;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (rb * 16 < K) {                           // wave-uniform: skip all-zero row blocks
+            if (rb * 16 < Kt) {                          // wave-uniform: skip all-zero row blocks
 #pragma unroll 4
                 for (int sg = 0; sg < TS / 4; ++sg) {
                     const double av = rbase[sg * RSS];
@@ -181,7 +190,7 @@ int launch_t(const FusedArgs& a, int grid, hipStream_t stream)
 {
     constexpr int PS = D + D * (D + 1) / 2 + 1;
     constexpr int XSS = xss<D>();
-    const size_t smem = sizeof(double) * (4 * ((size_t)TS * XSS + (size_t)TS * RSS) + (size_t)a.K * PS);
+    const size_t smem = sizeof(double) * (4 * ((size_t)TS * XSS + (size_t)TS * RSS) + (size_t)16 * RBW * PS);
     hipLaunchKernelGGL((em_fused_small_kernel<D, RBW, CB>), dim3(grid), dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d, a.shift,
                        a.params, a.K, stats_count(a.d), a.lse, a.partials, RBW * 16, CB * 16, a.ll_partials);
     return grid;
