@@ -6,14 +6,19 @@
 //     |x - c_k|^2 = |x|^2 - 2 s_k,      s_k = x . c_k - |c_k|^2 / 2        (larger score = nearer)
 // and S = C X is a GEMM. So, per 64-sample group of a wave:
 //   1. scores by v_mfma_f64_16x16x4_f64: A = 16 centroids x 4 dims (LDS), B = 4 dims x 16 samples (coordinates held in
-//      VGPRs in operand layout), accumulator initialised with -|c|^2/2; every lane tracks best, second-best and argbest
-//      over the 4 x (K/16) clusters it sees, the four lane groups are merged by shuffles;
+//      VGPRs in operand layout), accumulator initialised with -|c|^2/2; every lane tracks best and second-best over the
+//      4 x (K/16) clusters it sees. The cluster's position is carried IN the score (low mantissa byte, see tagged()), and
+//      the four scores of an accumulator enter the tracking through their maximum (track_quad): 1.5 fp64 VALU
+//      operations per score -- they share the pipe with the MFMAs -- instead of 3 plus a compare and a select. The four
+//      lane groups are merged by shuffles;
 //   2. one lane per sample re-reads the sample's row and evaluates the EXACT direct-form distance to the winner with the
-//      same fma chain as the host point query (this is the min distance / inertia contribution that is stored);
-//   3. if best - second is not larger than E = 8 (d+2) 2^-53 (|x|^2 + max_k |c_k|^2) -- a bound on the rounding error of
-//      the two scores plus that of the direct form itself, with a factor 2 to spare -- the sample is AMBIGUOUS and the
-//      lane falls back to the full exact scan (strict '<', ascending k). Otherwise every other cluster is farther than
-//      the winner by more than all rounding involved, so the reference's comparison chain picks the same label.
+//      same fma chain as the host point query (this is the min distance / inertia contribution that is stored), and the
+//      scores of the winner's three quad-mates, which step 1 left out of the runner-up;
+//   3. if best - second (or best - a mate's score) is not larger than E = (8 (d+2) + 1024) 2^-53 (|x|^2 + max_k |c_k|^2)
+//      -- a bound on the rounding error of the two scores plus that of the direct form itself, with a factor 2 to spare,
+//      plus the 2 x 2^-44 the tags perturb the two scores by -- the sample is AMBIGUOUS and the lane falls back to the
+//      full exact scan (strict '<', ascending k). Otherwise every other cluster is farther than the winner by more than
+//      all rounding involved, so the reference's comparison chain picks the same label.
 // The labels are therefore bit-exact and the stored distances bit-identical to the VALU kernel (kmeans.hip); only the
 // work of the N x K search moves to the matrix pipe (2d flop per pair instead of 3d, no per-cluster compare chain).
 //
@@ -28,6 +33,11 @@ namespace {
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int BSM = 512;   // threads per workgroup (8 waves; two workgroups per CU)
+constexpr int kSubBlocks = 64;   // 16-cluster blocks per tagged sub-chunk: 4 accumulator rows x 64 blocks = 256 tags (one byte)
+/// Score of the rows that pad K to a multiple of 16: finite (a tag inserted into -inf's mantissa would make it a NaN),
+/// below every real score (|score| <= |x|^2 + max|c|^2 overflows long before it gets here).
+constexpr double kPadScore = -0x1p1020;
+constexpr int kQuadFactor = 16;   // quad tracking for K >= kQuadFactor * D (and D <= kRegDim)
 
 /// second = max(second, min(best, v)); best = max(best, v) as three bare v_min_f64 / v_max_f64. Written as machine
 /// instructions because fmin / fmax on values the compiler cannot prove to be non-signalling (matrix-core results,
@@ -43,9 +53,36 @@ __device__ __forceinline__ void track_top2(double& best, double& second, double 
         : "v"(v), "v"(order));
 }
 
-/// One sample's coordinates for the exact phase: registers up to d = 64, re-read from memory (L1/L2) above.
-template <int D> struct SampleRow {
-    static constexpr bool kInRegs = D <= kMidDim;
+/// Tagged scores: the low mantissa BYTE of a score is REPLACED by `tag` (wave-uniform: which of the 256 clusters of the
+/// current 1024-cluster sub-chunk this lane is looking at), so a running maximum carries its own argmax -- no separate
+/// index register, no compare + select. The perturbation is below 256 ulp = 2^-44 |score| <= 2^-44 (|x|^2 + max|c|^2);
+/// the certainty threshold (err_unit) carries it for both scores of a gap. The byte permute is a compiler builtin, not
+/// inline assembly, so that the compiler sees the first VALU reader of the matrix-core result and inserts the wait
+/// states itself.
+__device__ __forceinline__ double tagged(double v, int tag)
+{
+    // bytes 3..1 of the low word, byte 0 of the tag: selector {3, 2, 1, 4} over the byte string {tag (4..7), lo (0..3)}
+    const int lo = (int)__builtin_amdgcn_perm((unsigned)tag, (unsigned)__double2loint(v), 0x03020104u);
+    return __hiloint2double(__double2hiint(v), lo);
+}
+
+/// The four scores one accumulator holds for a sample (rows r = 0..3: clusters b + g + 4 r of block b) enter the top-2
+/// tracking through their MAXIMUM only: 3 + 3 fp64 VALU operations per four scores instead of 12 -- the fp64 min / max
+/// share the pipe with the matrix instructions, so they are what the loop pays for next to the MFMAs. What this loses is
+/// exactly the three quad-mates of the final winner (every other quad's losers are below that quad's maximum, which IS
+/// tracked); the exact phase scores those three itself (phase 2).
+__device__ __forceinline__ void track_quad(double& best, double& second, d4 acc, int tag0)
+{
+    const double t0 = tagged(acc[0], tag0), t1 = tagged(acc[1], tag0 + 1), t2 = tagged(acc[2], tag0 + 2),
+                 t3 = tagged(acc[3], tag0 + 3);
+    double m, u;
+    asm("v_max_f64 %0, %2, %3\n\tv_max_f64 %1, %4, %5\n\tv_max_f64 %0, %0, %1" : "=&v"(m), "=&v"(u) : "v"(t0), "v"(t1), "v"(t2), "v"(t3));
+    track_top2(best, second, m, 0);
+}
+
+/// One sample's coordinates for the exact phase: in registers (INREGS) or re-read from memory (L1/L2) at every use.
+template <int D, bool INREGS> struct SampleRow {
+    static constexpr bool kInRegs = INREGS;
     double x[kInRegs ? D : 1];
     const double* p;
     size_t ld;
@@ -67,7 +104,11 @@ template <int D> struct SampleRow {
 /// budget, i.e. large K): the table is streamed through LDS in chunks of KC clusters; the 8 waves of a workgroup then
 /// walk their 64-sample groups in lockstep (two barriers per chunk), keep the running best / second / argbest in
 /// registers across chunks, and the exact recheck reads the winner's centroid from global memory (L2).
-template <int D, bool USE_LDS, bool CHUNKED>
+///
+/// QUAD selects how the scores enter the top-2 tracking: tagged quad maxima + mate scores in the exact phase (the fp64
+/// VALU work of the scoring loop halves, the exact phase gains 3 d fma per sample: pays when K is large against d), or
+/// every score on its own with a separate argbest register (no extra work per sample: small K).
+template <int D, bool USE_LDS, bool CHUNKED, bool QUAD>
 __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
     const double* __restrict__ xt, size_t ldx, uint32_t n, uint32_t n_pad, int d, const double* __restrict__ cent, int K,
     const double* __restrict__ scale, uint32_t* __restrict__ labels, const uint32_t* __restrict__ old_labels,
@@ -77,15 +118,17 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
     constexpr int Q = D / 4;          // 4-dimension steps of the MFMA
     constexpr int NSB = D <= kMidDim ? 4 : 2;   // 16-sample blocks per wave: the coordinates take Q * NSB doubles per lane
     constexpr int GS = 16 * NSB;      // samples per wave group
-    // exact phase: fully unrolled on register-resident coordinates up to d = 64; above, rolled loops that re-read the
-    // sample (unrolling would let the compiler hoist all D loads back into registers)
-    constexpr int kExactUnroll = D <= kMidDim ? D : 8;   // 8 loads in flight per trip: a trip per load is latency-bound
+    // exact phase: fully unrolled on register-resident coordinates up to d = 64 (d = 32 with the mate scores: five fma
+    // chains run over the row, beyond that it spills); above, rolled loops that re-read the sample (unrolling would let
+    // the compiler hoist all D loads back into registers)
+    constexpr bool kRowInRegs = D <= (QUAD ? kRegDim : kMidDim);
+    constexpr int kExactUnroll = kRowInRegs ? D : 8;   // 8 loads in flight per trip: a trip per load is latency-bound
     constexpr int DS = D + 1;         // odd row stride of the centroid table: conflict-free A-operand reads
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int Kp = (K + 15) & ~15;
     const int KT = CHUNKED ? KC : Kp;          // rows of the LDS table (a multiple of 16)
     double* Cs = smem;                         // [KT][DS] centroids (padding rows zero)
-    double* cn = Cs + (size_t)KT * DS;         // [KT]  -|c|^2/2, -inf for padding rows
+    double* cn = Cs + (size_t)KT * DS;         // [KT]  -|c|^2/2, kPadScore for padding rows
     double* cmax_slot = cn + KT;               // [1]   max_k |c_k|^2
     u64* acc_lds = reinterpret_cast<u64*>(cmax_slot + 1);   // [K][3d+1] when USE_LDS
     __shared__ double red[2 * (BSM / 64)];
@@ -109,7 +152,7 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
         for (int k = tid; k < Kp; k += BSM) {
             double nn = 0.0;
             for (int j = 0; j < D; ++j) nn = __builtin_fma(Cs[k * DS + j], Cs[k * DS + j], nn);
-            cn[k] = k < K ? -0.5 * nn : -__builtin_inf();
+            cn[k] = k < K ? -0.5 * nn : kPadScore;
         }
         __syncthreads();
         if (tid < 64) {
@@ -134,7 +177,9 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
     }
     __syncthreads();
     const double cmax2 = *cmax_slot;
-    const double err_unit = 8.0 * (D + 2) * 0x1p-53;
+    // rounding of the two scores and of the direct form (8 (d+2) 2^-53, factor 2 to spare) + the tag perturbation of the two
+    // scores of the gap (2 x 2^-44 = 1024 x 2^-53)
+    const double err_unit = (8.0 * (D + 2) + (QUAD ? 1024.0 : 0.0)) * 0x1p-53;
 
     double inertia = 0.0, changed = 0.0;
     const uint32_t n_groups = n_pad / GS;
@@ -154,10 +199,16 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
         for (int q = 0; q < Q; ++q)
 #pragma unroll
             for (int sb = 0; sb < NSB; ++sb) xb[q][sb] = xt[(size_t)(4 * q + g) * ldx + base + 16 * sb + s];
-        double best[NSB], second[NSB];
-        int idx[NSB];
+        // QUAD: running winner over the sub-chunks done so far (tagged score, runner-up, first cluster of the winning
+        // sub-chunk) next to the sub-chunk's own best / second; otherwise best / second / idx run over all clusters
+        double gbest[NSB], gsecond[NSB], best[NSB], second[NSB];
+        int gbase[NSB], idx[NSB];
 #pragma unroll
-        for (int sb = 0; sb < NSB; ++sb) { best[sb] = -__builtin_inf(); second[sb] = -__builtin_inf(); idx[sb] = 0; }
+        for (int sb = 0; sb < NSB; ++sb) {
+            gbest[sb] = best[sb] = -__builtin_inf();
+            gsecond[sb] = second[sb] = -__builtin_inf();
+            gbase[sb] = idx[sb] = 0;
+        }
 
         for (int k0 = 0; k0 < Kp; k0 += KT) {
         const int rows = min(KT, Kp - k0);      // a multiple of 16
@@ -180,10 +231,30 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
                     if (gi < total) Cs[(gi / D) * DS + gi % D] = v[u];
                 }
             }
-            for (int k = tid; k < rows; k += BSM) cn[k] = cnorm[k0 + k];     // -inf for the padding rows
+            for (int k = tid; k < rows; k += BSM) cn[k] = cnorm[k0 + k];     // kPadScore for the padding rows
             __syncthreads();
         }
-        for (int cb = 0; cb < rows / 16; ++cb) {
+        for (int cb0 = 0; cb0 < rows / 16; cb0 += kSubBlocks) {
+        // ---- QUAD: one sub-chunk of up to 1024 clusters, tag = 4 (cb - cb0) + r identifies the cluster within it
+        const int cb_end = QUAD ? min(cb0 + kSubBlocks, rows / 16) : rows / 16;
+        if constexpr (QUAD) {
+#pragma unroll
+            for (int sb = 0; sb < NSB; ++sb) { best[sb] = -__builtin_inf(); second[sb] = -__builtin_inf(); }
+        }
+        // the four scores (accumulator rows) of block cb for one sample block
+        auto consume = [&](double& bst, double& sec, int& ix, const d4& sc, int cb) {
+            if constexpr (QUAD) {
+                track_quad(bst, sec, sc, 4 * (cb - cb0));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double v = sc[r];
+                    ix = (v > bst) ? k0 + 16 * cb + g + 4 * r : ix;
+                    track_top2(bst, sec, v, ix);
+                }
+            }
+        };
+        for (int cb = cb0; cb < cb_end; ++cb) {
             d4 init;
 #pragma unroll
             for (int r = 0; r < 4; ++r) init[r] = cn[16 * cb + g + 4 * r];           // D row = (lane>>4) + 4 r
@@ -200,9 +271,9 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
                 }
             } else {
                 // large d: the A operands are read step by step (Q of them would not fit next to the coordinates), and
-                // TWO cluster blocks advance together where the chunk has a second one: with 2 sample blocks per wave
+                // TWO cluster blocks advance together where the sub-chunk has a second one: with 2 sample blocks per wave
                 // that gives 4 independent accumulator chains instead of 2 (a dependent MFMA waits out the pipeline).
-                const bool pair = cb + 1 < rows / 16;               // wave-uniform
+                const bool pair = cb + 1 < cb_end;                  // wave-uniform
                 d4 acc2[NSB];
 #pragma unroll
                 for (int sb = 0; sb < NSB; ++sb) acc[sb] = init;
@@ -224,12 +295,7 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
                     }
 #pragma unroll
                     for (int sb = 0; sb < NSB; ++sb) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const double v = acc[sb][r];
-                            idx[sb] = (v > best[sb]) ? k0 + 16 * cb + g + 4 * r : idx[sb];
-                            track_top2(best[sb], second[sb], v, idx[sb]);
-                        }
+                        consume(best[sb], second[sb], idx[sb], acc[sb], cb);
                         acc[sb] = acc2[sb];                          // the second block goes through the common tail
                     }
                     ++cb;
@@ -243,23 +309,27 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
                 }
             }
 #pragma unroll
-            for (int sb = 0; sb < NSB; ++sb) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double v = acc[sb][r];
-                    idx[sb] = (v > best[sb]) ? k0 + 16 * cb + g + 4 * r : idx[sb];
-                    track_top2(best[sb], second[sb], v, idx[sb]);
-                }
-            }
+            for (int sb = 0; sb < NSB; ++sb) consume(best[sb], second[sb], idx[sb], acc[sb], cb);
         }
+        if constexpr (!QUAD) break;             // one pass over the chunk
+        // fold the sub-chunk into the running winner (5 VALU operations per sub-chunk)
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb) {
+            gbase[sb] = (best[sb] > gbest[sb]) ? k0 + 16 * cb0 : gbase[sb];
+            gsecond[sb] = fmax(fmax(gsecond[sb], second[sb]), fmin(gbest[sb], best[sb]));
+            gbest[sb] = fmax(gbest[sb], best[sb]);
+        }
+        }   // sub-chunks
         }   // chunks
         // merge the 4 lane groups (disjoint cluster subsets) of every sample block; lane (g, s) keeps sample 16 g + s
         double my_best = 0.0, my_second = 0.0;
         int my_idx = 0;
 #pragma unroll
         for (int sb = 0; sb < NSB; ++sb) {
-            double b = best[sb], sd = second[sb];
-            int ix = idx[sb];
+            double b = QUAD ? gbest[sb] : best[sb], sd = QUAD ? gsecond[sb] : second[sb];
+            // QUAD: cluster = first of the sub-chunk + 16 (tag >> 2) + 4 (tag & 3) + g  (accumulator row tag & 3 of block tag >> 2)
+            const int tag = __double2loint(b) & 255;
+            int ix = QUAD ? gbase[sb] + 16 * (tag >> 2) + 4 * (tag & 3) + g : idx[sb];
 #pragma unroll
             for (int off = 16; off <= 32; off <<= 1) {
                 const double b2 = __shfl_xor(b, off, 64), s2 = __shfl_xor(sd, off, 64);
@@ -276,12 +346,28 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
         // ---- phase 2: one lane per sample, exact arithmetic
         const uint32_t i = base + lane;
         if (active && lane < GS && i < n) {
-            const SampleRow<D> x(xt, ldx, i);
+            const SampleRow<D, kRowInRegs> x(xt, ldx, i);
             double xn = 0.0;
-            uint32_t arg = (uint32_t)my_idx;
+            // (scores that were all NaN never replaced the initial -inf: decoded tag 0 -> cluster g < 16 <= Kp; the clamp keeps
+            //  the winner's row inside the table whatever the scores were)
+            uint32_t arg = min((uint32_t)my_idx, (uint32_t)(K - 1));
             double dist = 0.0;
+            // the winner's three quad-mates (same block, same lane group, the other accumulator rows: clusters that differ
+            // from the winner in bits 2..3 only) did not take part in the runner-up tracking: their scores x.c - |c|^2/2 are
+            // evaluated here, with the rounding bound of the matrix-core scores (an ascending fma chain of d + 1 terms)
+            const uint32_t quad = arg & ~12u, rw = (arg >> 2) & 3u;
+            uint32_t mate[3];
+            double ms[3];
+            const double* mc[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                mate[t] = quad | (((rw + 1 + t) & 3u) << 2);
+                const uint32_t row = min(mate[t], (uint32_t)(K - 1));      // padding rows: any valid row, result unused
+                mc[t] = CHUNKED ? cent + (size_t)row * D : Cs + (size_t)row * DS;
+                ms[t] = !QUAD ? 0.0 : CHUNKED ? cnorm[row] : cn[row];
+            }
             {
-                // |x|^2 and the exact distance to the winner in one pass over the sample (two independent fma chains)
+                // |x|^2, the exact distance to the winner and the mates' scores in one pass over the sample
                 const double* c = CHUNKED ? cent + (size_t)arg * D : Cs + (size_t)arg * DS;
 #pragma unroll kExactUnroll
                 for (int j = 0; j < D; ++j) {
@@ -289,9 +375,18 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
                     xn = __builtin_fma(v, v, xn);
                     const double t = v - c[j];
                     dist = __builtin_fma(t, t, dist);
+                    if constexpr (QUAD) {
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) ms[m] = __builtin_fma(v, mc[m][j], ms[m]);
+                    }
                 }
             }
-            const bool certain = (my_best - my_second) > err_unit * (xn + cmax2);   // false for NaN / inf as well
+            const double margin = err_unit * (xn + cmax2);
+            bool certain = (my_best - my_second) > margin;                      // false for NaN / inf as well
+            if constexpr (QUAD) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) certain = certain && (mate[t] >= (uint32_t)K || (my_best - ms[t]) > margin);
+            }
             if (!certain) {
                 // ambiguous: the reference's own loop (ML/KMeans.cpp:155-163)
                 double bd = __builtin_inf();
@@ -352,7 +447,7 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
     }
 }
 
-/// cnorm[k] = -|c_k|^2 / 2 with the ascending-j fma chain used everywhere, -inf for the rows that pad K up to a multiple
+/// cnorm[k] = -|c_k|^2 / 2 with the ascending-j fma chain used everywhere, kPadScore for the rows that pad K up to a multiple
 /// of 16: computed once per step for the chunked-table kernel (per chunk and sweep it would be a serial chain of D
 /// dependent loads in front of every barrier).
 __global__ __launch_bounds__(256) void kmeans_cnorm_kernel(const double* __restrict__ cent, int K, int Kp, int D,
@@ -363,7 +458,7 @@ __global__ __launch_bounds__(256) void kmeans_cnorm_kernel(const double* __restr
     double nn = 0.0;
     if (k < K)
         for (int j = 0; j < D; ++j) nn = __builtin_fma(cent[(size_t)k * D + j], cent[(size_t)k * D + j], nn);
-    cnorm[k] = k < K ? -0.5 * nn : -__builtin_inf();
+    cnorm[k] = k < K ? -0.5 * nn : kPadScore;
 }
 
 template <int D>
@@ -382,6 +477,12 @@ int launch_t(const KmeansArgs& a, int num_cus, size_t pstride, hipStream_t strea
     const uint32_t need = (groups + BSM / 64 - 1) / (BSM / 64);
     if ((uint32_t)grid > need) grid = (int)(need ? need : 1);
     if ((size_t)grid * pstride > a.partials_capacity) return -2;
+    // quad tracking pays when the scoring loop's saving (1.5 K fp64 VALU operations per 64 samples) clearly exceeds the
+    // mate scores (3 d fma + 3 d table reads per sample). Measured (kernel time quad / plain, 5M samples): d = 4: 0.96 at
+    // K = 64, 0.80 at K = 256; d = 8: 1.15 at K = 32, 1.00 at 64, 0.88 at 256; d = 16: 1.04 at 128, 0.96 at 256; d = 32:
+    // 1.03 at 128, 0.98 at 256, 1.00 at 1024; d >= 64: 1.06 .. 1.22 everywhere (the row no longer fits in registers).
+    constexpr bool kQuadBuilt = D <= kRegDim;
+    const bool quad = kQuadBuilt && a.K >= kQuadFactor * D;
 #define MLHIP_KM_ARGS a.xt, a.ldx, a.n, n_pad, a.d, a.centroids, a.K, a.scale, a.labels, a.old_labels, a.have_old, a.min_dist, \
                       accumulate_here, a.partials, pstride
     if (chunked) {
@@ -389,11 +490,14 @@ int launch_t(const KmeansArgs& a, int num_cus, size_t pstride, hipStream_t strea
         if (KC < 16) KC = 16;
         const size_t smem = sizeof(double) * ((size_t)KC * (D + 1) + KC + 1);
         hipLaunchKernelGGL(kmeans_cnorm_kernel, dim3((Kp + 255) / 256), dim3(256), 0, stream, a.centroids, a.K, Kp, D, a.cnorm);
-        hipLaunchKernelGGL((kmeans_mfma_kernel<D, false, true>), dim3(grid), dim3(BSM), smem, stream, MLHIP_KM_ARGS, KC, a.cnorm);
+        if (quad) hipLaunchKernelGGL((kmeans_mfma_kernel<D, false, true, kQuadBuilt>), dim3(grid), dim3(BSM), smem, stream, MLHIP_KM_ARGS, KC, a.cnorm);
+        else      hipLaunchKernelGGL((kmeans_mfma_kernel<D, false, true, false>), dim3(grid), dim3(BSM), smem, stream, MLHIP_KM_ARGS, KC, a.cnorm);
     } else if (use_lds) {
-        hipLaunchKernelGGL((kmeans_mfma_kernel<D, true, false>), dim3(grid), dim3(BSM), table + accb, stream, MLHIP_KM_ARGS, 0, a.cnorm);
+        if (quad) hipLaunchKernelGGL((kmeans_mfma_kernel<D, true, false, kQuadBuilt>), dim3(grid), dim3(BSM), table + accb, stream, MLHIP_KM_ARGS, 0, a.cnorm);
+        else      hipLaunchKernelGGL((kmeans_mfma_kernel<D, true, false, false>), dim3(grid), dim3(BSM), table + accb, stream, MLHIP_KM_ARGS, 0, a.cnorm);
     } else {
-        hipLaunchKernelGGL((kmeans_mfma_kernel<D, false, false>), dim3(grid), dim3(BSM), table, stream, MLHIP_KM_ARGS, 0, a.cnorm);
+        if (quad) hipLaunchKernelGGL((kmeans_mfma_kernel<D, false, false, kQuadBuilt>), dim3(grid), dim3(BSM), table, stream, MLHIP_KM_ARGS, 0, a.cnorm);
+        else      hipLaunchKernelGGL((kmeans_mfma_kernel<D, false, false, false>), dim3(grid), dim3(BSM), table, stream, MLHIP_KM_ARGS, 0, a.cnorm);
     }
 #undef MLHIP_KM_ARGS
     if (a.accumulate && !use_lds) launch_kmeans_update(a, grid, pstride, stream);

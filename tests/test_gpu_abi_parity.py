@@ -309,6 +309,53 @@ def test_kmeans_mfma_and_valu_kernels_agree_bitwise(ctx, oracle, n, d, K, monkey
     assert np.array_equal(a[4][::step], ref)          # distances bit-identical to the oracle's fma chain
 
 
+@pytest.mark.parametrize("n,d,K", [(6000, 8, 256), (6000, 4, 70), (5000, 8, 2100), (5000, 16, 300), (4000, 32, 520),
+                                   (6000, 4, 5000), (4000, 12, 200)])
+def test_kmeans_quad_tracking_sees_the_winners_mates(ctx, oracle, n, d, K, monkeypatch):
+    """For K >= 16 d the scoring loop tracks the maximum of each accumulator's four scores (clusters k, k+4, k+8, k+12 of a
+    16-block) and the exact phase scores the winner's three quad-mates itself. Ties and near-ties INSIDE a quad --
+    duplicated mates, samples on and next to the bisector of two mates, in the first block, in the padded last block
+    and beyond the first 1024-cluster sub-chunk -- must still give the reference's label and distance bit for bit."""
+    rng = np.random.default_rng(7 * n + d + K)
+    C = 2.0 * rng.standard_normal((K, d))
+    X = np.ascontiguousarray(C[rng.integers(0, K, n)] + 0.7 * rng.standard_normal((n, d)))
+    last = 16 * ((K - 1) // 16)                       # first cluster of the last (possibly padded) block
+    pairs = [(0, 4), (1, 13), (18, 26), (last, last + 4 if last + 4 < K else last + 1), (K - 1, K - 5)]
+    if K > 1100:
+        pairs += [(1030, 1038), (1024 + 16 * 3 + 2, 1024 + 16 * 3 + 14)]
+    C[pairs[0][1]] = C[pairs[0][0]]                   # a duplicated quad-mate: exact tie for every sample near it
+    X[:40] = C[pairs[0][0]] + 0.01 * rng.standard_normal((40, d))
+    row = 40
+    for a, b in pairs[1:]:
+        mid = 0.5 * (C[a] + C[b])
+        X[row:row + 8] = mid                          # on the bisector (up to the rounding of the midpoint)
+        for e in (1e-15, 1e-13, 1e-11, 1e-8):         # and next to it, on either side
+            X[row + 8] = mid + e * (C[a] - C[b])
+            X[row + 9] = mid - e * (C[a] - C[b])
+            row += 2
+        row += 8
+    res = {}
+    ctx.timing_enable(False)
+    for variant in ("mfma", "valu"):
+        if variant == "valu":
+            monkeypatch.setenv("MLHIP_KMEANS", "valu")
+        else:
+            monkeypatch.delenv("MLHIP_KMEANS", raising=False)
+        dt = _data(ctx, X)
+        inertia, changed, counts, C1 = dt.kmeans_step(C)
+        res[variant] = (inertia, counts, C1, dt.kmeans_labels(), dt.min_squared_distances(C))
+        dt.close()
+    monkeypatch.delenv("MLHIP_KMEANS", raising=False)
+    a, b = res["mfma"], res["valu"]
+    km = oracle.KMeans(K)
+    km.set_centroids(C, n)
+    km.assignment_step(X)
+    assert np.array_equal(a[3], km.labels)
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    ref = np.array([km.assign_label(X[i])[1] for i in range(0, row)])
+    assert np.array_equal(a[4][:row], ref)            # the contested samples' distances, bit-identical to the oracle
+
+
 @pytest.mark.parametrize("d", [8, 4])        # d = 4: the fused small-shape kernel (the refinement rebuilds lw first)
 @pytest.mark.parametrize("sigma,tol", [(1.0, 1e-12), (1e-2, 1e-11), (1e-4, 1e-10), (1e-6, 1e-8)])
 def test_tight_clusters_far_from_the_global_mean(ctx, oracle, sigma, tol, d):
