@@ -79,3 +79,39 @@ def test_random_shape(ctx, oracle, d, K, n, seed):
     km.update_step(X)
     assert np.array_equal(counts, np.bincount(km.labels, minlength=K).astype(float))
     assert relerr(C1, km.centroids) < 1e-13
+
+
+def _lattice_cases():
+    rng = np.random.default_rng(77)
+    cases = []
+    for d in (4, 4, 8, 8, 8, 12, 16, 16, 20, 32, 32, 5, 3, 40, 64):
+        for K in (int(rng.choice([16, 31, 64, 100])), int(rng.choice([130, 256, 300, 520, 1100, 2500]))):
+            cases.append((d, K, int(rng.integers(1500, 4000)), int(rng.integers(1 << 30))))
+    return cases
+
+
+@pytest.mark.parametrize("d,K,n,seed", _lattice_cases())
+def test_kmeans_on_an_integer_lattice(ctx, oracle, d, K, n, seed):
+    """Samples and centroids on a small integer lattice: distances are small integers, so EXACT ties between clusters
+    are everywhere (and every product is exact, so the matrix-core scores tie exactly too). The reference's rule --
+    strict '<', first minimum wins (ML/KMeans.cpp:155-163) -- must come out of both tracking modes of the matrix-core
+    kernel (per-score for small K, tagged quad maxima for K >= 16 d), of the chunked-table variant and of the VALU
+    kernel: labels, counts, inertia and per-sample distances bit for bit."""
+    from ml_amd import _lib
+    rng = np.random.default_rng(seed)
+    C = rng.integers(-3, 4, (K, d)).astype(np.float64)
+    X = np.ascontiguousarray(rng.integers(-3, 4, (n, d)).astype(np.float64))
+    X[: n // 4] = C[rng.integers(0, K, n // 4)]                      # zero distances as well
+    dt = _lib.Data(ctx, X)
+    inertia, changed, counts, C1 = dt.kmeans_step(C)
+    labels = dt.kmeans_labels()
+    dist = dt.min_squared_distances(C)
+    dt.close()
+    km = oracle.KMeans(K)
+    km.set_centroids(C, n)
+    km.assignment_step(X)
+    assert np.array_equal(labels, km.labels)
+    ref = np.array([km.assign_label(X[i])[1] for i in range(0, n, 7)])
+    assert np.array_equal(dist[::7], ref)
+    assert inertia == km.inertia                                     # sums of small integers: exact in any order
+    assert np.array_equal(counts, np.bincount(km.labels, minlength=K).astype(float))
