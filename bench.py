@@ -192,26 +192,30 @@ class Job:
         self.dist.all_gather_object(box, obj)
         return box
 
-    def timed(self, run, steps, warmup):
+    def timed(self, run, steps, warmup, names=(), live=True):
         """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks.
-        run(k) executes k steps."""
+        run(k) executes k steps. Returns (seconds, {kernel family: average ms per launch}).
+        live: the kernels of the timed steps themselves carry HIP event pairs on the stream they are launched on; the
+        pairs are only recorded inside the region and read after its closing barrier, so the region runs without any
+        extra synchronisation (cost: a few microseconds per pair -- 0.1 % of an EM iteration, 0.5 % of a K-means step).
+        not live (iterations of ~0.1 ms, where those microseconds would be 10 % of the metric): the region runs without
+        events and the same K steps are replayed with them right afterwards."""
         if warmup:
             run(warmup)
+        self.ctx.timing_reset()
+        live = live and not self.args.replay_events
+        self.ctx.timing_enable(bool(names) and live)
         self.barrier()
         t0 = time.perf_counter()
         run(steps)
         self.barrier()
-        return self.max_over_ranks(time.perf_counter() - t0)
-
-    def kernel_ms(self, run, names, reps=3):
-        """Per-kernel device time (HIP events on the kernels' own stream) in a separate pass, so that the event
-        synchronisation does not perturb the timed region."""
-        self.ctx.timing_enable(True)
-        self.ctx.timing_reset()
-        run(reps)
-        out = {name: self.ctx.timing_get(name)[0] for name in names}
+        elapsed = self.max_over_ranks(time.perf_counter() - t0)
+        if names and not live:
+            self.ctx.timing_enable(True)
+            run(steps)
+        kernel_ms = {name: self.ctx.timing_get(name)[0] for name in names}
         self.ctx.timing_enable(False)
-        return out
+        return elapsed, kernel_ms
 
     def close(self):
         self.ctx.close()
@@ -244,11 +248,19 @@ def kmeans_measure(job, n, d, K, steps, warmup, with_cpu, cpu_samples):
     state = {"C": mix.means + 0.3 * np.random.default_rng(1).standard_normal((K, d)), "inertia": None}
 
     def run(k):
-        for _ in range(k):
-            state["inertia"], _, _, state["C"] = data.kmeans_step(state["C"])
+        if job.args.per_step_calls:
+            for _ in range(k):
+                state["inertia"], _, _, state["C"] = data.kmeans_step(state["C"])
+            return
+        # the reference's step loop (ML/KMeans.cpp:80-110) in one call, tolerance 0: it can only stop early on identical
+        # labels; exactly k steps are executed either way -- a converged loop is entered again
+        done = 0
+        while done < k:
+            n_steps, _, state["inertia"], _, state["C"], _ = data.kmeans_iterate(state["C"], k - done, 0.0)
+            done += n_steps
 
-    elapsed = job.timed(run, steps, warmup)
-    k_ms = job.kernel_ms(run, ["kmeans_assign"])["kmeans_assign"]
+    elapsed, ms = job.timed(run, steps, warmup, ["kmeans_assign"])
+    k_ms = ms["kmeans_assign"]
     n_locals = job.gather(hi - lo)
     out = None
     if job.rank == 0:
@@ -284,6 +296,13 @@ def kmeans_measure(job, n, d, K, steps, warmup, with_cpu, cpu_samples):
     return out
 
 
+def elapsed_hint_ms(n, d, K, diagonal, world):
+    """Rough iteration time (60 TFLOP/s full, 20 TFLOP/s diagonal / small shapes): only decides whether event pairs
+    inside the timed region are negligible next to an iteration."""
+    flops = (diag_flops if diagonal else algorithmic_flops)(n / world, d, K)
+    return flops / ((20e12 if diagonal or d < 12 else 60e12)) * 1e3
+
+
 def em_measure(job, n, d, K, steps, warmup, with_cpu, cpu_samples, diagonal=False):
     """EM iterations/sec (full covariances, or the diagonal extension), N row-sharded over the ranks."""
     import numpy as np
@@ -312,9 +331,8 @@ def em_measure(job, n, d, K, steps, warmup, with_cpu, cpu_samples, diagonal=Fals
                                                                                        0.0, 0.0, diagonal)
         assert done == k
 
-    elapsed = job.timed(run, steps, warmup)
     names = ["em_diag", "em_close"] if diagonal else ["em_estep", "em_mstats", "em_fused", "em_close"]
-    ms = job.kernel_ms(run, names)
+    elapsed, ms = job.timed(run, steps, warmup, names, live=(elapsed_hint_ms(n, d, K, diagonal, job.world) >= 1.0))
     ms.setdefault("em_fused_wide", 0.0)
     n_locals = job.gather(hi - lo)
     if job.rank != 0:
@@ -455,8 +473,10 @@ def main():
     ap.add_argument("--force-hook", action="store_true",
                     help="(diagnostic) single rank, but with the RCCL all-reduce installed (1-rank communicator)")
     ap.add_argument("--per-step-calls", action="store_true",
-                    help="(A/B) one mlhip_em_step call per iteration with the closing arithmetic on the host, instead of "
-                         "mlhip_em_iterate (device-side closing)")
+                    help="(A/B) one mlhip_em_step / mlhip_kmeans_step call per iteration with the closing arithmetic on the host, instead of "
+                         "mlhip_em_iterate / mlhip_kmeans_iterate (device-side closing)")
+    ap.add_argument("--replay-events", action="store_true",
+                    help="(A/B) no HIP events inside the timed region: the kernel times come from a replay of the same steps")
     ap.add_argument("--dry-launch", action="store_true",
                     help="(test) start the ranks, join a gloo group, report the launch environment; no GPU work")
     args = ap.parse_args()

@@ -185,6 +185,17 @@ int mlhip_process_covariance(uint32_t d, const double* covariance, double* inver
  *        centroid is the origin (:184). Labels stay on the device for mlhip_kmeans_labels. */
 int mlhip_kmeans_step(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* centroids,
                       double* inertia, uint64_t* n_changed, double* counts, double* centroids_out);
+/* The step loop of KMeans::fit_once (ML/KMeans.cpp:80-110) in ONE call: up to max_steps trips of mlhip_kmeans_step with the
+ * reference's two stopping rules -- the same labels as in the previous trip (:84-89; the centroids then stay as they are), or
+ * from the second trip on a squared centroid shift |C - C_old|_F^2 below absolute_tolerance, followed by one more assignment
+ * (:103-108). Between two tests everything stays on the device: the update's sums are all-reduced there, divided by the counts
+ * (empty cluster -> origin, :184) and become the next trip's centroid table without a host round trip; the host reads back
+ * 2 + K (d + 1) doubles per trip for the two tests. Same results, bit for bit, as the loop over mlhip_kmeans_step.
+ *   in/out: centroids[d*K] (start -> final); out: old_centroids[d*K] (the table before the last update; may be NULL),
+ *   counts[K] of the last update (may be NULL), *inertia of the last assignment, *steps_done, *converged. */
+int mlhip_kmeans_iterate(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, double* centroids, double* old_centroids,
+                         uint32_t max_steps, double absolute_tolerance, uint32_t* steps_done, int* converged,
+                         double* inertia, double* counts);
 /* Assignment only (KMeans::assignment_step, :167-178): labels + inertia, no update. */
 int mlhip_kmeans_assign(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* centroids,
                         double* inertia, uint64_t* n_changed);
@@ -197,7 +208,9 @@ int mlhip_min_squared_distances(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, co
 
 /* ---- timing (for bench.py / profiling) -------------------------------------------------------------- */
 /* Average device time in ms of the named kernel family over its launches since the last reset, measured with
- * HIP events on the context's stream. name: "em_estep", "em_mstats", "kmeans_assign". Returns count in *launches. */
+ * HIP events on the context's stream. name: "em_estep", "em_mstats", "kmeans_assign", ... Returns count in *launches.
+ * While enabled, every launch is bracketed by a pair of events that is only recorded; the times are read (one stream
+ * synchronisation) when mlhip_timing_get / _reset / _enable(off) is called, so a timed region is not perturbed. */
 int mlhip_timing_enable(mlhip_ctx* ctx, int on);
 int mlhip_timing_reset(mlhip_ctx* ctx);
 int mlhip_timing_get(mlhip_ctx* ctx, const char* name, double* avg_ms, uint64_t* launches);

@@ -345,6 +345,18 @@ class Data:
                                     dptr(counts), dptr(cout)))
         return inertia.value, changed.value, counts, cout
 
+    def kmeans_iterate(self, centroids, max_steps, atol=0.0):
+        """The step loop of KMeans::fit_once in one call (mlhip_kmeans_iterate): the centroid table stays on the device
+        between steps. Returns (steps_done, converged, inertia, counts, centroids, old_centroids)."""
+        cur = np.array(centroids, dtype=np.float64, order="C")
+        K = cur.shape[0]
+        assert cur.shape == (K, self.d)
+        old, counts = np.zeros((K, self.d)), np.zeros(K)
+        steps, conv, inertia = C.c_uint32(), C.c_int(), C.c_double()
+        check(lib.mlhip_kmeans_iterate(self.ctx.handle, self._h, K, dptr(cur), dptr(old), C.c_uint32(max_steps), C.c_double(atol),
+                                       C.byref(steps), C.byref(conv), C.byref(inertia), dptr(counts)))
+        return steps.value, bool(conv.value), inertia.value, counts, cur, old
+
     def kmeans_assign(self, centroids):
         centroids = np.ascontiguousarray(centroids, dtype=np.float64)
         K = centroids.shape[0]

@@ -141,5 +141,9 @@ size_t kmeans_scratch_doubles(int d, int K, int num_cus);
 /// Assignment kernel; returns the number of per-workgroup partials (>0) or <0 on error.
 int launch_kmeans_assign(const KmeansArgs& a, int num_cus, hipStream_t stream);
 void launch_kmeans_reduce(const KmeansArgs& a, int n_partials, hipStream_t stream);
+/// update_step's closing arithmetic on the (all-reduced) output block [inertia, changed, counts(K), sums(K*d)]: the sums
+/// become the means IN PLACE (empty cluster -> origin, ML/KMeans.cpp:184) and are written as the next centroid table
+/// next[K][D] (padded coordinates zero).
+void launch_kmeans_close(double* out, int K, int d, int D, double* next, hipStream_t stream);
 
 }  // namespace mlhip

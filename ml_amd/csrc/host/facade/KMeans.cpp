@@ -200,6 +200,19 @@ bool KMeans::fit_once(ConstMatrixRef data, mlhip_data* device_data, const bool e
     check(mlhip_ctx_world(ctx, &world, &rank));
     detail::init_centroids(*centroids_initialiser_, data, prng_, K, centroids_, ctx, device_data);   // identical on all ranks
 
+    if (!verbose_) {
+        // The whole step loop in one call: between two stopping tests the centroid table stays on the device (same
+        // arithmetic and the same decisions as the loop below, which prints the centroids of every step).
+        uint32_t steps = 0;
+        int converged = 0;
+        check(mlhip_kmeans_iterate(ctx, device_data, K, centroids_.data(), old_centroids_.data(), maximum_steps_, absolute_tolerance_,
+                                   &steps, &converged, &inertia_, work_vector_.data()));
+        steps_done_ = steps;
+        converged_ = converged != 0;
+        sequential_inertia(device_data, sample_size);
+        return converged_;
+    }
+
     MatrixXd updated(number_dimensions, K);
     for (unsigned int step = 0; step < maximum_steps_; ++step) {
         // Assignment + the per-cluster sums of the update in one pass over the resident data.

@@ -152,24 +152,43 @@ struct mlhip_ctx {
     PinnedBuf up_pin[2];
     // timing
     bool timing = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    typedef std::pair<hipEvent_t, hipEvent_t> EventPair;
+    std::vector<EventPair> spare_events;
+    std::vector<std::pair<const char*, EventPair>> pending;     // (names are string literals)
     std::map<std::string, Timer> timers;
 
     void use() const { HIP_CHECK(hipSetDevice(device)); }
     void sync() const { HIP_CHECK(hipStreamSynchronize(stream)); }
 
+    /// Device time of a launch by a pair of HIP events on the stream the kernel goes to. The pair is only RECORDED here;
+    /// the elapsed times are read when somebody asks (resolve_timers), so a timed region runs as it does untimed: no
+    /// synchronisation between launches, the clocks the chip holds under a back-to-back stream of kernels.
     template <class F> void timed(const char* name, F&& launch)
     {
         if (!timing) { launch(); return; }
-        HIP_CHECK(hipEventRecord(ev0, stream));
+        if (pending.size() >= 4096) resolve_timers();
+        EventPair e;
+        if (!spare_events.empty()) { e = spare_events.back(); spare_events.pop_back(); }
+        else { HIP_CHECK(hipEventCreate(&e.first)); HIP_CHECK(hipEventCreate(&e.second)); }
+        HIP_CHECK(hipEventRecord(e.first, stream));
         launch();
-        HIP_CHECK(hipEventRecord(ev1, stream));
-        HIP_CHECK(hipEventSynchronize(ev1));
-        float ms = 0;
-        HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
-        Timer& t = timers[name];
-        t.total_ms += ms;
-        t.launches += 1;
+        HIP_CHECK(hipEventRecord(e.second, stream));
+        pending.push_back({name, e});
+    }
+
+    void resolve_timers()
+    {
+        if (pending.empty()) return;
+        HIP_CHECK(hipEventSynchronize(pending.back().second.second));
+        for (auto& p : pending) {
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, p.second.first, p.second.second));
+            Timer& t = timers[p.first];
+            t.total_ms += ms;
+            t.launches += 1;
+            spare_events.push_back(p.second);
+        }
+        pending.clear();
     }
 
     /// Sum `count` host doubles across ranks (no-op single rank).
@@ -221,7 +240,7 @@ struct mlhip_data {
     DevBuf refine_shift, refine_stats;
     uint64_t refined_components = 0;   // diagnostic counter
     // K-means workspace
-    DevBuf km_labels[2], km_cent, km_partials, km_out, km_mind, km_probe, km_scale, km_cnorm, km_xt_pad;
+    DevBuf km_labels[2], km_cent, km_cent_next, km_partials, km_out, km_mind, km_probe, km_scale, km_cnorm, km_xt_pad;
     PinnedBuf km_host;
     int km_cur = 0;
     bool km_have_old = false;
@@ -229,7 +248,7 @@ struct mlhip_data {
     ~mlhip_data()
     {
         for (DevBuf* b : {&xt, &shift_dev, &lw, &lse, &esum, &ll_partials, &params_dev, &partials, &stats_dev, &resp_dev,
-                          &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_partials, &km_out, &km_mind, &km_probe, &km_scale, &km_cnorm, &km_xt_pad,
+                          &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_cent_next, &km_partials, &km_out, &km_mind, &km_probe, &km_scale, &km_cnorm, &km_xt_pad,
                           &refine_shift, &refine_stats, &params_next, &it_pack[0], &it_pack[1]})
             b->release();
         it_info_host.release();
@@ -807,34 +826,52 @@ void ensure_km_workspace(mlhip_data* dt, int K)
     dt->km_host.reserve(hb);
 }
 
-/// Assignment (+ optional accumulation); leaves all-reduced [inertia, changed, counts, sums] in km_host.
-void run_kmeans(mlhip_data* dt, int K, const double* centroids, bool accumulate, double* min_dist_out = nullptr)
+/// What one K-means pass runs on: the data block (a zero-padded copy where the matrix-core kernel needs one) and its rows.
+struct KmBlock {
+    const double* xt;
+    int D;
+};
+
+KmBlock km_block(mlhip_data* dt, int K)
 {
     mlhip_ctx* ctx = dt->ctx;
     ensure_km_workspace(dt, K);
     // The matrix-core kernel needs a multiple of 4 dimensions. For d = 1, 2, 3, 5, 6 (stored with D = d or 6 rows) and many
     // clusters it still beats the direct-form kernel (d = 6, K = 256: 1.9 -> 1.2 ms at N = 10M), so such blocks get a copy
     // padded with zero rows once: zero coordinates add exactly 0 to every distance, labels and sums are unchanged.
-    int D = dt->D;
-    const double* xt = dt->xt.as<double>();
-    if (D % 4 != 0 && K >= 128 && !std::getenv("MLHIP_KMEANS")) {
-        const int Dp = (D + 3) & ~3;
+    KmBlock b{dt->xt.as<double>(), dt->D};
+    if (b.D % 4 != 0 && K >= 128 && !std::getenv("MLHIP_KMEANS")) {
+        const int Dp = (b.D + 3) & ~3;
         if (!dt->km_xt_pad.p) {
             dt->km_xt_pad.reserve(sizeof(double) * dt->ldx * Dp);
             HIP_CHECK(hipMemsetAsync(dt->km_xt_pad.p, 0, sizeof(double) * dt->ldx * Dp, ctx->stream));
-            HIP_CHECK(hipMemcpyAsync(dt->km_xt_pad.p, dt->xt.p, sizeof(double) * dt->ldx * D, hipMemcpyDeviceToDevice, ctx->stream));
+            HIP_CHECK(hipMemcpyAsync(dt->km_xt_pad.p, dt->xt.p, sizeof(double) * dt->ldx * b.D, hipMemcpyDeviceToDevice, ctx->stream));
         }
-        D = Dp;
-        xt = dt->km_xt_pad.as<double>();
+        b.D = Dp;
+        b.xt = dt->km_xt_pad.as<double>();
     }
+    return b;
+}
+
+/// Host centroids [K][d] -> the device table km_cent [K][D] (padded coordinates zero).
+void km_upload_centroids(mlhip_data* dt, int K, const KmBlock& b, const double* centroids)
+{
+    mlhip_ctx* ctx = dt->ctx;
     double* ch = dt->km_host.as<double>();
     for (int k = 0; k < K; ++k)
-        for (int j = 0; j < D; ++j) ch[(size_t)k * D + j] = j < dt->d ? centroids[(size_t)k * dt->d + j] : 0.0;
-    HIP_CHECK(hipMemcpyAsync(dt->km_cent.p, ch, sizeof(double) * (size_t)K * D, hipMemcpyHostToDevice, ctx->stream));
-    ctx->sync();   // km_host is reused for the results below
+        for (int j = 0; j < b.D; ++j) ch[(size_t)k * b.D + j] = j < dt->d ? centroids[(size_t)k * dt->d + j] : 0.0;
+    HIP_CHECK(hipMemcpyAsync(dt->km_cent.p, ch, sizeof(double) * (size_t)K * b.D, hipMemcpyHostToDevice, ctx->stream));
+    ctx->sync();   // km_host is reused for the results
+}
+
+/// Assignment (+ optional accumulation) against the table in km_cent, partials reduced into km_out =
+/// [inertia, changed, counts, sums] and summed across ranks there when the all-reduce works on device memory.
+void km_launch(mlhip_data* dt, int K, const KmBlock& b, bool accumulate, double* min_dist_out)
+{
+    mlhip_ctx* ctx = dt->ctx;
     const int nxt = dt->km_cur ^ 1;
     KmeansArgs a{};
-    a.xt = xt; a.ldx = dt->ldx; a.n = dt->n; a.D = D; a.d = dt->d;
+    a.xt = b.xt; a.ldx = dt->ldx; a.n = dt->n; a.D = b.D; a.d = dt->d;
     a.centroids = dt->km_cent.as<double>(); a.K = K;
     a.scale = dt->km_scale.as<double>();
     a.labels = dt->km_labels[nxt].as<uint32_t>();
@@ -853,16 +890,106 @@ void run_kmeans(mlhip_data* dt, int K, const double* centroids, bool accumulate,
     HIP_CHECK(hipGetLastError());
     dt->km_cur = nxt;
     dt->km_have_old = true;
-    const size_t count = 2 + (accumulate ? (size_t)K * (dt->d + 1) : 0);
     if (ctx->reduce_fn && ctx->reduce_on_device) {
+        const size_t count = 2 + (accumulate ? (size_t)K * (dt->d + 1) : 0);
         if (ctx->reduce_fn(ctx->reduce_user, dt->km_out.as<double>(), count, 1, ctx->stream) != 0)
             throw std::runtime_error("all-reduce hook failed");
     }
+}
+
+/// km_out -> km_host (`count` doubles), summed across ranks on the host when the all-reduce works on host memory.
+void km_fetch(mlhip_data* dt, size_t count)
+{
+    mlhip_ctx* ctx = dt->ctx;
+    double* ch = dt->km_host.as<double>();
     HIP_CHECK(hipMemcpyAsync(ch, dt->km_out.p, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
     ctx->sync();
     if (ctx->reduce_fn && !ctx->reduce_on_device) {
         if (ctx->reduce_fn(ctx->reduce_user, ch, count, 0, ctx->stream) != 0) throw std::runtime_error("all-reduce hook failed");
     }
+}
+
+/// Assignment (+ optional accumulation); leaves all-reduced [inertia, changed, counts, sums] in km_host.
+void run_kmeans(mlhip_data* dt, int K, const double* centroids, bool accumulate, double* min_dist_out = nullptr)
+{
+    const KmBlock b = km_block(dt, K);
+    km_upload_centroids(dt, K, b, centroids);
+    km_launch(dt, K, b, accumulate, min_dist_out);
+    km_fetch(dt, 2 + (accumulate ? (size_t)K * (dt->d + 1) : 0));
+}
+
+/// update_step's closing arithmetic on the host (ML/KMeans.cpp:180-192 as sums / counts; empty cluster -> origin, :184).
+void km_close_host(const double* r, int K, int d, double* counts, double* centroids_out)
+{
+    for (int k = 0; k < K; ++k) {
+        const double c = r[2 + k];
+        if (counts) counts[k] = c;
+        for (int j = 0; j < d; ++j) centroids_out[(size_t)k * d + j] = c > 0 ? r[2 + K + (size_t)k * d + j] / c : 0.0;
+    }
+}
+
+/// The step loop of KMeans::fit_once (ML/KMeans.cpp:80-110). With the all-reduce on device memory (or none) the centroid
+/// table never leaves the device between trips: sums -> means -> next table by launch_kmeans_close, one read-back per trip
+/// for the two stopping tests. With a host-memory all-reduce (gloo rehearsals) every trip goes through run_kmeans.
+void km_iterate(mlhip_data* dt, int K, double* centroids, double* old_centroids, uint32_t max_steps, double atol,
+                uint32_t* steps_done, int* converged, double* inertia, double* counts)
+{
+    mlhip_ctx* ctx = dt->ctx;
+    const int d = dt->d;
+    const size_t kd = (size_t)K * d;
+    const bool device_route = !(ctx->reduce_fn && !ctx->reduce_on_device) && !std::getenv("MLHIP_KMEANS_HOST_LOOP");
+    const KmBlock b = km_block(dt, K);
+    std::vector<double> cur(centroids, centroids + kd), old(kd, 0.0), upd(kd);
+    if (device_route) {
+        dt->km_cent_next.reserve(sizeof(double) * (size_t)K * b.D);
+        km_upload_centroids(dt, K, b, cur.data());
+    }
+    *converged = 0;
+    *steps_done = 0;
+    for (uint32_t step = 0; step < max_steps; ++step) {
+        if (device_route) {
+            km_launch(dt, K, b, true, nullptr);
+            launch_kmeans_close(dt->km_out.as<double>(), K, d, b.D, dt->km_cent_next.as<double>(), ctx->stream);
+            km_fetch(dt, 2 + (size_t)K * (d + 1));
+            const double* r = dt->km_host.as<double>();
+            if (counts) std::copy(r + 2, r + 2 + K, counts);
+            std::copy(r + 2 + K, r + 2 + K + kd, upd.begin());
+        } else {
+            run_kmeans(dt, K, cur.data(), true);
+            km_close_host(dt->km_host.as<double>(), K, d, counts, upd.data());
+        }
+        const double* r = dt->km_host.as<double>();
+        *inertia = r[0];
+        const uint64_t changed = (uint64_t)std::llround(r[1]);
+        ++*steps_done;
+        if (step > 0 && changed == 0) {   // same labels twice (:84-89): the centroids stay as they are
+            *converged = 1;
+            break;
+        }
+        old.swap(cur);                    // update_step (:180-192)
+        cur.swap(upd);
+        if (device_route) std::swap(dt->km_cent, dt->km_cent_next);
+        if (step > 0) {
+            double shift = 0;
+            for (size_t t = 0; t < kd; ++t) {
+                const double delta = cur[t] - old[t];
+                shift += delta * delta;
+            }
+            if (shift < atol) {           // (:103-108) one more assignment under the final centroids
+                if (device_route) {
+                    km_launch(dt, K, b, false, nullptr);
+                    km_fetch(dt, 2);
+                } else {
+                    run_kmeans(dt, K, cur.data(), false);
+                }
+                *inertia = dt->km_host.as<double>()[0];
+                *converged = 1;
+                break;
+            }
+        }
+    }
+    std::copy(cur.begin(), cur.end(), centroids);
+    if (old_centroids) std::copy(old.begin(), old.end(), old_centroids);
 }
 
 /// K within one row-block group of the wide statistics kernel: the matrix-core E-step writes the log-responsibilities only and
@@ -1218,8 +1345,6 @@ int mlhip_ctx_create(int device_id, mlhip_ctx** out)
             HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
             ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
             HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-            HIP_CHECK(hipEventCreate(&ctx->ev0));
-            HIP_CHECK(hipEventCreate(&ctx->ev1));
         } catch (...) {
             delete ctx;
             throw;
@@ -1238,8 +1363,8 @@ int mlhip_ctx_destroy(mlhip_ctx* ctx)
         ctx->small_dev.release();
         ctx->small_host.release();
         for (int b = 0; b < 2; ++b) { ctx->up_stage[b].release(); ctx->up_pin[b].release(); }
-        if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-        if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+        for (auto& p : ctx->pending) ctx->spare_events.push_back(p.second);
+        for (auto& e : ctx->spare_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
     });
@@ -1638,15 +1763,22 @@ int mlhip_kmeans_step(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double
         require(centroids && inertia && n_changed && counts && centroids_out, "null argument");
         run_kmeans(data, (int)K, centroids, true);
         const double* r = data->km_host.as<double>();
-        const int d = data->d;
         *inertia = r[0];
         *n_changed = (uint64_t)std::llround(r[1]);
-        for (uint32_t k = 0; k < K; ++k) {
-            const double c = r[2 + k];
-            counts[k] = c;
-            for (int j = 0; j < d; ++j)
-                centroids_out[(size_t)k * d + j] = c > 0 ? r[2 + K + (size_t)k * d + j] / c : 0.0;   // empty -> origin (:184)
-        }
+        km_close_host(r, (int)K, data->d, counts, centroids_out);
+    });
+}
+
+int mlhip_kmeans_iterate(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, double* centroids, double* old_centroids,
+                         uint32_t max_steps, double absolute_tolerance, uint32_t* steps_done, int* converged,
+                         double* inertia, double* counts)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, K);
+        require(centroids && steps_done && converged && inertia, "null argument");
+        require(max_steps >= 1, "at least one step");
+        require(absolute_tolerance >= 0, "negative tolerance");
+        km_iterate(data, (int)K, centroids, old_centroids, max_steps, absolute_tolerance, steps_done, converged, inertia, counts);
     });
 }
 
@@ -1709,16 +1841,28 @@ int mlhip_min_squared_distances(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, co
 
 int mlhip_timing_enable(mlhip_ctx* ctx, int on)
 {
-    return guarded([&] { require(ctx, "null context"); ctx->timing = on != 0; });
+    return guarded([&] {
+        require(ctx, "null context");
+        ctx->use();
+        if (!on) ctx->resolve_timers();
+        ctx->timing = on != 0;
+    });
 }
 int mlhip_timing_reset(mlhip_ctx* ctx)
 {
-    return guarded([&] { require(ctx, "null context"); ctx->timers.clear(); });
+    return guarded([&] {
+        require(ctx, "null context");
+        ctx->use();
+        ctx->resolve_timers();
+        ctx->timers.clear();
+    });
 }
 int mlhip_timing_get(mlhip_ctx* ctx, const char* name, double* avg_ms, uint64_t* launches)
 {
     return guarded([&] {
         require(ctx && name && avg_ms && launches, "null argument");
+        ctx->use();
+        ctx->resolve_timers();
         auto it = ctx->timers.find(name);
         if (it == ctx->timers.end() || it->second.launches == 0) { *avg_ms = 0; *launches = 0; return; }
         *avg_ms = it->second.total_ms / (double)it->second.launches;

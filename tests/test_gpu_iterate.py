@@ -139,3 +139,75 @@ def test_device_close_can_be_switched_off(ctx, monkeypatch):
     steps, ll, mu = json.loads(out.stdout.strip().splitlines()[-1])
     assert steps == a[0] and abs(ll - a[2]) <= 1e-13 * abs(ll)
     assert relerr(np.array(mu), a[4]) < 1e-12
+
+
+def _kmeans_step_loop(dt, C, max_steps, atol):
+    """The facade's loop (ML/KMeans.cpp:80-110) made of mlhip_kmeans_step / mlhip_kmeans_assign calls."""
+    cur, old = np.array(C), np.zeros_like(C)
+    steps, conv, inertia, counts = 0, False, None, None
+    for step in range(max_steps):
+        inertia, changed, counts, upd = dt.kmeans_step(cur)
+        steps += 1
+        if step > 0 and changed == 0:
+            conv = True
+            break
+        old, cur = cur, upd
+        if step > 0:
+            shift = 0.0
+            for delta in (cur - old).ravel():
+                shift += delta * delta
+            if shift < atol:
+                inertia, _ = dt.kmeans_assign(cur)
+                conv = True
+                break
+    return steps, conv, inertia, counts, cur, old
+
+
+@pytest.mark.parametrize("d,K,n,max_steps,atol", [
+    (8, 256, 40000, 12, 0.0),       # quad-tracking kernel, stops on the step count
+    (8, 16, 6000, 200, 0.0),        # runs until the labels repeat
+    (4, 5, 3000, 200, 1e-6),        # stops on the centroid shift, then assigns once more
+    (2, 7, 5000, 300, 1e-10),       # direct-form kernel
+    (6, 130, 9000, 10, 0.0),        # zero-padded copy of the block (d = 6 -> 8 rows)
+    (32, 40, 4000, 100, 1e-8),
+    (16, 3, 500, 2, 0.0),
+    (3, 4, 60, 1, 0.0),             # a single step
+    (8, 300, 320, 50, 0.0),         # nearly as many clusters as samples: empty clusters go to the origin
+])
+def test_kmeans_iterate_equals_the_step_loop(ctx, oracle, d, K, n, max_steps, atol):
+    """mlhip_kmeans_iterate -- the step loop of KMeans::fit_once with the centroid table kept on the device between the
+    stopping tests -- gives the same step count, decisions, centroids, counts, inertia and labels, bit for bit, as the loop
+    of mlhip_kmeans_step calls (closing arithmetic on the host), which the parity tests pin to the oracle."""
+    from ml_amd import _lib
+    rng = np.random.default_rng(11 * d + K + n)
+    means = 3.0 * rng.standard_normal((K, d))
+    X = np.ascontiguousarray(means[rng.integers(0, K, n)] + rng.standard_normal((n, d)))
+    C0 = X[rng.choice(n, K, replace=False)].copy()
+    if K >= 300:
+        C0[5] = 100.0                                    # a centroid no sample is nearest to
+    dt = _lib.Data(ctx, X)
+    a = dt.kmeans_iterate(C0, max_steps, atol)
+    la = dt.kmeans_labels()
+    da = dt.kmeans_distances()
+    dt.close()
+    dt = _lib.Data(ctx, X)
+    b = _kmeans_step_loop(dt, C0, max_steps, atol)
+    lb = dt.kmeans_labels()
+    db = dt.kmeans_distances()
+    dt.close()
+    assert a[0] == b[0] and a[1] == b[1]
+    assert a[2] == b[2]
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+    assert np.array_equal(la, lb) and np.array_equal(da, db)
+    if K >= 300:
+        assert np.all(a[4][a[3] == 0] == 0.0)            # ML/KMeans.cpp:184
+    if max_steps >= 2:
+        # and the oracle's own fit from the same start: same number of steps, same decision, same labels
+        km = oracle.KMeans(K)
+        km.set_absolute_tolerance(atol)
+        km.set_maximum_steps(max_steps)
+        km.set_centroids_initialiser(oracle.FIXED, C0)
+        assert km.fit(X) == a[1]
+        assert km.steps_done == a[0]
+        assert np.array_equal(km.labels, la)
+        assert relerr(a[4], km.centroids) < 1e-12
