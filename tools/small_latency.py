@@ -19,6 +19,9 @@ for n, d, K in ((10_000, 4, 3), (100_000, 8, 8), (1_000_000, 16, 16)):
     for _ in range(200):
         ll, pi, mu, S = dt.em_step(pi, mu, S)
     out[f"N={n},d={d},K={K}"] = {"us_per_iteration": (time.perf_counter() - t0) / 200 * 1e6}
+    t0 = time.perf_counter()
+    dt.em_iterate(pi, mu, S, 200)
+    out[f"N={n},d={d},K={K}"]["us_per_iteration_em_iterate"] = (time.perf_counter() - t0) / 200 * 1e6
     Cc = mu.copy()
     for _ in range(5):
         _, _, _, Cc = dt.kmeans_step(Cc)
@@ -26,5 +29,10 @@ for n, d, K in ((10_000, 4, 3), (100_000, 8, 8), (1_000_000, 16, 16)):
     for _ in range(200):
         _, _, _, Cc = dt.kmeans_step(Cc)
     out[f"N={n},d={d},K={K}"]["us_per_kmeans_step"] = (time.perf_counter() - t0) / 200 * 1e6
+    t0 = time.perf_counter()
+    done = 0
+    while done < 200:
+        done += dt.kmeans_iterate(Cc, 200 - done)[0]
+    out[f"N={n},d={d},K={K}"]["us_per_kmeans_step_iterate"] = (time.perf_counter() - t0) / 200 * 1e6
     dt.close()
 print(json.dumps(out))
