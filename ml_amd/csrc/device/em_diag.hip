@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256, (D <= 16 && RBT <= 2) ? 2 : 1) void em_diag_ke
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 if ((rb0 + rb) * 16 < Kt) {                          // wave-uniform: skip all-zero row blocks
+                    __builtin_amdgcn_s_setprio(kMatrixPhasePriority);  // see em_estep_mfma4.hip
 #pragma unroll 4
                     for (int sg = 0; sg < TS / 4; ++sg) {
                         const double av = rbase[sg * RSS];           // r of (sample 16 g + sg, component lane & 15)
@@ -208,6 +209,7 @@ __global__ __launch_bounds__(256, (D <= 16 && RBT <= 2) ? 2 : 1) void em_diag_ke
                             acc[rb][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[rb][c], 0, 0, 0);
                         }
                     }
+                    __builtin_amdgcn_s_setprio(0);
                 }
             }
         }

@@ -146,6 +146,13 @@ __global__ __launch_bounds__(64 * NW, D <= 32 ? 8 / SB : 2) void em_estep_mfma4_
             for (int t = 0; t < W && t < NB; ++t) aw[t] = rec[t * 16 + aoff];
             // Nested static loops (column quad C, then row quad R >= C): every index below is a compile-time constant
             // after unrolling, so the accumulators and the window stay in registers.
+            // The wave in its matrix phase gets the issue priority over the SIMD's other wave, which is in its VALU phase
+            // (squares, reduce-scatter, epilogue) or waiting at the barrier: the MFMA stream is not broken up by the
+            // neighbour's VALU instructions, which fit into its shadow instead. Measured: d = 32, K = 64 12.35 -> 12.0 ms;
+            // -1.5 % at d = 24 / 28, neutral at d = 20 and from d = 48 on, but +3 .. 4 % at d = 12 / 16, where the matrix phase of a
+            // component is 6 - 10 blocks short and the neighbour's epilogue is most of the work: not used there.
+            constexpr bool kPrioritise = D >= 20;
+            if constexpr (kPrioritise) __builtin_amdgcn_s_setprio(kMatrixPhasePriority);
 #pragma unroll
             for (int C = 0; C < Q; ++C) {
                 // the record's two vectors: the mean (exact form) / -W (mu - shift) (FOLD: the accumulator initialiser)
@@ -168,6 +175,7 @@ __global__ __launch_bounds__(64 * NW, D <= 32 ? 8 / SB : 2) void em_estep_mfma4_
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            if constexpr (kPrioritise) __builtin_amdgcn_s_setprio(0);
             double qs[SB];
 #pragma unroll
             for (int sb = 0; sb < SB; ++sb) {

@@ -19,6 +19,8 @@ inline uint32_t padded_samples(uint64_t n)
 /// above it only the 4x4-block matrix-core E-step, the wide statistics kernel and the matrix-core K-means kernel, with
 /// fewer samples per wave in each tier (kRegDim < d <= kMidDim, kMidDim < d <= kMaxDim): a wave keeps its samples'
 /// coordinates in registers.
+/// s_setprio level of a wave while it streams matrix instructions (0 elsewhere): see em_estep_mfma4.hip.
+constexpr int kMatrixPhasePriority = 2;
 constexpr int kMaxDim = 128;
 constexpr int kMidDim = 64;
 constexpr int kRegDim = 32;
