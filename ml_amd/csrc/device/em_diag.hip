@@ -14,6 +14,9 @@
 // whose B operand is generated in registers as a product of two LDS reads (x~_j * 1 or x~_j * x~_j); S0 is a per-lane
 // running sum folded once at the end. No atomics; per-workgroup partials are combined in fixed order by em_reduce_kernel.
 // Bound: ~3d VALU + one exp per (sample, component) against 8d bytes per sample -- VALU/latency-bound at d = K = 16, not HBM.
+#include <cstdlib>
+#include <type_traits>
+
 #include "em_mstats_common.hpp"
 #include "exp_nonpos.hpp"
 
@@ -34,7 +37,7 @@ template <int D, int RBT, int RBW, int CB, int S>
 __global__ __launch_bounds__(256, (D <= 16 && RBT <= 2) ? 2 : 1) void em_diag_kernel(
     const double* __restrict__ xt, size_t ldx, uint32_t n, int d, const double* __restrict__ shift,
     const double* __restrict__ params, int K, double* __restrict__ lse_out, double* __restrict__ partials, int KP, int FP,
-    double* __restrict__ ll_partials)
+    double* __restrict__ ll_partials, double ab_limit)
 {
     constexpr int PS = 2 * D + 2;                             // diag_param_stride(D)
     constexpr int KMAX = 16 * RBT;
@@ -52,6 +55,41 @@ __global__ __launch_bounds__(256, (D <= 16 && RBT <= 2) ? 2 : 1) void em_diag_ke
     const int rb0 = blockIdx.y * RBW;                         // first row block accumulated here
     for (int e = tid; e < KMAX * PS; e += 256) recs[e] = params[e];
     __syncthreads();
+    // Two-operation form of the density loop: with a = 1/sigma and b = -(mu - shift)/sigma the term ((x - mu) / sigma)^2 is
+    // fma(a, x~, b)^2 on the shift-centred coordinate x~ -- 2 fp64 operations per (sample, component, dimension) instead of
+    // 3, a third of the loop that is most of this kernel. It costs about eps (|a x~| + |b|) of every term, so it is only
+    // taken while every |b| is below ab_limit (layout.hpp kDiagAbLimit: 1e-14 of a term, inside the parity tolerances);
+    // otherwise -- a tight component far from the global mean -- the exact form (x - mu first) runs. Every workgroup (and
+    // every rank) derives the same decision from the same records; the records in LDS are rewritten in place: mu -> b,
+    // 1/sigma^2 -> a.
+    bool ab;
+    {
+        double bm = 0.0;
+        for (int e = tid; e < KMAX * D; e += 256) {
+            const int k = e / D, j = e - k * D;
+            if (k < K && j < d) {
+                const double a = sqrt(recs[k * PS + D + j]);
+                bm = fmax(bm, fabs((recs[k * PS + j] - shift[j]) * a));       // (a NaN stays out of fmax; caught below)
+                if (!(a == a) || !(recs[k * PS + j] == recs[k * PS + j])) bm = __builtin_inf();
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) bm = fmax(bm, __shfl_xor(bm, off, 64));
+        if (lane == 0) red[wave] = bm;
+        __syncthreads();
+        bm = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        ab = bm <= ab_limit;
+        if (ab) {
+            for (int e = tid; e < KMAX * D; e += 256) {
+                const int k = e / D, j = e - k * D;
+                const double a = sqrt(recs[k * PS + D + j]);
+                const double b = -((recs[k * PS + j] - shift[j]) * a);
+                recs[k * PS + j] = b;
+                recs[k * PS + D + j] = a;
+            }
+        }
+        __syncthreads();
+    }
 
     // feature f of the GEMM: f < d -> x~_f * 1 ; d <= f < 2d -> x~_(f-d)^2 ; beyond -> 0 * 0
     int offa[CB], offb[CB];
@@ -92,12 +130,22 @@ __global__ __launch_bounds__(256, (D <= 16 && RBT <= 2) ? 2 : 1) void em_diag_ke
         for (int s = 0; s < S; ++s)
 #pragma unroll
             for (int j = 0; j < D; ++j) x[s][j] = xt[(size_t)j * ldx + i0 + TS * s];
+        if (ab) {                                             // the two-operation form works on x~ = x - shift throughout
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double sh = shift[j];
+#pragma unroll
+                for (int s = 0; s < S; ++s) x[s][j] -= sh;
+            }
+        }
 
         // ---- 1. log-densities of all K components (statically unrolled; wave-uniform guards per group of 4)
         double lwv[S][KMAX];
         double m[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) m[s] = -__builtin_inf();
+        auto densities = [&](auto two_op_form) {
+        constexpr bool AB = decltype(two_op_form)::value;
 #pragma unroll
         for (int k4 = 0; k4 < KMAX; k4 += 4) {
             if (k4 < Kt) {
@@ -125,8 +173,13 @@ __global__ __launch_bounds__(256, (D <= 16 && RBT <= 2) ? 2 : 1) void em_diag_ke
                         for (int u = 0; u < 4; ++u)
 #pragma unroll
                             for (int s = 0; s < S; ++s) {
-                                const double z = x[s][j0 + jj] - mu[u][jj];
-                                q[s][u] = __builtin_fma(z * iv[u][jj], z, q[s][u]);
+                                if constexpr (AB) {
+                                    const double t = __builtin_fma(iv[u][jj], x[s][j0 + jj], mu[u][jj]);   // (a, b) in the (iv, mu) slots
+                                    q[s][u] = __builtin_fma(t, t, q[s][u]);
+                                } else {
+                                    const double z = x[s][j0 + jj] - mu[u][jj];
+                                    q[s][u] = __builtin_fma(z * iv[u][jj], z, q[s][u]);
+                                }
                             }
                 }
 #pragma unroll
@@ -146,6 +199,8 @@ __global__ __launch_bounds__(256, (D <= 16 && RBT <= 2) ? 2 : 1) void em_diag_ke
                     for (int u = 0; u < 4; ++u) lwv[s][k4 + u] = -__builtin_inf();
             }
         }
+        };
+        if (ab) densities(std::true_type{}); else densities(std::false_type{});
         // ---- 2. normalisation: one exp per (sample, component)
         double inv[S];
 #pragma unroll
@@ -179,7 +234,7 @@ __global__ __launch_bounds__(256, (D <= 16 && RBT <= 2) ? 2 : 1) void em_diag_ke
         for (int s = 0; s < S; ++s) {
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int j = 0; j < D; ++j) Xw[lane * XSS + j] = x[s][j] - shift[j];   // shift is zero-padded to D entries
+            for (int j = 0; j < D; ++j) Xw[lane * XSS + j] = ab ? x[s][j] : x[s][j] - shift[j];   // shift is zero-padded to D entries
             Xw[lane * XSS + ONE] = 1.0;
             Xw[lane * XSS + ZERO] = 0.0;
 #pragma unroll
@@ -259,6 +314,13 @@ __global__ __launch_bounds__(256, (D <= 16 && RBT <= 2) ? 2 : 1) void em_diag_ke
 
 constexpr int rbw_of(int RBT) { return RBT >= 2 ? 2 : 1; }
 
+/// MLHIP_DIAG_AB=0: the exact form of the density loop always (A/B runs).
+inline double diag_ab_limit()
+{
+    const char* e = std::getenv("MLHIP_DIAG_AB");          // (read per launch: tests switch it inside one process)
+    return e && e[0] == '0' ? -1.0 : kDiagAbLimit;
+}
+
 /// Samples per lane: 2 while coordinates + densities of both fit the registers of 2 waves per SIMD, else 1.
 constexpr int samples_per_lane(int D, int RBT) { return (D <= 16 && RBT == 1) || (D <= 8 && RBT == 2) ? 2 : 1; }
 
@@ -269,7 +331,7 @@ int launch_t(const DiagArgs& a, int grid, hipStream_t stream)
     const size_t smem = sizeof(double) * (4 * ((size_t)TS * XSS + (size_t)TS * RSS) + (size_t)16 * RBT * PS);
     hipLaunchKernelGGL((em_diag_kernel<D, RBT, RBW, CB, S>), dim3(grid, RBT / RBW), dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d,
                        a.shift, a.params, a.K, a.lse, a.partials, em_diag_partial_rows(a.K), em_diag_partial_cols(a.d),
-                       a.ll_partials);
+                       a.ll_partials, diag_ab_limit());
     return grid;
 }
 

@@ -19,6 +19,9 @@ inline uint32_t padded_samples(uint64_t n)
 /// above it only the 4x4-block matrix-core E-step, the wide statistics kernel and the matrix-core K-means kernel, with
 /// fewer samples per wave in each tier (kRegDim < d <= kMidDim, kMidDim < d <= kMaxDim): a wave keeps its samples'
 /// coordinates in registers.
+/// Diagonal kernel: largest |(mu - shift) / sigma| for which the two-operation density form fma(a, x~, b)^2 is used
+/// (em_diag.hip); beyond it the exact (x - mu)^2 / sigma^2.
+constexpr double kDiagAbLimit = 64.0;
 /// s_setprio level of a wave while it streams matrix instructions (0 elsewhere): see em_estep_mfma4.hip.
 constexpr int kMatrixPhasePriority = 2;
 constexpr int kMaxDim = 128;

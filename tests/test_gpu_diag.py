@@ -196,3 +196,46 @@ def test_config_b_full_size_properties(ctx):
     labels = dt.em_labels(K)
     assert labels.shape == (n,) and labels.max() < K
     dt.close()
+
+
+@pytest.mark.parametrize("d,K,n", [(16, 16, 6000), (5, 17, 3000), (8, 40, 5000), (32, 64, 4000)])
+def test_two_operation_density_form_and_its_guard(ctx, oracle, d, K, n, monkeypatch):
+    """The diagonal kernel evaluates ((x - mu) / sigma)^2 as fma(a, x~, b)^2 on shift-centred coordinates while every
+    |b| = |mu - shift| / sigma is below kDiagAbLimit, and in the exact form (x - mu first) otherwise. Ordinary data: both forms
+    agree to rounding (and with the oracle within the usual tolerances). A tight component far from the global mean: the
+    guard selects the exact form by itself -- bit-identical to a run with the two-operation form switched off."""
+    rng = np.random.default_rng(100 * d + K)
+    means = 3.0 * rng.standard_normal((K, d))
+    sig = rng.uniform(0.6, 1.5, (K, d))
+    comp = rng.integers(0, K, n)
+    X = np.ascontiguousarray(means[comp] + sig[comp] * rng.standard_normal((n, d)))
+    pi0 = np.full(K, 1.0 / K)
+    mu0 = means + 0.1 * rng.standard_normal((K, d))
+    var0 = sig ** 2
+
+    def step(Xd, mu, var, off):
+        if off:
+            monkeypatch.setenv("MLHIP_DIAG_AB", "0")
+        else:
+            monkeypatch.delenv("MLHIP_DIAG_AB", raising=False)
+        dt = _data(ctx, Xd)
+        out = dt.em_step_diag(pi0, mu, var)
+        dt.close()
+        monkeypatch.delenv("MLHIP_DIAG_AB", raising=False)
+        return out
+
+    a, b = step(X, mu0, var0, False), step(X, mu0, var0, True)
+    assert abs(a[0] - b[0]) <= 1e-13 * abs(b[0])
+    assert relerr(a[1], b[1]) < 1e-12 and relerr(a[2], b[2]) < 1e-12 and relerr(a[3], b[3]) < 1e-11
+    ll0, _, _, pi_o, mu_o, var_o = _oracle_step(oracle, X, pi0, mu0, var0)
+    assert abs(a[0] - ll0) <= 1e-12 * abs(ll0)
+    assert relerr(a[1], pi_o) < 1e-11 and relerr(a[2], mu_o) < 1e-11 and relerr(a[3], var_o) < 1e-10
+
+    # component 0 becomes tight and far: |mu - shift| / sigma ~ 1e5 >> the limit
+    X2 = X.copy()
+    far = 50.0 + np.arange(d)
+    X2[comp == 0] = far + 1e-3 * rng.standard_normal((int(np.sum(comp == 0)), d))
+    mu2, var2 = mu0.copy(), var0.copy()
+    mu2[0], var2[0] = far, 1e-6
+    c, e = step(X2, mu2, var2, False), step(X2, mu2, var2, True)
+    assert c[0] == e[0] and np.array_equal(c[1], e[1]) and np.array_equal(c[2], e[2]) and np.array_equal(c[3], e[3])
