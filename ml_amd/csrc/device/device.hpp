@@ -39,6 +39,12 @@ int launch_em_estep_mfma(const EstepArgs& a, int num_cus, hipStream_t stream);
 #endif
 /// 4x4-block triangular variant (em_estep_mfma4.hip); params use the estep_mfma4_param_stride(D) record layout.
 int launch_em_estep_mfma4(const EstepArgs& a, int num_cus, hipStream_t stream);
+#ifdef MLHIP_EXPERIMENTS
+/// Component-stationary variant of it (experiments/em_estep_cs.hip): FOLD form, lw only (a.fold && !a.with_lse), same records;
+/// returns <0 when it does not serve the shape (em_estep_cs_supported).
+bool em_estep_cs_supported(int D, int K);
+int launch_em_estep_cs(const EstepArgs& a, int num_cus, hipStream_t stream);
+#endif
 
 enum MstatsMode : int {
     kFromLogResp = 0,   // r = exp(lw - lse)          (after an E-step)

@@ -519,7 +519,16 @@ void launch_estep(mlhip_data* dt, int K, bool with_lse = true)
     a.with_lse = (with_lse || dt->estep_variant != 2) ? 1 : 0;
     int grid = 0;
     ctx->timed("em_estep", [&] {
-        if (dt->estep_variant == 2) grid = launch_em_estep_mfma4(a, ctx->num_cus, ctx->stream);
+        if (dt->estep_variant == 2) {
+            grid = -1;
+#ifdef MLHIP_EXPERIMENTS
+            // component-stationary form (experiments/em_estep_cs.hip: W blocks in registers, samples from LDS): measured slower
+            // than the kernel below; MLHIP_ESTEP_CS=1 selects it for A/B runs
+            static const bool cs = [] { const char* e = std::getenv("MLHIP_ESTEP_CS"); return e && e[0] == '1'; }();
+            if (cs && a.fold && !a.with_lse && em_estep_cs_supported(a.D, K)) grid = launch_em_estep_cs(a, ctx->num_cus, ctx->stream);
+#endif
+            if (grid < 0) grid = launch_em_estep_mfma4(a, ctx->num_cus, ctx->stream);
+        }
 #ifdef MLHIP_EXPERIMENTS
         else if (dt->estep_variant == 1) grid = launch_em_estep_mfma(a, ctx->num_cus, ctx->stream);
 #endif
