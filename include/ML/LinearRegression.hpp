@@ -36,8 +36,8 @@ public:
     const std::vector<Index>& transpositions() const { return transpositions_; }
     /** D as a vector. */
     DLL_DECLSPEC VectorXd vectorD() const;
-    bool isPositive() const { return sign_ >= 0; }   // no negative pivot seen (semi-definite counts)
-    bool isNegative() const { return sign_ <= 0; }
+    bool isPositive() const { return sign_ == 0 || sign_ == 1; }    // no negative pivot seen (semi-definite counts), as Eigen::LDLT
+    bool isNegative() const { return sign_ == 0 || sign_ == -1; }   // an indefinite matrix (sign_ == 2) is neither
     /** A reconstructed from the factors (P^T L D L^T P), e.g. for tests. */
     DLL_DECLSPEC MatrixXd reconstructedMatrix() const;
 private:

@@ -68,8 +68,14 @@ int mlhip_ctx_set_allreduce(mlhip_ctx* ctx, mlhip_allreduce_fn fn, void* user, i
  *   all:      mlhip_ctx_init_rccl(ctx, id, world_size, rank);        (collective: returns when all ranks have joined)
  * mlhip_ctx_init_rccl_file does the hand-over through a file that all ranks can see (rank 0 writes it atomically,
  * the others wait for it up to MLHIP_RCCL_TIMEOUT_S seconds, default 120); use a fresh path per job.
- * librccl.so.1 is loaded on first use (override: MLHIP_RCCL_LIBRARY). RCCL refuses two ranks on the same GPU. */
+ * librccl.so.1 is loaded on first use (override: MLHIP_RCCL_LIBRARY). RCCL refuses two ranks on the same GPU.
+ * Rank 0 removes the rendezvous file once the communicator exists; files older than MLHIP_RCCL_STALE_S seconds (default 600:
+ * the left-over of a job that died before that) are ignored by the waiting ranks.
+ * mlhip_rccl_available() says whether librccl can be loaded in THIS process without touching a GPU: ranks of a job can agree on
+ * it (over whatever channel they have) BEFORE anyone enters the collective mlhip_ctx_init_rccl*, where a rank that cannot load
+ * the library would leave the others waiting. */
 #define MLHIP_RCCL_UNIQUE_ID_BYTES 128
+int mlhip_rccl_available(void);   /* 1 / 0; never fails */
 int mlhip_rccl_unique_id(void* unique_id /* MLHIP_RCCL_UNIQUE_ID_BYTES bytes */);
 int mlhip_ctx_init_rccl(mlhip_ctx* ctx, const void* unique_id, int world_size, int rank);
 int mlhip_ctx_init_rccl_file(mlhip_ctx* ctx, const char* path, int world_size, int rank);
@@ -214,6 +220,13 @@ int mlhip_min_squared_distances(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, co
 int mlhip_timing_enable(mlhip_ctx* ctx, int on);
 int mlhip_timing_reset(mlhip_ctx* ctx);
 int mlhip_timing_get(mlhip_ctx* ctx, const char* name, double* avg_ms, uint64_t* launches);
+/* Which kernels an EM iteration of K full-covariance components on `data` is made of (diagnostic: bench.py attributes the
+ * algorithmic flops of ML/EM.cpp:190-263 to the kernels that execute them). Bits of *flags: */
+#define MLHIP_PLAN_FUSED 1u          /* E-step + statistics in one kernel (small shapes, em_fused_small.hip) */
+#define MLHIP_PLAN_MATRIX_ESTEP 2u   /* matrix-core E-step (em_estep_mfma4.hip), else the scalar-fed one */
+#define MLHIP_PLAN_SELF_NORM 4u      /* the E-step writes log-responsibilities only; the statistics kernel normalises them
+                                        (the one exponential per (sample, component) runs THERE) */
+int mlhip_em_plan(const mlhip_data* data, uint32_t K, uint32_t* flags);
 
 #ifdef __cplusplus
 }

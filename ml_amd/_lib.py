@@ -82,6 +82,11 @@ def u32ptr(a):
 RCCL_UNIQUE_ID_BYTES = 128
 
 
+def rccl_available():
+    """Whether librccl can be loaded in this process (no GPU touched): agree on it across ranks BEFORE Context.init_rccl."""
+    return bool(lib.mlhip_rccl_available())
+
+
 def rccl_unique_id():
     """128 opaque bytes from ncclGetUniqueId (rank 0 calls this and hands them to every rank: Context.init_rccl)."""
     buf = C.create_string_buffer(RCCL_UNIQUE_ID_BYTES)
@@ -292,6 +297,13 @@ class Data:
         check(lib.mlhip_em_iterate(self.ctx.handle, self._h, K, int(bool(diagonal)), dptr(pi), dptr(mu), dptr(S), C.c_uint32(max_steps),
                                    C.c_double(atol), C.c_double(rtol), C.byref(steps), C.byref(conv), C.byref(ll), dptr(hist)))
         return steps.value, bool(conv.value), ll.value, pi, mu, S, hist[:steps.value]
+
+    def em_plan(self, K):
+        """Which kernels a full-covariance EM iteration of K components is made of (mlhip_em_plan):
+        {'fused', 'matrix_estep', 'self_norm'} -> bool."""
+        f = C.c_uint32()
+        check(lib.mlhip_em_plan(self._h, C.c_uint32(K), C.byref(f)))
+        return {"fused": bool(f.value & 1), "matrix_estep": bool(f.value & 2), "self_norm": bool(f.value & 4)}
 
     def em_expectation(self, mixing, means, covs):
         K = len(mixing)

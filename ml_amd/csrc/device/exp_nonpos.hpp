@@ -2,7 +2,7 @@
 // table, no branches, few live registers -- the library exp costs ~28 and, inlined several times next to the statistics
 // kernel's 160 accumulator registers, pushed it into spills. Cody-Waite reduction x = n ln2 + r, |r| <= ln2 / 2, degree-13
 // Taylor polynomial (truncation 0.3466^14 / 14! = 4e-18 relative), scaling by ldexp (correct gradual underflow; exactly 0
-// below -745.2 like the library function). Measured against the correctly rounded result: <= 1 ulp
+// below -745.2 like the library function; NaN for NaN). Measured against the correctly rounded result: <= 1 ulp
 // (tests/test_exp_nonpos.py). Plain C++: the same text compiles for the host in that test.
 #pragma once
 #include <cmath>
@@ -17,7 +17,9 @@ namespace mlhip {
 
 MLHIP_EXP_FN double exp_nonpos(double x)
 {
-    x = x > -800.0 ? x : -800.0;                                   // (-inf and NaN-free: -inf - m arrives here for padding rows)
+    x = x < -800.0 ? -800.0 : x;                                   // -inf (lw of a padding row minus the max) -> 0 below; a NaN stays a NaN: a
+                                                                   // component with NaN parameters poisons the sample's sum and the log-likelihood, as in
+                                                                   // the reference (ML/EM.cpp:205-218) -- the fit then never reports convergence
     const double n = __builtin_rint(x * 1.4426950408889634074);    // round(x / ln 2)
     double r = __builtin_fma(n, -6.93147180369123816490e-01, x);   // ln2_hi: low 32 mantissa bits zero, n * ln2_hi is exact
     r = __builtin_fma(n, -1.90821492927058770002e-10, r);          // ln2_lo

@@ -8,6 +8,7 @@
 #include <rccl/rccl.h>   // types only: the library is dlopen'ed on first use (librccl is 570 MB; single-GPU users never pay for it)
 
 #include <dlfcn.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -16,6 +17,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
+#include <ctime>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -191,6 +194,41 @@ struct mlhip_ctx {
         pending.clear();
     }
 
+    /// The installed hook on a DEVICE buffer, on the context's stream. Timed as "allreduce" (event pair around the collective
+    /// on the stream: on a rank that arrives early this includes the wait for the slowest rank -- what a first multi-GPU run
+    /// needs to see).
+    void reduce_device(double* buf, size_t count)
+    {
+        int rc = 0;
+        timed("allreduce", [&] { rc = reduce_fn(reduce_user, buf, count, 1, stream); });
+        if (rc != 0) throw std::runtime_error("all-reduce hook failed");
+    }
+
+    /// End-of-fit guard of a row-sharded job: parameters are never broadcast -- every rank applies the same closing arithmetic
+    /// to the same all-reduced sums -- so ranks that received different sums (a collective that is not bitwise reproducible
+    /// across ranks, a rank on different data) would drift apart silently. Every rank puts a 48-bit checksum of its results
+    /// (three exactly representable 16-bit pieces) into its own slot of a zero vector, the vector is summed across ranks,
+    /// and every rank compares all slots. One small collective per fit. MLHIP_RANK_CHECK=0 disables.
+    void check_ranks_agree(const char* what, std::initializer_list<std::pair<const double*, size_t>> blocks)
+    {
+        if (!reduce_fn || world_size <= 1) return;
+        static const bool on = [] { const char* e = std::getenv("MLHIP_RANK_CHECK"); return !(e && e[0] == '0'); }();
+        if (!on) return;
+        uint64_t h = 1469598103934665603ull;                         // FNV-1a over the bytes of the blocks
+        for (const auto& b : blocks) {
+            const unsigned char* p = reinterpret_cast<const unsigned char*>(b.first);
+            for (size_t i = 0; i < b.second * sizeof(double); ++i) { h ^= p[i]; h *= 1099511628211ull; }
+        }
+        std::vector<double> v(3 * (size_t)world_size, 0.0);
+        for (int j = 0; j < 3; ++j) v[3 * (size_t)rank + j] = (double)((h >> (16 * j)) & 0xffffu);
+        allreduce_host(v.data(), v.size());
+        for (int r = 1; r < world_size; ++r)
+            for (int j = 0; j < 3; ++j)
+                if (v[3 * (size_t)r + j] != v[j])
+                    throw std::runtime_error(std::string("ranks disagree on ") + what + " at the end of the fit (rank " + std::to_string(r) +
+                                             " differs from rank 0): the statistics all-reduce did not give every rank the same sums");
+    }
+
     /// Sum `count` host doubles across ranks (no-op single rank).
     void allreduce_host(double* v, size_t count)
     {
@@ -198,8 +236,7 @@ struct mlhip_ctx {
         if (reduce_on_device) {
             small_dev.reserve(count * sizeof(double));
             HIP_CHECK(hipMemcpyAsync(small_dev.p, v, count * sizeof(double), hipMemcpyHostToDevice, stream));
-            if (reduce_fn(reduce_user, small_dev.as<double>(), count, 1, stream) != 0)
-                throw std::runtime_error("all-reduce hook failed");
+            reduce_device(small_dev.as<double>(), count);
             HIP_CHECK(hipMemcpyAsync(v, small_dev.p, count * sizeof(double), hipMemcpyDeviceToHost, stream));
             sync();
         } else {
@@ -571,8 +608,7 @@ void collect_stats(mlhip_data* dt, int K, size_t count = 0)
     mlhip_ctx* ctx = dt->ctx;
     if (!count) count = (size_t)K * stats_count(dt->d) + 1;
     if (ctx->reduce_fn && ctx->reduce_on_device) {
-        if (ctx->reduce_fn(ctx->reduce_user, dt->stats_dev.as<double>(), count, 1, ctx->stream) != 0)
-            throw std::runtime_error("all-reduce hook failed");
+        ctx->reduce_device(dt->stats_dev.as<double>(), count);
     }
     HIP_CHECK(hipMemcpyAsync(dt->stats_host.p, dt->stats_dev.p, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
     ctx->sync();
@@ -901,8 +937,7 @@ void km_launch(mlhip_data* dt, int K, const KmBlock& b, bool accumulate, double*
     dt->km_have_old = true;
     if (ctx->reduce_fn && ctx->reduce_on_device) {
         const size_t count = 2 + (accumulate ? (size_t)K * (dt->d + 1) : 0);
-        if (ctx->reduce_fn(ctx->reduce_user, dt->km_out.as<double>(), count, 1, ctx->stream) != 0)
-            throw std::runtime_error("all-reduce hook failed");
+        ctx->reduce_device(dt->km_out.as<double>(), count);
     }
 }
 
@@ -1037,8 +1072,7 @@ void allreduce_stats_dev(mlhip_data* dt, size_t count)
     mlhip_ctx* ctx = dt->ctx;
     if (!ctx->reduce_fn) return;
     if (ctx->reduce_on_device) {
-        if (ctx->reduce_fn(ctx->reduce_user, dt->stats_dev.as<double>(), count, 1, ctx->stream) != 0)
-            throw std::runtime_error("all-reduce hook failed");
+        ctx->reduce_device(dt->stats_dev.as<double>(), count);
         return;
     }
     HIP_CHECK(hipMemcpyAsync(dt->stats_host.p, dt->stats_dev.p, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
@@ -1413,6 +1447,11 @@ int mlhip_ctx_set_allreduce(mlhip_ctx* ctx, mlhip_allreduce_fn fn, void* user, i
     });
 }
 
+int mlhip_rccl_available(void)
+{
+    try { (void)Rccl::get(); return 1; } catch (...) { return 0; }
+}
+
 int mlhip_rccl_unique_id(void* unique_id)
 {
     return guarded([&] {
@@ -1450,9 +1489,13 @@ int mlhip_ctx_init_rccl_file(mlhip_ctx* ctx, const char* path, int world_size, i
                 throw std::runtime_error(std::string("cannot write the RCCL rendezvous file ") + path);
         } else {
             const int limit_s = std::max(1, env_int("MLHIP_RCCL_TIMEOUT_S", 120));
+            const int stale_s = std::max(1, env_int("MLHIP_RCCL_STALE_S", 600));
             const auto t0 = std::chrono::steady_clock::now();
             for (;;) {
-                if (FILE* f = std::fopen(path, "rb")) {
+                // the left-over file of an earlier job (one that died before rank 0 removed it) must not be taken for this job's
+                struct stat st;
+                const bool fresh = ::stat(path, &st) == 0 && std::time(nullptr) - st.st_mtime <= stale_s;
+                if (FILE* f = fresh ? std::fopen(path, "rb") : nullptr) {
                     const size_t got = std::fread(&id, 1, sizeof id, f);
                     std::fclose(f);
                     if (got == sizeof id) break;
@@ -1463,6 +1506,8 @@ int mlhip_ctx_init_rccl_file(mlhip_ctx* ctx, const char* path, int world_size, i
             }
         }
         init_rccl(ctx, id, world_size, rank);
+        // ncclCommInitRank returns when every rank has joined: the file has served; a rerun with the same path starts clean
+        if (rank == 0) std::remove(path);
     });
 }
 
@@ -1603,6 +1648,8 @@ int mlhip_em_iterate(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, int covarianc
             throw Unsupported("diagonal-covariance EM is built for d <= 32 and K <= 64");
         em_iterate(data, (int)K, diag, mixing, means, covariances, max_steps, absolute_tolerance, relative_tolerance, steps_done,
                    converged, log_likelihood, log_likelihood_history);
+        const size_t cov_doubles = (size_t)K * data->d * (diag ? 1 : data->d);
+        ctx->check_ranks_agree("the EM parameters", {{mixing, K}, {means, (size_t)K * data->d}, {covariances, cov_doubles}, {log_likelihood, 1}});
     });
 }
 
@@ -1788,6 +1835,7 @@ int mlhip_kmeans_iterate(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, double* c
         require(max_steps >= 1, "at least one step");
         require(absolute_tolerance >= 0, "negative tolerance");
         km_iterate(data, (int)K, centroids, old_centroids, max_steps, absolute_tolerance, steps_done, converged, inertia, counts);
+        ctx->check_ranks_agree("the K-means centroids", {{centroids, (size_t)K * data->d}, {inertia, 1}});
     });
 }
 
@@ -1845,6 +1893,21 @@ int mlhip_min_squared_distances(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, co
         data->km_have_old = have;
         ctx->sync();
         download_columns(ctx, reinterpret_cast<char*>(dist2), 0, data->km_probe.as<char>(), 0, sizeof(double) * data->n, 1);
+    });
+}
+
+int mlhip_em_plan(const mlhip_data* data, uint32_t K, uint32_t* flags)
+{
+    return guarded([&] {
+        require(data && flags && K >= 1, "null argument");
+        uint32_t f = 0;
+        const bool matrix = estep_mfma4_supported(data->D) && !(data->D <= kRegDim && std::getenv("MLHIP_ESTEP"));
+        if (fused_step_applies(data, (int)K)) f |= MLHIP_PLAN_FUSED;
+        else {
+            if (matrix) f |= MLHIP_PLAN_MATRIX_ESTEP;
+            if (matrix && self_norm_applies(data, (int)K)) f |= MLHIP_PLAN_SELF_NORM;
+        }
+        *flags = f;
     });
 }
 

@@ -68,6 +68,17 @@ def install_native_rccl(ctx, world_size, rank, group=None):
     torch.distributed (any backend) only carries its 128 bytes to the other ranks; the iterations never enter Python."""
     import torch.distributed as dist
     from . import _lib
+    # every rank must be able to load librccl, or the ranks that can would wait forever inside ncclCommInitRank for the one
+    # that raised before it: agree on it first and fail (so that the caller can fall back) on ALL ranks together
+    ok = _lib.rccl_available()
+    if world_size > 1:
+        flags = [None] * world_size
+        dist.all_gather_object(flags, bool(ok), group=group)
+        missing = [r for r, f in enumerate(flags) if not f]
+    else:
+        missing = [] if ok else [0]
+    if missing:
+        raise RuntimeError(f"RCCL is not available on rank(s) {missing}: librccl.so.1 could not be loaded (MLHIP_RCCL_LIBRARY)")
     box = [None]
     if rank == 0:
         try:

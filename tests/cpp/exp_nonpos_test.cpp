@@ -23,6 +23,7 @@ int main()
     for (int i = 0; i < 1000000; ++i) { test(u(g)); test(u2(g)); test(u3(g)); }
     for (double x : {0.0, -0.0, -745.0, -745.13, -745.2, -746.0, -708.5, -1e300, 1e-17, -1e-17}) test(x);
     if (mlhip::exp_nonpos(0.0) != 1.0 || mlhip::exp_nonpos(-INFINITY) != 0.0 || mlhip::exp_nonpos(-746.0) != 0.0) ++bad;
+    if (!std::isnan(mlhip::exp_nonpos(NAN)) || !std::isnan(mlhip::exp_nonpos(-NAN))) ++bad;   // a NaN must stay a NaN
     long nonmono = 0;
     double prev = 0;
     for (double x = -60; x < 0; x += 3e-5) { const double v = mlhip::exp_nonpos(x); if (v < prev) ++nonmono; prev = v; }

@@ -155,7 +155,12 @@ static void ldlt_checks()
     for (int i = 0; i < 3; ++i) { double t = 0; for (int j = 0; j < 3; ++j) t += S(i, j) * z[j]; CHECK(std::abs(t - rhs[i]) <= 1e-12); }
     MatrixXd N(A);
     for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) N(i, j) = -A(i, j);
-    CHECK(ml::LDLT(N).isNegative());
+    CHECK(ml::LDLT(N).isNegative() && !ml::LDLT(N).isPositive());
+    // indefinite: neither positive nor negative (Eigen::LDLT::isPositive is true only for a positive or zero sign)
+    MatrixXd I2(2, 2);
+    I2(0, 0) = 1; I2(1, 1) = -2; I2(0, 1) = I2(1, 0) = 0;
+    const ml::LDLT indef(I2);
+    CHECK(indef.isIndefinite() && !indef.isPositive() && !indef.isNegative());
     CHECK_THROWS(ml::LDLT(MatrixXd(2, 3)), std::invalid_argument);
     CHECK_THROWS(ldlt.solve(VectorXd(n + 1)), std::invalid_argument);
 }

@@ -406,3 +406,67 @@ def test_small_and_empty_shards_follow_the_global_sample_size():
 
     for errs in (a["too_few"], b["too_few"]):
         assert all(e and "Not enough data" in e for e in errs), errs
+
+
+# ---- a rank that receives different sums must not go unnoticed -------------------------------------------------------
+
+def _diverging_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        import torch.distributed as dist
+        from ml_amd import _lib, synth
+        from ml_amd import dist as mldist
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        d, K, n = 8, 5, 4001
+        mix = synth.Mixture(d, K, seed=4)
+        X, _ = mix.sample(n)
+        lo, hi = mldist.shard_bounds(n, world, rank)
+        ctx = _lib.Context(0)
+
+        def hook(ptr, count, on_device, stream):
+            mldist.allreduce_sum(ptr, count, on_device, stream)
+            if rank == 1 and count > 16:            # the statistics buffers, not the small exchanges (shift, checksums)
+                import ctypes
+                buf = (ctypes.c_double * count).from_address(ptr)
+                buf[0] *= 1.0 + 1e-12               # what a collective that is not bitwise reproducible across ranks would do
+
+        ctx.set_allreduce(hook, False, world, rank)
+        data = _lib.Data(ctx, np.ascontiguousarray(X[lo:hi]))
+        _, cov = data.sample_covariance()
+        pi, mu, S = np.full(K, 1.0 / K), mix.initial_means(), np.stack([cov] * K)
+        msgs = []
+        for call in (lambda: data.em_iterate(pi, mu, S, 3), lambda: data.kmeans_iterate(mu, 3)):
+            try:
+                call()
+                msgs.append(None)
+            except _lib.MlhipError as e:
+                msgs.append(str(e))
+        q.put((rank, msgs))
+        data.close()
+        ctx.close()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), str(e)))
+
+
+@pytest.mark.gpu
+def test_diverging_ranks_fail_the_fit_on_every_rank():
+    """Parameters are never broadcast (every rank closes the same all-reduced sums): the end-of-fit checksum exchange of
+    mlhip_em_iterate / mlhip_kmeans_iterate must catch a rank whose sums differ in the last bits."""
+    import torch.multiprocessing as mp
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = _free_port()
+    procs = [mpctx.Process(target=_diverging_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+            p.join()
+    for r in results:
+        assert r[1] != "error", r[2]
+        assert len(r[1]) == 2 and all(m and "ranks disagree" in m for m in r[1]), r
