@@ -16,8 +16,10 @@ sufficient statistics per iteration: ncclAllReduce on the library's own RCCL com
 `--allreduce torch` routes it through torch.distributed's nccl backend instead). torch.distributed carries the
 RCCL unique id, the barriers around the timed region and the max-over-ranks of the elapsed time.
 
-Prints ONE JSON line on rank 0. At N=1 the line also carries `secondary`: K-means (BASELINE.json configs[4]) at one
-GPU's share of that job, N=12.5M, d=8, K=256, with its own roofline and cpu_baseline.
+Prints ONE JSON line on rank 0. At N=1 the line also carries `secondary`, a list: K-means (BASELINE.json configs[4]) at one
+GPU's share of that job, N=12.5M, d=8, K=256, and the diagonal-covariance GMM of configs[1] (N=1M, d=16, K=16), each with its
+own roofline and cpu_baseline. Every line carries `allreduce_ms` (average device time of the statistics all-reduce, max over
+ranks; 0 on one GPU) and the spread of the ranks' own time per step (`ms_per_step_min` / `_max`).
 
     python bench.py --workload kmeans [--gpus N ...]       K-means steps/sec at N=100M, d=8, K=256 as the primary line;
         one step = mlhip_kmeans_step = assignment + exact update sums + all-reduce of counts/sums + new centroids
@@ -46,12 +48,20 @@ def algorithmic_flops(n, d, K):
     return float(n) * K * (2 * d * d + 6 * d + 25)
 
 
-def estep_flops(n, d, K):
-    return float(n) * K * (d * d + 3 * d + 25)
+def estep_flops(n, d, K, self_norm=False):
+    """E-step share of the algorithmic flops. The ~25 flops of the exponential / normalisation of a pair run where the
+    exponential runs: in the E-step kernel, or -- self-normalising statistics kernel (mlhip_em_plan) -- in the statistics kernel."""
+    return float(n) * K * (d * d + 3 * d + (0 if self_norm else 25))
 
 
-def mstats_flops(n, d, K):
-    return float(n) * K * (d * d + 3 * d)
+def mstats_flops(n, d, K, self_norm=False):
+    return float(n) * K * (d * d + 3 * d + (25 if self_norm else 0))
+
+
+def kmeans_uses_matrix_cores(d, K):
+    """device/kmeans.hip serves d = 1, 2, 3, 5, 6 with K < 128 on the vector unit (direct form, 3d flops per pair);
+    everything else runs kmeans_mfma.hip, which EXECUTES 2d flops per pair (scores x.c - |c|^2/2) plus the exact recheck."""
+    return not (d in (1, 2, 3, 5, 6) and K < 128)
 
 
 def diag_flops(n, d, K):
@@ -151,6 +161,7 @@ class Job:
         self.ctx = _lib.Context(local_rank)
         self.allreduce = "none"
         self.rccl_ranks = 1
+        self.last_ranks = {}
         if world > 1 or args.force_hook:
             if args.allreduce == "native":
                 try:
@@ -208,13 +219,22 @@ class Job:
         self.barrier()
         t0 = time.perf_counter()
         run(steps)
+        own = time.perf_counter() - t0               # this rank's own steps, before it waits for the others
         self.barrier()
         elapsed = self.max_over_ranks(time.perf_counter() - t0)
         if names and not live:
             self.ctx.timing_enable(True)
             run(steps)
+        names = list(names) + ["allreduce"]
         kernel_ms = {name: self.ctx.timing_get(name)[0] for name in names}
         self.ctx.timing_enable(False)
+        # diagnosability of a multi-GPU run: every rank's own time per step and its average all-reduce time (which, on a rank
+        # that arrives early, includes the wait for the slowest one)
+        per_rank = self.gather({"ms_per_step": own / steps * 1e3, "allreduce_ms": kernel_ms["allreduce"]})
+        self.last_ranks = {"ms_per_step_min": min(r["ms_per_step"] for r in per_rank),
+                           "ms_per_step_max": max(r["ms_per_step"] for r in per_rank),
+                           "allreduce_ms": max(r["allreduce_ms"] for r in per_rank),
+                           "allreduce_ms_per_rank": [r["allreduce_ms"] for r in per_rank]}
         return elapsed, kernel_ms
 
     def close(self):
@@ -266,7 +286,11 @@ def kmeans_measure(job, n, d, K, steps, warmup, with_cpu, cpu_samples):
     if job.rank == 0:
         n_local = hi - lo
         flops = float(n_local) * K * 3 * d                  # N*K*3d (direct-form distances)
-        achieved = flops / (k_ms * 1e-3) / 1e12
+        algorithmic = flops / (k_ms * 1e-3) / 1e12
+        matrix = kmeans_uses_matrix_cores(d, K)
+        # the matrix-core kernel executes 2d flops per pair: `frac` prices what the pipe executes, the 3d form is
+        # reported beside it
+        achieved = algorithmic * (2.0 / 3.0 if matrix else 1.0)
         out = {
             "metric": f"K-means steps/sec at N={n} d={d} K={K} (fp64)",
             "value": steps / elapsed, "unit": "steps/s", "n_gpus": job.world, "steps": steps, "warmup": warmup,
@@ -274,9 +298,11 @@ def kmeans_measure(job, n, d, K, steps, warmup, with_cpu, cpu_samples):
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"K-means (Lloyd) N={n} d={d} K={K}, row-sharded over {job.world} GPU(s)", "N": n, "d": d,
                        "K": K, "parallelism": f"dp{job.world}", "inertia": state["inertia"]},
-            "rccl_ranks": job.rccl_ranks, "allreduce": job.allreduce, "n_local": n_locals,
+            "rccl_ranks": job.rccl_ranks, "allreduce": job.allreduce, "n_local": n_locals, **job.last_ranks,
             "roofline": {"bound": "mfma", "kernel": "kmeans_assign", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "flops_counted": "executed: 2d per (sample, cluster) on the matrix cores" if matrix else "3d per (sample, cluster)",
+                         "algorithmic_3d_tflops": algorithmic, "algorithmic_3d_frac": algorithmic / FP64_PEAK_TFLOPS,
                          "kernel_ms": {"kmeans_assign": k_ms},
                          "hbm_algorithmic_gbs": n_local * (8.0 * d + 4) / (k_ms * 1e-3) / 1e9, "hbm_peak_gbs": HBM_PEAK_GBS},
         }
@@ -316,6 +342,7 @@ def em_measure(job, n, d, K, steps, warmup, with_cpu, cpu_samples, diagonal=Fals
 
     # Start exactly like EM::fit without maximise_first (ML/EM.cpp:127-135): given means, shared sample covariance.
     _, cov = data.sample_covariance()
+    plan = {"fused": False, "matrix_estep": False, "self_norm": False} if diagonal else data.em_plan(K)
     S0 = np.stack([np.diag(cov)] * K) if diagonal else np.stack([cov] * K)
     state = {"ll": None, "pi": np.full(K, 1.0 / K), "mu": mix.initial_means(), "S": S0}
 
@@ -365,13 +392,17 @@ def em_measure(job, n, d, K, steps, warmup, with_cpu, cpu_samples, diagonal=Fals
                 "iteration_algorithmic_tflops": it_tflops}
     else:
         e_ms, m_ms = ms["em_estep"], ms["em_mstats"]
-        dom_name, dom_ms, dom_flops = ("em_estep", e_ms, estep_flops(n_local, d, K)) if e_ms >= m_ms else \
-                                      ("em_mstats", m_ms, mstats_flops(n_local, d, K))
+        sn = plan["self_norm"]
+        dom_name, dom_ms, dom_flops = ("em_estep", e_ms, estep_flops(n_local, d, K, sn)) if e_ms >= m_ms else \
+                                      ("em_mstats", m_ms, mstats_flops(n_local, d, K, sn))
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
         traffic, source = traffic_for(dom_name, headline and job.world == 1)
         roof = {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": source,
                 "kernel_ms": {"em_estep": e_ms, "em_mstats": m_ms, "em_close": ms.get("em_close", 0.0)},
+                "kernel_tflops": {"em_estep": estep_flops(n_local, d, K, sn) / (e_ms * 1e-3) / 1e12 if e_ms else None,
+                                  "em_mstats": mstats_flops(n_local, d, K, sn) / (m_ms * 1e-3) / 1e12 if m_ms else None},
+                "exp_runs_in": "em_mstats (self-normalising statistics kernel)" if sn else "em_estep",
                 "iteration_algorithmic_tflops": it_tflops}
     kind = "diagonal covariance (extension; the reference is full-covariance only)" if diagonal else "full covariance"
     out = {
@@ -382,7 +413,7 @@ def em_measure(job, n, d, K, steps, warmup, with_cpu, cpu_samples, diagonal=Fals
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"GMM-EM N={n} d={d} K={K} {kind}, row-sharded over {job.world} GPU(s)",
                    "N": n, "d": d, "K": K, "parallelism": f"dp{job.world}", "final_mean_log_likelihood": state["ll"]},
-        "rccl_ranks": job.rccl_ranks, "allreduce": job.allreduce, "n_local": n_locals,
+        "rccl_ranks": job.rccl_ranks, "allreduce": job.allreduce, "n_local": n_locals, **job.last_ranks,
         "roofline": roof,
     }
     data.close()
@@ -536,12 +567,16 @@ def main():
                          with_cpu, args.cpu_samples)
         default_shape = (args.n, args.dim, args.components) == (None, None, None)
         if world == 1 and default_shape and not args.no_secondary:
-            # BASELINE.json configs[4] (K-means N=100M, d=8, K=256 on 8 GPUs) at ONE GPU's share of it, in the same
-            # driver-timed run: the EM block has been freed above.
+            # In the same driver-timed run (the EM block has been freed above), as a LIST:
+            # [0] BASELINE.json configs[4] (K-means N=100M, d=8, K=256 on 8 GPUs) at ONE GPU's share of it;
+            # [1] BASELINE.json configs[1] (N=1M, d=16, K=16 diagonal-covariance GMM on one GPU) -- an iteration is ~0.1 ms, so
+            #     it gets ten times the steps.
             sec = kmeans_measure(job, 12_500_000, 8, 256, args.steps, args.warmup, with_cpu, args.cpu_samples)
-            if out is not None and sec is not None:
+            diag = em_measure(job, 1_000_000, 16, 16, 10 * args.steps, 10 * args.warmup, with_cpu, args.cpu_samples, diagonal=True)
+            if out is not None and sec is not None and diag is not None:
                 sec["config"]["workload"] += " = one GPU's row shard of BASELINE.json configs[4] (N=100M on 8 GPUs)"
-                out["secondary"] = sec
+                diag["config"]["workload"] += " = BASELINE.json configs[1]"
+                out["secondary"] = [sec, diag]
     if rank == 0:
         print(json.dumps(out))
     job.close()

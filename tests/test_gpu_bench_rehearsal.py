@@ -30,6 +30,12 @@ def test_two_rank_em_line_matches_the_single_rank_run():
     a, b = one["config"]["final_mean_log_likelihood"], two["config"]["final_mean_log_likelihood"]
     assert abs(a - b) <= 1e-12 * abs(a)
     assert "roofline" in two and two["roofline"]["kernel_ms"]["em_estep"] > 0
+    # the fields a first multi-GPU run is diagnosed with: every line has them, a single rank reports no all-reduce time
+    for line in (one, two):
+        assert line["ms_per_step_min"] <= line["ms_per_step_max"] <= line["ms_per_step"] * 1.5 + 1.0
+        assert len(line["allreduce_ms_per_rank"]) == line["n_gpus"]
+    assert one["allreduce_ms"] == 0
+    assert one["roofline"]["exp_runs_in"].startswith("em_mstats")        # d = 32, K = 64: self-normalising statistics kernel
 
 
 def test_three_rank_kmeans_and_diag_lines():
