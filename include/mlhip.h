@@ -212,6 +212,14 @@ int mlhip_kmeans_distances(mlhip_ctx* ctx, mlhip_data* data, double* dist2);
 /* min_k |x_i - c_k|^2 per sample of this rank's shard (the weights of KPP::init, ML/Clustering.cpp:44-51). */
 int mlhip_min_squared_distances(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* centroids, double* dist2);
 
+/* The running means of RandomPartition::init (ML/Clustering.cpp:27-37) over this rank's rows, bit-identical to the host loop
+ * `c_k += (x_i - c_k) / ++n_k`: the caller makes the per-row cluster draws (the reference's std::uniform_int_distribution calls)
+ * and passes their stable partition -- order[offsets[k] .. offsets[k+1]) = the local row indices drawn for cluster k, ascending;
+ * offsets[0] = 0, offsets[K] = n_local. means (K x d, centroid k = d contiguous doubles: the reference's column-major d x K) and
+ * sizes (K counts) are CONTINUED: zeros for a fresh start, the previous rank's result in a row-sharded job (ranks in row order). */
+int mlhip_random_partition_means(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const uint32_t* order, const uint32_t* offsets,
+                                 double* means, double* sizes);
+
 /* ---- timing (for bench.py / profiling) -------------------------------------------------------------- */
 /* Average device time in ms of the named kernel family over its launches since the last reset, measured with
  * HIP events on the context's stream. name: "em_estep", "em_mstats", "kmeans_assign", ... Returns count in *launches.

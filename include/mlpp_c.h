@@ -29,6 +29,10 @@ int mlpp_centroids_initialiser_destroy(mlpp_centroids_initialiser* h);
  * or default-constructed; out: K x d row-major. For tests of the host-side initialisers. */
 int mlpp_centroids_initialiser_run(const mlpp_centroids_initialiser* h, const double* data, uint64_t n, uint32_t d,
                                    uint32_t K, int seed_set, uint32_t seed, double* centroids_out);
+/* The same through the path `fit` takes: the data is uploaded to the facade's GPU and the initialiser's O(N) passes (K-means++
+ * distances, RandomPartition's running means: SURVEY 8 f1) run there; the result is bit-identical to the host run above. */
+int mlpp_centroids_initialiser_run_on_device(const mlpp_centroids_initialiser* h, const double* data, uint64_t n, uint32_t d,
+                                             uint32_t K, int seed_set, uint32_t seed, double* centroids_out);
 int mlpp_closest_centroid_create(const mlpp_centroids_initialiser* centroids_initialiser, mlpp_responsibilities_initialiser** out);
 int mlpp_responsibilities_initialiser_destroy(mlpp_responsibilities_initialiser* h);
 /* out: N x K column-major. */

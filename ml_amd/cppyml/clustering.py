@@ -53,6 +53,16 @@ class CentroidsInitialiser:
         return out
 
 
+    def _run_on_device(self, data, number_components, seed=None):
+        """Test hook: the same through the path `fit` takes (data uploaded, the O(N) passes on the GPU)."""
+        data = _require_data(data)
+        n, d = data.shape
+        out = np.empty((number_components, d))
+        _check(_l.mlpp_centroids_initialiser_run_on_device(self._h, _dp(data), C.c_uint64(n), d, number_components,
+                                                           int(seed is not None), C.c_uint32(seed or 0), _dp(out)))
+        return out
+
+
 class ResponsibilitiesInitialiser:
     """Abstract responsibilities initialiser."""
 

@@ -97,7 +97,51 @@ __global__ __launch_bounds__(256) void colsum_stage2(const double* __restrict__ 
     if (threadIdx.x == 0) sums[j] = red[0];
 }
 
+/// RandomPartition::init's running means (reference ML/Clustering.cpp:27-37): `c_k += (x_i - c_k) / ++n_k` over the rows of
+/// cluster k in ROW ORDER. The K d chains are independent of each other; each is strictly sequential, and IEEE subtraction,
+/// division and addition are correctly rounded on the device as on the host, so one thread per (cluster, dimension) that
+/// walks its cluster's rows in order reproduces the host's bits. `order` lists the row indices grouped by cluster (group k =
+/// [offsets[k], offsets[k+1]), ascending inside a group: the caller's stable partition of the per-row draws). The loads do
+/// not depend on the chain, so 8 of them are in flight per thread.
+__global__ __launch_bounds__(128) void random_partition_kernel(const double* __restrict__ xt, size_t ldx, int d,
+                                                                const uint32_t* __restrict__ order,
+                                                                const uint32_t* __restrict__ offsets, double* __restrict__ means,
+                                                                double* __restrict__ sizes)
+{
+    const int k = blockIdx.x, j = threadIdx.x;
+    const uint32_t lo = offsets[k], hi = offsets[k + 1];
+    double count = sizes[k];
+    if (j < d) {
+        const double* __restrict__ row = xt + (size_t)j * ldx;
+        double c = means[(size_t)k * d + j];
+        uint32_t t = lo;
+        for (; t + 8 <= hi; t += 8) {
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = row[order[t + u]];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                count += 1.0;
+                c += (x[u] - c) / count;
+            }
+        }
+        for (; t < hi; ++t) {
+            count += 1.0;
+            c += (row[order[t]] - c) / count;
+        }
+        means[(size_t)k * d + j] = c;
+    }
+    __syncthreads();                      // every thread of the block has read sizes[k]
+    if (j == 0) sizes[k] = count;
+}
+
 }  // namespace
+
+void launch_random_partition(const double* xt, size_t ldx, int d, int K, const uint32_t* order, const uint32_t* offsets,
+                             double* means, double* sizes, hipStream_t stream)
+{
+    hipLaunchKernelGGL(random_partition_kernel, dim3(K), dim3(64 * ((d + 63) / 64)), 0, stream, xt, ldx, d, order, offsets, means, sizes);
+}
 
 void launch_transpose_to_dim_major(const double* src, int64_t lds, int d, uint64_t n, double* dst, size_t ldd,
                                    uint64_t i0, hipStream_t stream)

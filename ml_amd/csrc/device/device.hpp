@@ -19,6 +19,11 @@ void launch_transpose_to_dim_major(const double* src, int64_t lds, int d, uint64
 void launch_column_maxabs(const double* xt, size_t ldx, int d, uint64_t n, double* scratch, double* maxabs, hipStream_t stream);
 void launch_column_sums(const double* xt, size_t ldx, int d, uint64_t n, double* scratch, double* sums, hipStream_t stream);
 
+/// RandomPartition::init's running means on the resident block (data_kernels.hip): means[k*d + j] and sizes[k] are continued
+/// over the rows order[offsets[k] .. offsets[k+1]) of cluster k, in that order. All pointers device memory.
+void launch_random_partition(const double* xt, size_t ldx, int d, int K, const uint32_t* order, const uint32_t* offsets,
+                             double* means, double* sizes, hipStream_t stream);
+
 // ---- EM ----------------------------------------------------------------------------------------------
 struct EstepArgs {
     const double* xt; size_t ldx; uint32_t n; int D;      // D = padded dimension

@@ -1,6 +1,7 @@
 #include "DeviceInit.hpp"
 
 #include <algorithm>
+#include <cstdint>
 #include <iterator>
 #include <limits>
 #include <random>
@@ -82,11 +83,25 @@ void forgy_sharded(const Shard& sh, ConstMatrixRef data, std::default_random_eng
     allreduce_matrix(ctx, centroids);
 }
 
+/// The stable partition of this rank's rows by their cluster draw: order[offsets[k] .. offsets[k+1]) = local rows drawn for
+/// cluster k, ascending (a counting sort of `mine`).
+void partition_rows(const std::vector<unsigned int>& mine, unsigned int K, std::vector<uint32_t>& order, std::vector<uint32_t>& offsets)
+{
+    offsets.assign(static_cast<std::size_t>(K) + 1, 0);
+    for (unsigned int k : mine) ++offsets[k + 1];
+    for (unsigned int k = 0; k < K; ++k) offsets[k + 1] += offsets[k];
+    std::vector<uint32_t> next(offsets.begin(), offsets.end() - 1);
+    order.resize(mine.size());
+    for (std::size_t i = 0; i < mine.size(); ++i) order[next[mine[i]]++] = static_cast<uint32_t>(i);
+}
+
 /// RandomPartition on the whole sample (ML/Clustering.cpp:27-37): the per-row cluster draws are a function of the engine
 /// alone, so every rank replays all of them and keeps its own rows'; the running means are order dependent, so the
-/// ranks update the shared state one after the other, in row order.
+/// ranks update the shared state one after the other, in row order. The O(N d) running means themselves -- K d independent
+/// sequential chains -- run on the device-resident rows when there are any (mlhip_random_partition_means: bit-identical
+/// to the host loop), on the host otherwise; a single rank is the world-of-one case of the same code.
 void random_partition_sharded(const Shard& sh, ConstMatrixRef data, std::default_random_engine& prng, unsigned int K,
-                              MatrixRef centroids, mlhip_ctx* ctx)
+                              MatrixRef centroids, mlhip_ctx* ctx, mlhip_data* device_data)
 {
     const Index d = data.rows(), n_local = data.cols();
     std::uniform_int_distribution<unsigned int> pick(0, K - 1);
@@ -95,19 +110,25 @@ void random_partition_sharded(const Shard& sh, ConstMatrixRef data, std::default
         const unsigned int k = pick(prng);
         if (i >= sh.lo && i < sh.hi) mine[static_cast<std::size_t>(i - sh.lo)] = k;
     }
+    std::vector<uint32_t> order, offsets;
+    if (device_data) partition_rows(mine, K, order, offsets);
     std::vector<double> state(static_cast<std::size_t>(d) * K + K, 0.0);   // [centroids d x K | sizes K]
     for (int r = 0; r < sh.world; ++r) {
         if (r == sh.rank) {
             double* sizes = state.data() + static_cast<std::size_t>(d) * K;
-            for (Index i = 0; i < n_local; ++i) {
-                const unsigned int k = mine[static_cast<std::size_t>(i)];
-                const double count = (sizes[k] += 1.0);
-                double* c = state.data() + static_cast<std::size_t>(d) * k;
-                const double* x = data.col(i);
-                for (Index j = 0; j < d; ++j) c[j] += (x[j] - c[j]) / count;
+            if (device_data) {
+                device::check(mlhip_random_partition_means(ctx, device_data, K, order.data(), offsets.data(), state.data(), sizes));
+            } else {
+                for (Index i = 0; i < n_local; ++i) {
+                    const unsigned int k = mine[static_cast<std::size_t>(i)];
+                    const double count = (sizes[k] += 1.0);
+                    double* c = state.data() + static_cast<std::size_t>(d) * k;
+                    const double* x = data.col(i);
+                    for (Index j = 0; j < d; ++j) c[j] += (x[j] - c[j]) / count;
+                }
             }
         }
-        broadcast_from(ctx, r, sh.rank, state.data(), state.size());
+        if (sh.world > 1) broadcast_from(ctx, r, sh.rank, state.data(), state.size());
     }
     for (unsigned int k = 0; k < K; ++k) std::copy_n(state.data() + static_cast<std::size_t>(d) * k, d, centroids.col(k));
 }
@@ -194,7 +215,7 @@ void init_centroids(const CentroidsInitialiser& initialiser, ConstMatrixRef data
         if (typeid(initialiser) == typeid(Forgy)) {
             forgy_sharded(sh, data, prng, number_components, centroids, ctx);
         } else if (typeid(initialiser) == typeid(RandomPartition)) {
-            random_partition_sharded(sh, data, prng, number_components, centroids, ctx);
+            random_partition_sharded(sh, data, prng, number_components, centroids, ctx, device_data);
         } else if (typeid(initialiser) == typeid(KPP) && device_data) {
             kpp_sharded(sh, data, prng, number_components, centroids, ctx, device_data);
         } else {
@@ -202,6 +223,12 @@ void init_centroids(const CentroidsInitialiser& initialiser, ConstMatrixRef data
             if (rank != 0) centroids.setZero();
             allreduce_matrix(ctx, centroids);
         }
+        return;
+    }
+    if (ctx && device_data && typeid(initialiser) == typeid(RandomPartition)) {
+        Shard sh;                                   // the whole sample on one rank
+        sh.hi = sh.n_global = data.cols();
+        random_partition_sharded(sh, data, prng, number_components, centroids, ctx, device_data);
         return;
     }
     if (!ctx || !device_data || typeid(initialiser) != typeid(KPP)) {

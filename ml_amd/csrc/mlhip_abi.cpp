@@ -1896,6 +1896,39 @@ int mlhip_min_squared_distances(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, co
     });
 }
 
+int mlhip_random_partition_means(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const uint32_t* order, const uint32_t* offsets,
+                                 double* means, double* sizes)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, K);
+        require(offsets && means && sizes && (order || data->n == 0), "null argument");
+        require(offsets[0] == 0 && offsets[K] == data->n, "offsets must cover this rank's rows");
+        for (uint32_t k = 0; k < K; ++k) require(offsets[k] <= offsets[k + 1], "offsets must ascend");
+        const int d = data->d;
+        DevBuf order_dev, small;   // released below (one initialisation per fit: no point in keeping them)
+        struct Release { DevBuf& a; DevBuf& b; ~Release() { a.release(); b.release(); } } release{order_dev, small};
+        const size_t off_bytes = ((sizeof(uint32_t) * (K + 1) + 15) / 16) * 16;
+        const size_t mean_doubles = (size_t)K * d;
+        order_dev.reserve(std::max<size_t>(16, sizeof(uint32_t) * data->n));
+        small.reserve(off_bytes + sizeof(double) * (mean_doubles + K));
+        uint32_t* off_dev = small.as<uint32_t>();
+        double* means_dev = reinterpret_cast<double*>(small.as<char>() + off_bytes);
+        double* sizes_dev = means_dev + mean_doubles;
+        if (data->n) HIP_CHECK(hipMemcpyAsync(order_dev.p, order, sizeof(uint32_t) * data->n, hipMemcpyHostToDevice, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(off_dev, offsets, sizeof(uint32_t) * (K + 1), hipMemcpyHostToDevice, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(means_dev, means, sizeof(double) * mean_doubles, hipMemcpyHostToDevice, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(sizes_dev, sizes, sizeof(double) * K, hipMemcpyHostToDevice, ctx->stream));
+        ctx->timed("random_partition", [&] {
+            launch_random_partition(data->xt.as<double>(), data->ldx, d, (int)K, order_dev.as<uint32_t>(), off_dev, means_dev, sizes_dev,
+                                    ctx->stream);
+        });
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(means, means_dev, sizeof(double) * mean_doubles, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(sizes, sizes_dev, sizeof(double) * K, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->sync();
+    });
+}
+
 int mlhip_em_plan(const mlhip_data* data, uint32_t K, uint32_t* flags)
 {
     return guarded([&] {

@@ -8,6 +8,7 @@
 #include <stdexcept>
 #include <string>
 
+#include "host/facade/DeviceInit.hpp"
 #include "ML/Clustering.hpp"
 #include "ML/Device.hpp"
 #include "ML/EM.hpp"
@@ -64,6 +65,19 @@ int mlpp_centroids_initialiser_run(const mlpp_centroids_initialiser* h, const do
         need(h); need(data); need(centroids_out);
         auto prng = make_engine(seed_set, seed);
         h->p->init(ConstMatrixRef(data, d, static_cast<Index>(n)), prng, K, MatrixRef(centroids_out, d, K, d));
+    });
+}
+int mlpp_centroids_initialiser_run_on_device(const mlpp_centroids_initialiser* h, const double* data, uint64_t n, uint32_t d, uint32_t K,
+                                             int seed_set, uint32_t seed, double* centroids_out)
+{
+    return guarded([&] {
+        need(h); need(data); need(centroids_out);
+        auto prng = make_engine(seed_set, seed);
+        mlhip_ctx* ctx = device::context();
+        mlhip_data* dev = nullptr;
+        device::check(mlhip_data_upload(ctx, data, d, n, d, &dev));
+        struct Free { mlhip_data* p; ~Free() { mlhip_data_free(p); } } free_it{dev};
+        Clustering::detail::init_centroids(*h->p, ConstMatrixRef(data, d, static_cast<Index>(n)), prng, K, MatrixRef(centroids_out, d, K, d), ctx, dev);
     });
 }
 int mlpp_closest_centroid_create(const mlpp_centroids_initialiser* ci, mlpp_responsibilities_initialiser** out)

@@ -58,7 +58,7 @@ def _step_loop(dt, pi, mu, S, max_steps, atol, rtol, diagonal):
     (5, 17, 9000, True),
     (32, 64, 12000, True),
 ])
-def test_iterate_equals_the_step_loop(ctx, d, K, n, diagonal):
+def test_iterate_equals_the_step_loop(ctx, oracle, d, K, n, diagonal):
     from ml_amd import _lib
     X, mu0, _, _ = _problem(d, K, n, 100 * d + K)
     dt = _lib.Data(ctx, X)
@@ -72,6 +72,26 @@ def test_iterate_equals_the_step_loop(ctx, d, K, n, diagonal):
     assert np.max(np.abs(hist - np.array(lls)) / np.abs(np.array(lls))) < 1e-13
     assert ll_b == hist[-1]
     assert relerr(pi_b, pi_a) < 1e-12 and relerr(mu_b, mu_a) < 1e-12 and relerr(S_b, S_a) < 1e-11
+    # ... and against the ORACLE's loop (ML/EM.cpp:143-170 spelt out with expectation_step / maximisation_step): the same
+    # trajectory, not only the same as the per-step HIP calls
+    ref = oracle.EM(K)
+    if diagonal:
+        ref.set_covariance_type("diag")
+    ref.set_parameters(mu0, np.stack([np.diag(v) for v in S0]) if diagonal else S0, pi0)
+    ref_lls, old = [], None
+    for step in range(12):
+        ref.expectation_step(X)
+        ref.maximisation_step(X)
+        ref_lls.append(ref.log_likelihood)
+        if step > 0 and abs(ref_lls[-1] - old) < 1e-9 + 1e-9 * max(abs(old), abs(ref_lls[-1])):
+            break
+        old = ref_lls[-1]
+    assert len(ref_lls) == steps_b
+    assert np.max(np.abs(hist - np.array(ref_lls)) / np.abs(np.array(ref_lls))) < 1e-12
+    S_ref = np.stack([np.diag(c) for c in ref.covariances]) if diagonal else ref.covariances
+    assert relerr(pi_b, ref.mixing_probabilities) < 1e-11 and relerr(mu_b, ref.means) < 1e-10 and relerr(S_b, S_ref) < 1e-9
+    ref.calculate_labels()
+    assert np.array_equal(dt.em_labels(K), np.asarray(ref.labels))
     # the E-step results left on the device are those of the LAST iteration, as after the step loop
     assert np.array_equal(dt.em_labels(K), labels_a)
     assert np.max(np.abs(dt.em_responsibilities(K) - R_a)) < 1e-12
