@@ -312,6 +312,173 @@ __global__ __launch_bounds__(256, (D <= 16 && RBT <= 2) ? 2 : 1) void em_diag_ke
     }
 }
 
+/// The same iteration for K <= 16 with the component records fed from SCALAR registers instead of LDS: the
+/// records are wave-uniform, so the compiler fetches them with s_load and every v_add / v_mul / v_fma of the density loop
+/// takes its record operand from an SGPR pair -- one scalar source per instruction, which is what the constant bus of gfx950
+/// allows; that is the reference's three-operation form  z = x - mu ; q += (z / sigma^2) z  (the two-operation form
+/// fma(a, x~, b)^2 would need two). No operand goes through the LDS pipe, so ONE sample per lane costs nothing extra: half
+/// the registers, FOUR waves per SIMD instead of two (the kernel is latency-bound: 3.8 tiles per wave, each starting with
+/// an HBM round trip), and the statistics tiles pass through LDS in two 32-sample halves (9.2 KB per wave: 16 waves per CU).
+template <int D, int CB>
+__global__ __launch_bounds__(256, D <= 8 ? 4 : 3) void em_diag_sgpr_kernel(
+    const double* __restrict__ xt, size_t ldx, uint32_t n, int d, const double* __restrict__ shift,
+    const double* __restrict__ params, int K, double* __restrict__ lse_out, double* __restrict__ partials, int KP, int FP,
+    double* __restrict__ ll_partials)
+{
+    constexpr int PS = 2 * D + 2;                             // diag_param_stride(D)
+    constexpr int KMAX = 16;
+    constexpr int XSS = xsd<D>();
+    constexpr int HT = TS / 2;                                // samples per statistics half tile
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double red[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double* Xw = smem + (size_t)wave * (HT * XSS + HT * RSS);
+    double* Rw = Xw + HT * XSS;
+    constexpr int ONE = D, ZERO = D + 1;                      // LDS row: [x~_0 .. x~_(D-1) | 1 | 0]
+
+    int offa[CB], offb[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+        const int f = c * 16 + (lane & 15);
+        offa[c] = f < d ? f : (f < 2 * d ? f - d : ZERO);
+        offb[c] = f < d ? ONE : (f < 2 * d ? f - d : ZERO);
+    }
+    d4 acc[CB];
+    double s0 = 0.0;                                          // lane (g, c): partial S0 of component c
+#pragma unroll
+    for (int c = 0; c < CB; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
+
+    const uint32_t n_tiles = (n + TS - 1) / TS;
+    const uint32_t stride = gridDim.x * 4;
+    const double* xbase = Xw + 8 * (lane >> 4) * XSS;         // half tile: lane group g reads samples 8 g + sg
+    const double* rbase = Rw + 8 * (lane >> 4) * RSS + (lane & 15);
+    double ll_acc = 0.0;
+
+    for (uint32_t tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += stride) {
+        const uint32_t i = tile * TS + lane;                  // < n_pad (a multiple of 256)
+        double x[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) x[j] = xt[(size_t)j * ldx + i];
+
+        // ---- 1. log-densities: records from scalar registers (params + k PS is wave-uniform)
+        double lwv[KMAX];
+        double m = -__builtin_inf();
+#pragma unroll
+        for (int k4 = 0; k4 < KMAX; k4 += 4) {
+            if (k4 < K) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double* __restrict__ p = params + (size_t)(k4 + u) * PS;      // records k >= K: coef = -inf
+                    double q = 0.0;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        const double z = x[j] - p[j];
+                        q = __builtin_fma(z * p[D + j], z, q);
+                    }
+                    const double lw = __builtin_fma(-0.5, q, p[2 * D]);
+                    lwv[k4 + u] = lw;
+                    m = lw > m ? lw : m;
+                    __builtin_amdgcn_sched_barrier(0);        // one record in scalar registers at a time
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) lwv[k4 + u] = -__builtin_inf();
+            }
+        }
+        // ---- 2. normalisation: one exp per (sample, component)
+        double sum = 0.0;
+#pragma unroll
+        for (int k4 = 0; k4 < KMAX; k4 += 4) {
+            if (k4 < K) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double e = exp_nonpos(lwv[k4 + u] - m);                   // exp(-inf) = 0 for the neutral tail
+                    lwv[k4 + u] = e;
+                    sum += e;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) lwv[k4 + u] = 0.0;
+            }
+        }
+        const double lse = m + log(sum);
+        const bool live = i < n;
+        lse_out[i] = lse;
+        if (live) ll_acc += lse;
+        const double inv = live ? 1.0 / sum : 0.0;                                  // padding samples contribute nothing
+
+        // ---- 3. statistics on the matrix cores, the tile in two 32-sample halves through LDS
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            __builtin_amdgcn_wave_barrier();
+            if ((lane >> 5) == h) {
+                double* xw = Xw + (lane & 31) * XSS;
+#pragma unroll
+                for (int j = 0; j < D; ++j) xw[j] = x[j] - shift[j];               // shift is zero-padded to D entries
+                xw[ONE] = 1.0;
+                xw[ZERO] = 0.0;
+                double* rw = Rw + (lane & 31) * RSS;
+#pragma unroll
+                for (int it = 0; it < 16; ++it) rw[it] = lwv[it] * inv;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_setprio(kMatrixPhasePriority);
+#pragma unroll 4
+            for (int sg = 0; sg < HT / 4; ++sg) {
+                const double av = rbase[sg * RSS];               // r of (sample 8 g + sg of the half, component lane & 15)
+                const double* xr = xbase + sg * XSS;
+                s0 += av;
+#pragma unroll
+                for (int c = 0; c < CB; ++c) {
+                    const double bv = xr[offa[c]] * xr[offb[c]];
+                    acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[c], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+
+    // ---- epilogue: fold the 4 waves' accumulators, S0 sums and log-likelihood sums in fixed order
+    s0 += __shfl_xor(s0, 16, 64);
+    s0 += __shfl_xor(s0, 32, 64);
+    double* out = partials + (size_t)blockIdx.x * KP * FP;
+    for (int w = 0; w < 4; ++w) {
+        if (w == wave) {
+#pragma unroll
+            for (int c = 0; c < CB; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int k = (lane >> 4) + 4 * g;
+                    const int f = c * 16 + (lane & 15);
+                    if (f < 2 * d) {
+                        double* p = out + (size_t)k * FP + f;
+                        *p = (w == 0 ? 0.0 : *p) + acc[c][g];
+                    }
+                }
+            if (lane < 16) {
+                double* p = out + (size_t)lane * FP + 2 * d;
+                *p = (w == 0 ? 0.0 : *p) + s0;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ll_acc += __shfl_down(ll_acc, off, 64);
+    if (lane == 0) red[wave] = ll_acc;
+    __syncthreads();
+    if (tid == 0) ll_partials[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+/// Shapes the scalar-fed kernel serves: one row block of components, coordinates + densities within 128 registers.
+/// MLHIP_DIAG_SGPR=0: off (A/B runs).
+inline bool diag_sgpr_applies(int d, int K)
+{
+    const char* e = std::getenv("MLHIP_DIAG_SGPR");
+    return !(e && e[0] == '0') && K <= 16 && padded_dim(d) <= 16;
+}
+
 constexpr int rbw_of(int RBT) { return RBT >= 2 ? 2 : 1; }
 
 /// MLHIP_DIAG_AB=0: the exact form of the density loop always (A/B runs).
@@ -328,6 +495,14 @@ template <int D, int RBT>
 int launch_t(const DiagArgs& a, int grid, hipStream_t stream)
 {
     constexpr int CB = (2 * D + 15) / 16, RBW = rbw_of(RBT), PS = 2 * D + 2, XSS = xsd<D>(), S = samples_per_lane(D, RBT);
+    if constexpr (RBT == 1 && D <= 16) {
+        if (diag_sgpr_applies(a.d, a.K)) {
+            const size_t smem = sizeof(double) * 4 * ((size_t)(TS / 2) * XSS + (size_t)(TS / 2) * RSS);
+            hipLaunchKernelGGL((em_diag_sgpr_kernel<D, CB>), dim3(grid), dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d, a.shift, a.params,
+                               a.K, a.lse, a.partials, em_diag_partial_rows(a.K), em_diag_partial_cols(a.d), a.ll_partials);
+            return grid;
+        }
+    }
     const size_t smem = sizeof(double) * (4 * ((size_t)TS * XSS + (size_t)TS * RSS) + (size_t)16 * RBT * PS);
     hipLaunchKernelGGL((em_diag_kernel<D, RBT, RBW, CB, S>), dim3(grid, RBT / RBW), dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d,
                        a.shift, a.params, a.K, a.lse, a.partials, em_diag_partial_rows(a.K), em_diag_partial_cols(a.d),
@@ -356,10 +531,11 @@ int em_diag_grid(int d, int K, uint32_t n, int num_cus)
 {
     const int RB = (K + 15) / 16;
     const int D = padded_dim(d), RBT = RB == 1 ? 1 : (RB == 2 ? 2 : 4);
-    const uint32_t tw = (uint32_t)TS * samples_per_lane(D, RBT);
+    const bool sgpr = diag_sgpr_applies(d, K);
+    const uint32_t tw = (uint32_t)TS * (sgpr ? 1 : samples_per_lane(D, RBT));
     const uint32_t n_tiles = (n + tw - 1) / tw;
     const int groups = RB >= 4 ? 2 : 1;                          // row-block groups in grid.y
-    int per_cu = (padded_dim(d) <= 16 && RB <= 2) ? 2 : 1;
+    int per_cu = sgpr ? (D <= 8 ? 4 : 3) : ((D <= 16 && RB <= 2) ? 2 : 1);   // workgroups the registers / LDS admit per CU
     int grid = per_cu * num_cus / groups;
     if ((uint32_t)grid * 4 > n_tiles) grid = (int)((n_tiles + 3) / 4);
     return grid < 1 ? 1 : grid;

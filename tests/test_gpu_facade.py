@@ -494,16 +494,23 @@ def test_random_partition_on_device_is_bit_identical_to_the_reference_loop(oracl
         X, _ = synth.Mixture(d, K, seed=3).sample(n)
         ref = oracle.init_centroids(oracle.RANDOM_PARTITION, X, K, seed)
         init = cl.RandomPartition()
+        from ml_amd import cppyml
+        dctx = cppyml.device_context()
+        dctx.timing_reset()
+        dctx.timing_enable(True)
         t0 = time.perf_counter()
         dev = init._run_on_device(X, K, seed=seed)
         t_dev = time.perf_counter() - t0
+        k_ms = dctx.timing_get("random_partition")[0]
+        dctx.timing_enable(False)
         assert np.array_equal(dev, ref), (d, K, n)
         if n == 1_000_000:
             t0 = time.perf_counter()
             host = init._run(X, K, seed=seed)
             t_host = time.perf_counter() - t0
             assert np.array_equal(host, ref)
-            print(f"RandomPartition N=1M d=32 K=64: device path {t_dev * 1e3:.1f} ms incl. the upload of X, host loop {t_host * 1e3:.1f} ms")
+            print(f"RandomPartition N=1M d=32 K=64: device path {t_dev * 1e3:.1f} ms incl. the upload of X (the chains' kernel: "
+                  f"{k_ms:.2f} ms), host loop {t_host * 1e3:.1f} ms")
     # through fit(): same start => same labels after the same steps
     X, _ = synth.Mixture(6, 8, seed=21).sample(30000)
     km, okm = cl.KMeans(8), oracle.KMeans(8)
