@@ -7,13 +7,13 @@
 // and S = C X is a GEMM. So, per 64-sample group of a wave:
 //   1. scores by v_mfma_f64_16x16x4_f64: A = 16 centroids x 4 dims (LDS), B = 4 dims x 16 samples (coordinates held in
 //      VGPRs in operand layout), accumulator initialised with -|c|^2/2; every lane tracks best and second-best over the
-//      4 x (K/16) clusters it sees. The cluster's position is carried IN the score (low mantissa byte, see tagged()), and
-//      the four scores of an accumulator enter the tracking through their maximum (track_quad): 1.5 fp64 VALU
-//      operations per score -- they share the pipe with the MFMAs -- instead of 3 plus a compare and a select. The four
+//      4 x (K/16) clusters it sees. For large K (QUAD) the tracking runs on 32-bit integer keys -- the high dword of the
+//      biased, hence positive, score -- and the four scores of an accumulator enter it through their maximum
+//      (track_quad_keys): 1.75 integer operations per score instead of 3 fp64 ones plus a compare and a select. The four
 //      lane groups are merged by shuffles;
 //   2. one lane per sample re-reads the sample's row and evaluates the EXACT direct-form distance to the winner with the
-//      same fma chain as the host point query (this is the min distance / inertia contribution that is stored), and the
-//      scores of the winner's three quad-mates, which step 1 left out of the runner-up;
+//      same fma chain as the host point query (this is the min distance / inertia contribution that is stored); QUAD: the
+//      exact distances to all four clusters of the winning quad, which step 1 did not tell apart;
 //   3. if best - second (or best - a mate's score) is not larger than E = (8 (d+2) + 1024) 2^-53 (|x|^2 + max_k |c_k|^2)
 //      -- a bound on the rounding error of the two scores plus that of the direct form itself, with a factor 2 to spare,
 //      plus the 2 x 2^-44 the tags perturb the two scores by -- the sample is AMBIGUOUS and the lane falls back to the
@@ -33,7 +33,6 @@ namespace {
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int BSM = 512;   // threads per workgroup (8 waves; two workgroups per CU)
-constexpr int kSubBlocks = 64;   // 16-cluster blocks per tagged sub-chunk: 4 accumulator rows x 64 blocks = 256 tags (one byte)
 /// Score of the rows that pad K to a multiple of 16: finite (a tag inserted into -inf's mantissa would make it a NaN),
 /// below every real score (|score| <= |x|^2 + max|c|^2 overflows long before it gets here).
 constexpr double kPadScore = -0x1p1020;
@@ -53,31 +52,24 @@ __device__ __forceinline__ void track_top2(double& best, double& second, double 
         : "v"(v), "v"(order));
 }
 
-/// Tagged scores: the low mantissa BYTE of a score is REPLACED by `tag` (wave-uniform: which of the 256 clusters of the
-/// current 1024-cluster sub-chunk this lane is looking at), so a running maximum carries its own argmax -- no separate
-/// index register, no compare + select. The perturbation is below 256 ulp = 2^-44 |score| <= 2^-44 (|x|^2 + max|c|^2);
-/// the certainty threshold (err_unit) carries it for both scores of a gap. The byte permute is a compiler builtin, not
-/// inline assembly, so that the compiler sees the first VALU reader of the matrix-core result and inserts the wait
-/// states itself.
-__device__ __forceinline__ double tagged(double v, int tag)
+/// QUAD tracking on 32-bit integer keys (round 3; before: tagged fp64 scores, v_min / v_max_f64): the scores are biased by
+/// max|c|^2 / 2 in the accumulator initialiser, so the score of every cluster a sample can belong to is positive, and the HIGH
+/// dword of a positive double orders like the double itself as a signed integer (negative scores -- clusters far behind, or the
+/// padding rows -- are negative integers: never ahead of a positive one). The four scores one accumulator holds for a sample
+/// (rows r = 0..3: clusters 16 b + g + 4 r) enter the top-2 tracking through the maximum of their keys, and only the BLOCK of
+/// the running best is remembered: 7 integer operations per four scores (v_max3_i32, v_max_i32, v_min_i32, v_max_i32,
+/// v_cmp_gt_i32, v_cndmask_b32, v_max_i32) instead of 4 byte permutes + 6 fp64 min / max -- next to the matrix
+/// instructions a vector instruction costs its issue slot whatever its width (tools/microbench_issue), and these are 30 %
+/// fewer. The key keeps 20 mantissa bits: the exact phase turns (best, runner-up) back into a lower / upper bound of the two
+/// scores and demands their distance to exceed the rounding margin; the winner's quad (4 clusters) is then settled by exact
+/// direct-form distances, everything else falls back to the full scan.
+__device__ __forceinline__ void track_quad_keys(int& best, int& second, int& block, d4 acc, int this_block)
 {
-    // bytes 3..1 of the low word, byte 0 of the tag: selector {3, 2, 1, 4} over the byte string {tag (4..7), lo (0..3)}
-    const int lo = (int)__builtin_amdgcn_perm((unsigned)tag, (unsigned)__double2loint(v), 0x03020104u);
-    return __hiloint2double(__double2hiint(v), lo);
-}
-
-/// The four scores one accumulator holds for a sample (rows r = 0..3: clusters b + g + 4 r of block b) enter the top-2
-/// tracking through their MAXIMUM only: 3 + 3 fp64 VALU operations per four scores instead of 12 -- the fp64 min / max
-/// share the pipe with the matrix instructions, so they are what the loop pays for next to the MFMAs. What this loses is
-/// exactly the three quad-mates of the final winner (every other quad's losers are below that quad's maximum, which IS
-/// tracked); the exact phase scores those three itself (phase 2).
-__device__ __forceinline__ void track_quad(double& best, double& second, d4 acc, int tag0)
-{
-    const double t0 = tagged(acc[0], tag0), t1 = tagged(acc[1], tag0 + 1), t2 = tagged(acc[2], tag0 + 2),
-                 t3 = tagged(acc[3], tag0 + 3);
-    double m, u;
-    asm("v_max_f64 %0, %2, %3\n\tv_max_f64 %1, %4, %5\n\tv_max_f64 %0, %0, %1" : "=&v"(m), "=&v"(u) : "v"(t0), "v"(t1), "v"(t2), "v"(t3));
-    track_top2(best, second, m, 0);
+    const int k0 = __double2hiint(acc[0]), k1 = __double2hiint(acc[1]), k2 = __double2hiint(acc[2]), k3 = __double2hiint(acc[3]);
+    const int m = max(max(k0, k1), max(k2, k3));
+    second = max(second, min(best, m));
+    block = m > best ? this_block : block;
+    best = max(best, m);
 }
 
 /// One sample's coordinates for the exact phase: in registers (INREGS) or re-read from memory (L1/L2) at every use.
@@ -177,9 +169,14 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
     }
     __syncthreads();
     const double cmax2 = *cmax_slot;
+    // QUAD: scores biased by max|c|^2 / 2 (>= 0 for every real row; see track_quad_keys)
+    if constexpr (QUAD && !CHUNKED) {
+        for (int k = tid; k < K; k += BSM) cn[k] += 0.5 * cmax2;
+        __syncthreads();
+    }
     // rounding of the two scores and of the direct form (8 (d+2) 2^-53, factor 2 to spare) + the tag perturbation of the two
     // scores of the gap (2 x 2^-44 = 1024 x 2^-53)
-    const double err_unit = (8.0 * (D + 2) + (QUAD ? 1024.0 : 0.0)) * 0x1p-53;
+    const double err_unit = 8.0 * (D + 2) * 0x1p-53;
 
     double inertia = 0.0, changed = 0.0;
     const uint32_t n_groups = n_pad / GS;
@@ -199,15 +196,16 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
         for (int q = 0; q < Q; ++q)
 #pragma unroll
             for (int sb = 0; sb < NSB; ++sb) xb[q][sb] = xt[(size_t)(4 * q + g) * ldx + base + 16 * sb + s];
-        // QUAD: running winner over the sub-chunks done so far (tagged score, runner-up, first cluster of the winning
-        // sub-chunk) next to the sub-chunk's own best / second; otherwise best / second / idx run over all clusters
-        double gbest[NSB], gsecond[NSB], best[NSB], second[NSB];
-        int gbase[NSB], idx[NSB];
+        // best / second / idx run over all clusters this lane sees; QUAD: integer keys (kbest / ksecond) and the 16-cluster
+        // block of the running best in idx
+        double best[NSB], second[NSB];
+        int kbest[NSB], ksecond[NSB], idx[NSB];
 #pragma unroll
         for (int sb = 0; sb < NSB; ++sb) {
-            gbest[sb] = best[sb] = -__builtin_inf();
-            gsecond[sb] = second[sb] = -__builtin_inf();
-            gbase[sb] = idx[sb] = 0;
+            best[sb] = -__builtin_inf();
+            second[sb] = -__builtin_inf();
+            kbest[sb] = ksecond[sb] = (int)0x80000000;
+            idx[sb] = 0;
         }
 
         __builtin_amdgcn_s_setprio(kMatrixPhasePriority);   // scoring loop over exact phase of the SIMD's other waves (1.25 -> 1.20 ms at d = 8, K = 256)
@@ -232,20 +230,19 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
                     if (gi < total) Cs[(gi / D) * DS + gi % D] = v[u];
                 }
             }
-            for (int k = tid; k < rows; k += BSM) cn[k] = cnorm[k0 + k];     // kPadScore for the padding rows
+            for (int k = tid; k < rows; k += BSM)                            // kPadScore for the padding rows
+                cn[k] = (QUAD && k0 + k < K) ? cnorm[k0 + k] + 0.5 * cmax2 : cnorm[k0 + k];
             __syncthreads();
         }
-        for (int cb0 = 0; cb0 < rows / 16; cb0 += kSubBlocks) {
-        // ---- QUAD: one sub-chunk of up to 1024 clusters, tag = 4 (cb - cb0) + r identifies the cluster within it
-        const int cb_end = QUAD ? min(cb0 + kSubBlocks, rows / 16) : rows / 16;
-        if constexpr (QUAD) {
-#pragma unroll
-            for (int sb = 0; sb < NSB; ++sb) { best[sb] = -__builtin_inf(); second[sb] = -__builtin_inf(); }
-        }
+        {
+        const int cb0 = 0, cb_end = rows / 16;
         // the four scores (accumulator rows) of block cb for one sample block
-        auto consume = [&](double& bst, double& sec, int& ix, const d4& sc, int cb) {
+        auto consume = [&](int sb, const d4& sc, int cb) {
+            double& bst = best[sb];
+            double& sec = second[sb];
+            int& ix = idx[sb];
             if constexpr (QUAD) {
-                track_quad(bst, sec, sc, 4 * (cb - cb0));
+                track_quad_keys(kbest[sb], ksecond[sb], ix, sc, k0 / 16 + cb);
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -296,7 +293,7 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
                     }
 #pragma unroll
                     for (int sb = 0; sb < NSB; ++sb) {
-                        consume(best[sb], second[sb], idx[sb], acc[sb], cb);
+                        consume(sb, acc[sb], cb);
                         acc[sb] = acc2[sb];                          // the second block goes through the common tail
                     }
                     ++cb;
@@ -310,39 +307,45 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
                 }
             }
 #pragma unroll
-            for (int sb = 0; sb < NSB; ++sb) consume(best[sb], second[sb], idx[sb], acc[sb], cb);
+            for (int sb = 0; sb < NSB; ++sb) consume(sb, acc[sb], cb);
         }
-        if constexpr (!QUAD) break;             // one pass over the chunk
-        // fold the sub-chunk into the running winner (5 VALU operations per sub-chunk)
-#pragma unroll
-        for (int sb = 0; sb < NSB; ++sb) {
-            gbase[sb] = (best[sb] > gbest[sb]) ? k0 + 16 * cb0 : gbase[sb];
-            gsecond[sb] = fmax(fmax(gsecond[sb], second[sb]), fmin(gbest[sb], best[sb]));
-            gbest[sb] = fmax(gbest[sb], best[sb]);
+        (void)cb0;
         }
-        }   // sub-chunks
         }   // chunks
         __builtin_amdgcn_s_setprio(0);
         // merge the 4 lane groups (disjoint cluster subsets) of every sample block; lane (g, s) keeps sample 16 g + s
         double my_best = 0.0, my_second = 0.0;
+        int my_kbest = 0, my_ksecond = 0;
         int my_idx = 0;
 #pragma unroll
         for (int sb = 0; sb < NSB; ++sb) {
-            double b = QUAD ? gbest[sb] : best[sb], sd = QUAD ? gsecond[sb] : second[sb];
-            // QUAD: cluster = first of the sub-chunk + 16 (tag >> 2) + 4 (tag & 3) + g  (accumulator row tag & 3 of block tag >> 2)
-            const int tag = __double2loint(b) & 255;
-            int ix = QUAD ? gbase[sb] + 16 * (tag >> 2) + 4 * (tag & 3) + g : idx[sb];
+            if constexpr (QUAD) {
+                int b = kbest[sb], sd = ksecond[sb];
+                int ix = 16 * idx[sb] + g;              // first cluster of the winning quad: 16 block + g (+ 4 r, r = 0..3)
 #pragma unroll
-            for (int off = 16; off <= 32; off <<= 1) {
-                const double b2 = __shfl_xor(b, off, 64), s2 = __shfl_xor(sd, off, 64);
-                const int i2 = __shfl_xor(ix, off, 64);
-                // keep the smaller index on exactly equal scores so that all four lanes agree
-                const bool take2 = (b2 > b) || (b2 == b && i2 < ix);
-                sd = fmax(fmin(b, b2), fmax(sd, s2));
-                ix = take2 ? i2 : ix;
-                b = fmax(b, b2);
+                for (int off = 16; off <= 32; off <<= 1) {
+                    const int b2 = __shfl_xor(b, off, 64), s2 = __shfl_xor(sd, off, 64), i2 = __shfl_xor(ix, off, 64);
+                    const bool take2 = (b2 > b) || (b2 == b && i2 < ix);   // (equal keys: the runner-up equals the best -> ambiguous)
+                    sd = max(min(b, b2), max(sd, s2));
+                    ix = take2 ? i2 : ix;
+                    b = max(b, b2);
+                }
+                if (g == sb) { my_kbest = b; my_ksecond = sd; my_idx = ix; }
+            } else {
+                double b = best[sb], sd = second[sb];
+                int ix = idx[sb];
+#pragma unroll
+                for (int off = 16; off <= 32; off <<= 1) {
+                    const double b2 = __shfl_xor(b, off, 64), s2 = __shfl_xor(sd, off, 64);
+                    const int i2 = __shfl_xor(ix, off, 64);
+                    // keep the smaller index on exactly equal scores so that all four lanes agree
+                    const bool take2 = (b2 > b) || (b2 == b && i2 < ix);
+                    sd = fmax(fmin(b, b2), fmax(sd, s2));
+                    ix = take2 ? i2 : ix;
+                    b = fmax(b, b2);
+                }
+                if (g == sb) { my_best = b; my_second = sd; my_idx = ix; }
             }
-            if (g == sb) { my_best = b; my_second = sd; my_idx = ix; }
         }
 
         // ---- phase 2: one lane per sample, exact arithmetic
@@ -354,22 +357,41 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
             //  the winner's row inside the table whatever the scores were)
             uint32_t arg = min((uint32_t)my_idx, (uint32_t)(K - 1));
             double dist = 0.0;
-            // the winner's three quad-mates (same block, same lane group, the other accumulator rows: clusters that differ
-            // from the winner in bits 2..3 only) did not take part in the runner-up tracking: their scores x.c - |c|^2/2 are
-            // evaluated here, with the rounding bound of the matrix-core scores (an ascending fma chain of d + 1 terms)
-            const uint32_t quad = arg & ~12u, rw = (arg >> 2) & 3u;
-            uint32_t mate[3];
-            double ms[3];
-            const double* mc[3];
+            bool certain;
+            if constexpr (QUAD) {
+                // the four clusters of the winning quad (same block, same lane group: my_idx + 4 r) were told apart by nobody:
+                // exact direct-form distances to all of them, the reference's comparison among them (strict '<', ascending k)
+                const double* qc[4];
+                double qd[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                mate[t] = quad | (((rw + 1 + t) & 3u) << 2);
-                const uint32_t row = min(mate[t], (uint32_t)(K - 1));      // padding rows: any valid row, result unused
-                mc[t] = CHUNKED ? cent + (size_t)row * D : Cs + (size_t)row * DS;
-                ms[t] = !QUAD ? 0.0 : CHUNKED ? cnorm[row] : cn[row];
-            }
-            {
-                // |x|^2, the exact distance to the winner and the mates' scores in one pass over the sample
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t row = min((uint32_t)my_idx + 4u * r, (uint32_t)(K - 1));   // padding rows: any valid row, result unused
+                    qc[r] = CHUNKED ? cent + (size_t)row * D : Cs + (size_t)row * DS;
+                }
+#pragma unroll kExactUnroll
+                for (int j = 0; j < D; ++j) {
+                    const double v = x(j);
+                    xn = __builtin_fma(v, v, xn);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double t = v - qc[r][j];
+                        qd[r] = __builtin_fma(t, t, qd[r]);
+                    }
+                }
+                arg = (uint32_t)my_idx;
+                dist = qd[0];
+#pragma unroll
+                for (int r = 1; r < 4; ++r)
+                    if ((uint32_t)my_idx + 4u * r < (uint32_t)K && qd[r] < dist) { dist = qd[r]; arg = (uint32_t)my_idx + 4u * r; }
+                // every cluster outside the quad scores below `upper` (its key, one unit up), the quad's best at least `lower`:
+                // the quad holds the reference's winner if they are further apart than all rounding involved. A non-positive
+                // or non-finite best key (a sample far from every centroid; NaN scores) is never certain.
+                const double lower = __hiloint2double(my_kbest, 0);
+                const double upper = my_ksecond < 0 ? 0.0 : __hiloint2double(my_ksecond + 1, 0);
+                certain = (uint32_t)my_idx < (uint32_t)K && my_kbest > 0 && my_kbest < 0x7ff00000 &&
+                          (lower - upper) > err_unit * (xn + cmax2);
+            } else {
+                // |x|^2 and the exact distance to the winner in one pass over the sample
                 const double* c = CHUNKED ? cent + (size_t)arg * D : Cs + (size_t)arg * DS;
 #pragma unroll kExactUnroll
                 for (int j = 0; j < D; ++j) {
@@ -377,17 +399,8 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
                     xn = __builtin_fma(v, v, xn);
                     const double t = v - c[j];
                     dist = __builtin_fma(t, t, dist);
-                    if constexpr (QUAD) {
-#pragma unroll
-                        for (int m = 0; m < 3; ++m) ms[m] = __builtin_fma(v, mc[m][j], ms[m]);
-                    }
                 }
-            }
-            const double margin = err_unit * (xn + cmax2);
-            bool certain = (my_best - my_second) > margin;                      // false for NaN / inf as well
-            if constexpr (QUAD) {
-#pragma unroll
-                for (int t = 0; t < 3; ++t) certain = certain && (mate[t] >= (uint32_t)K || (my_best - ms[t]) > margin);
+                certain = (my_best - my_second) > err_unit * (xn + cmax2);          // false for NaN / inf as well
             }
             if (!certain) {
                 // ambiguous: the reference's own loop (ML/KMeans.cpp:155-163)
