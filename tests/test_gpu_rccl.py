@@ -97,7 +97,7 @@ def _rccl_worker(rank, world, path, q):
         q.put((rank, "error", traceback.format_exc(), str(e)))
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("world", [2, 4])      # (+ the parent: at most 5 processes on the GPUs at once)
 def test_native_rccl_ranks_reproduce_the_single_gpu_fit(tmp_path, world):
     """mlhip_ctx_init_rccl_file with one process per GPU: the row-sharded EM and K-means fits (statistics all-reduced by
     ncclAllReduce on the library's own communicators) against the single-GPU fit of the whole sample: same steps, parameters to
