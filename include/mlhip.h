@@ -117,7 +117,7 @@ int mlhip_em_step(mlhip_ctx* ctx, mlhip_data* data, uint32_t K,
 /* EXTENSION (no counterpart in the reference, whose ml::EM is full-covariance only, ML/EM.hpp:175; BASELINE.json configs[1]):
  * one EM iteration with DIAGONAL covariances -- the loops of mlhip_em_step restricted to the diagonal, in one kernel
  * (X read once, no N x K block in HBM). variances / variances_out: K*d doubles, variances[k*d + j] = sigma_kj^2 (ridge 1e-15
- * included on output, ML/EM.cpp:252). 1 <= d <= 32, 1 <= K <= 64 (MLHIP_E_UNSUPPORTED otherwise). mlhip_em_responsibilities /
+ * included on output, ML/EM.cpp:252). One fused kernel for d <= 32, K <= 64; other shapes (d <= 128) run the full-covariance kernels on diagonal matrices. mlhip_em_responsibilities /
  * mlhip_em_labels afterwards work as after mlhip_em_step (the block is rebuilt from the same parameters on demand). */
 int mlhip_em_step_diag(mlhip_ctx* ctx, mlhip_data* data, uint32_t K,
                        const double* mixing, const double* means, const double* variances,

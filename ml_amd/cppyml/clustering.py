@@ -182,7 +182,8 @@ class EM:
 
     def set_covariance_type(self, covariance_type):
         """Extension (not in the reference surface): "full" (default, the reference's only mode) or "diag" -- every
-        covariance restricted to its diagonal; `covariance(k)` then returns a diagonal matrix. d <= 32, K <= 64."""
+        covariance restricted to its diagonal; `covariance(k)` then returns a diagonal matrix. One fused kernel per iteration for
+        d <= 32, K <= 64; other shapes run the full-covariance kernels on diagonal matrices."""
         if covariance_type not in ("full", "diag"):
             raise ValueError("covariance_type must be 'full' or 'diag'")
         _check(_l.mlpp_em_set_covariance_type(self._h, int(covariance_type == "diag")))

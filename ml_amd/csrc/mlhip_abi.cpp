@@ -1129,10 +1129,26 @@ void refine_diag(mlhip_data* data, int K, const double* mixing_out, double* mean
 }
 
 /// One diagonal-covariance EM iteration with the closing arithmetic on the HOST (the body of mlhip_em_step_diag).
+void em_step_full(mlhip_data* data, int K, const double* mixing, const double* means, const double* covariances,
+                  double* log_likelihood, double* mixing_out, double* means_out, double* covariances_out);
+
 void em_step_diag(mlhip_data* data, int K, const double* mixing, const double* means, const double* variances,
                   double* log_likelihood, double* mixing_out, double* means_out, double* variances_out)
 {
     const int d = data->d;
+    if (!mstats::em_diag_supported(d, K)) {
+        // Shapes the one-kernel diagonal iteration is not built for (d > 32 or K > 64): the same iteration through the
+        // full-covariance kernels on diagonal matrices -- the E-step's Cholesky of a diagonal matrix is its square root, and
+        // the diagonal of the M-step's full covariance IS the diagonal-mode variance (ML/EM.cpp:245-257 entry by entry); the
+        // off-diagonal sums are computed and dropped. Slower than it could be, never refused.
+        std::vector<double> cov((size_t)K * d * d, 0.0), cov_out((size_t)K * d * d);
+        for (int k = 0; k < K; ++k)
+            for (int j = 0; j < d; ++j) cov[((size_t)k * d + j) * d + j] = variances[(size_t)k * d + j];
+        em_step_full(data, K, mixing, means, cov.data(), log_likelihood, mixing_out, means_out, cov_out.data());
+        for (int k = 0; k < K; ++k)
+            for (int j = 0; j < d; ++j) variances_out[(size_t)k * d + j] = cov_out[((size_t)k * d + j) * d + j];
+        return;
+    }
     ensure_em_workspace(data, K);
     // keep the input parameters: labels / responsibilities are produced from them on demand (ensure_lw)
     data->diag_mixing.assign(mixing, mixing + K);
@@ -1176,7 +1192,7 @@ void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* mean
     };
     static const bool device_close_allowed = [] { const char* e = std::getenv("MLHIP_DEVICE_CLOSE"); return !(e && e[0] == '0'); }();
     ensure_em_workspace(data, K);
-    bool device_close = device_close_allowed && em_close_supported(d);
+    bool device_close = device_close_allowed && em_close_supported(d) && !(diag && !mstats::em_diag_supported(d, K));
     if (device_close && !diag) {
         prepare_estep(data, K, mixing, means, covs);           // records of the caller's parameters -> params_dev
         if (data->estep_variant == 1) device_close = false;    // (experimental record layout: host closing only)
@@ -1627,8 +1643,6 @@ int mlhip_em_step_diag(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const doubl
     return guarded([&] {
         check_em_args(ctx, data, K);
         require(mixing && means && variances && log_likelihood && mixing_out && means_out && variances_out, "null argument");
-        if (!mstats::em_diag_supported(data->d, (int)K))
-            throw Unsupported("diagonal-covariance EM is built for d <= 32 and K <= 64");
         em_step_diag(data, (int)K, mixing, means, variances, log_likelihood, mixing_out, means_out, variances_out);
     });
 }
@@ -1644,8 +1658,6 @@ int mlhip_em_iterate(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, int covarianc
         require(max_steps >= 1, "at least one step required");
         if (absolute_tolerance < 0 || relative_tolerance < 0) throw DomainError("negative tolerance");
         const bool diag = covariance_type == MLHIP_COVARIANCE_DIAGONAL;
-        if (diag && !mstats::em_diag_supported(data->d, (int)K))
-            throw Unsupported("diagonal-covariance EM is built for d <= 32 and K <= 64");
         em_iterate(data, (int)K, diag, mixing, means, covariances, max_steps, absolute_tolerance, relative_tolerance, steps_done,
                    converged, log_likelihood, log_likelihood_history);
         const size_t cov_doubles = (size_t)K * data->d * (diag ? 1 : data->d);

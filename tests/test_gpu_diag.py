@@ -119,17 +119,31 @@ def test_tight_clusters_far_from_the_global_mean_are_refined(ctx, oracle):
     dt.close()
 
 
-def test_unsupported_shapes_are_refused(ctx):
-    from ml_amd import _lib
-    rng = np.random.default_rng(0)
-    dt = _data(ctx, rng.standard_normal((500, 40)))
-    with pytest.raises(_lib.MlhipError) as e:
-        dt.em_step_diag(np.full(2, 0.5), np.zeros((2, 40)), np.ones((2, 40)))
-    assert e.value.code == _lib.E_UNSUPPORTED
-    dt.close()
-    dt = _data(ctx, rng.standard_normal((500, 4)))
-    with pytest.raises(_lib.MlhipError):
-        dt.em_step_diag(np.full(65, 1 / 65), np.zeros((65, 4)), np.ones((65, 4)))
+@pytest.mark.parametrize("d,K,n", [(40, 3, 3000), (4, 65, 6000), (100, 5, 4000), (24, 130, 9000)])
+def test_shapes_beyond_the_fused_kernel_run_through_the_full_covariance_kernels(ctx, oracle, d, K, n):
+    """d > 32 or K > 64: the diagonal mode is not refused any more (missing #5) -- the iteration goes through the
+    full-covariance kernels on diagonal matrices and must agree with the oracle's diagonal mode like the fused kernel does."""
+    rng = np.random.default_rng(d * 1000 + K)
+    centres = 4.0 * rng.standard_normal((K, d))
+    X = np.ascontiguousarray(centres[rng.integers(0, K, n)] + rng.standard_normal((n, d)) * rng.uniform(0.5, 1.5, d))
+    mu0 = centres + 0.2 * rng.standard_normal((K, d))
+    var0 = np.tile(np.var(X, axis=0), (K, 1)) * rng.uniform(0.8, 1.2, (K, d))
+    pi0 = rng.dirichlet(np.full(K, 5.0))
+    dt = _data(ctx, X)
+    ll, pi1, mu1, var1 = dt.em_step_diag(pi0, mu0, var0)
+    em = oracle.EM(K)
+    em.set_covariance_type("diag")
+    em.set_parameters(mu0, np.stack([np.diag(v) for v in var0]), pi0)
+    em.expectation_step(X)
+    assert abs(ll - em.log_likelihood) <= 1e-12 * abs(em.log_likelihood)
+    em.calculate_labels()
+    assert np.array_equal(dt.em_labels(K), np.asarray(em.labels))
+    em.maximisation_step(X)
+    var_o = np.stack([np.diag(c) for c in em.covariances])
+    assert relerr(pi1, em.mixing_probabilities) < 1e-11 and relerr(mu1, em.means) < 1e-11
+    assert np.max(np.abs(var1 - var_o) / var_o) < 1e-9
+    steps, conv, ll_it, pi_b, mu_b, var_b, hist = dt.em_iterate(pi0, mu0, var0, 3, 0.0, 0.0, True)
+    assert steps == 3 and abs(hist[0] - ll) <= 1e-13 * abs(ll)
     dt.close()
 
 
