@@ -268,8 +268,12 @@ struct mlhip_data {
     bool diag_step = false;
     std::vector<double> diag_mixing, diag_means, diag_vars;
     // mlhip_em_iterate: parameters and the next E-step's records stay on the device between iterations
-    DevBuf params_next, it_pack[2];      // it_pack: [info (1 + 2K) | mixing (K) | means (K d) | covariances], one D2H covers it
+    DevBuf params_next, it_pack[3];      // it_pack: [info (1 + 2K) | mixing (K) | means (K d) | covariances], one D2H covers it
     PinnedBuf it_info_host;
+    // ... and, for the lagged (speculative) loop of small shapes: a third record buffer, one read-back slot and event per pack
+    DevBuf params_prev;
+    PinnedBuf it_info_slot[3];
+    hipEvent_t it_event[3] = {nullptr, nullptr, nullptr};
     // source of the last statistics pass (for the per-component refinement pass)
     int stats_mode = 0;
     const double* stats_resp = nullptr;
@@ -286,9 +290,11 @@ struct mlhip_data {
     {
         for (DevBuf* b : {&xt, &shift_dev, &lw, &lse, &esum, &ll_partials, &params_dev, &partials, &stats_dev, &resp_dev,
                           &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_cent_next, &km_partials, &km_out, &km_mind, &km_probe, &km_scale, &km_cnorm, &km_xt_pad,
-                          &refine_shift, &refine_stats, &params_next, &it_pack[0], &it_pack[1]})
+                          &refine_shift, &refine_stats, &params_next, &params_prev, &it_pack[0], &it_pack[1], &it_pack[2]})
             b->release();
         it_info_host.release();
+        for (auto& sl : it_info_slot) sl.release();
+        for (auto& e : it_event) if (e) (void)hipEventDestroy(e);
         params_host.release(); stats_host.release(); km_host.release();
     }
 };
@@ -1211,7 +1217,7 @@ void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* mean
     const size_t F = diag ? diag_stats_count(d) : stats_count(d);
     const size_t n_info = em_close_info_doubles(K);
     const size_t n_pack = n_info + K + (size_t)K * d + n_cov;
-    for (int b = 0; b < 2; ++b) data->it_pack[b].reserve(sizeof(double) * n_pack);
+    for (int b = 0; b < 3; ++b) data->it_pack[b].reserve(sizeof(double) * n_pack);
     data->it_info_host.reserve(sizeof(double) * n_pack);          // info, then (diagonal mode) a shadow of the newest parameters
     auto pack_mixing = [&](int b) { return data->it_pack[b].as<double>() + n_info; };
     auto pack_means = [&](int b) { return pack_mixing(b) + K; };
@@ -1236,8 +1242,9 @@ void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* mean
     double* info = data->it_info_host.as<double>();
     double* shadow = info + n_info;
 
-    for (uint32_t step = 0; step < max_steps; ++step) {
-        PhaseTrace tr;
+    // One iteration's device work: E-step + statistics from the records in params_dev, all-reduce, closing arithmetic into
+    // it_pack[out] and the next records into params_next. Nothing here waits for the device.
+    auto launch_iteration = [&](int out) {
         if (diag) {
             run_diag_kernel(data, K, data->shift_dev.as<double>(), false);
         } else if (fused) {
@@ -1249,16 +1256,120 @@ void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* mean
         data->have_estep = true;
         data->lw_valid = !(diag || fused);
         allreduce_stats_dev(data, (size_t)K * F + 1);
-        const int nxt = cur ^ 1;
         CloseArgs ca{};
         ca.stats = data->stats_dev.as<double>(); ca.K = K; ca.d = d; ca.D = data->D;
         ca.shift = data->shift_dev.as<double>(); ca.n_global = (double)data->n_global;
         ca.layout = data->estep_variant; ca.refine_limit = limit;
-        ca.mixing = pack_mixing(nxt); ca.means = pack_means(nxt);
-        ca.covs = pack_covs(nxt); ca.records = data->params_next.as<double>();
-        ca.info = data->it_pack[nxt].as<double>();
+        ca.mixing = pack_mixing(out); ca.means = pack_means(out);
+        ca.covs = pack_covs(out); ca.records = data->params_next.as<double>();
+        ca.info = data->it_pack[out].as<double>();
         ctx->timed("em_close", [&] { if (diag) launch_em_close_diag(ca, ctx->stream); else launch_em_close(ca, ctx->stream); });
         HIP_CHECK(hipGetLastError());
+    };
+
+    // ---- lagged loop (small shapes: an iteration is tens of microseconds, of which the host's launches and its wait for the
+    // read-back are most). Iteration i + 1 is launched BEFORE the host looks at iteration i's log-likelihood: the convergence
+    // test of ML/EM.cpp:161-168 then fires one iteration late, and the speculative iteration is simply dropped -- three record
+    // buffers and three packs keep the inputs and outputs of iteration i intact while i + 1 runs, so the results are
+    // bit-identical to the synchronous loop. Not taken when the host has to decide something per iteration (FOLD form of the
+    // matrix-core E-step) or carries the all-reduce itself (host hooks); a refinement flag (far, tight component) rolls the
+    // loop back to the flagged iteration and hands over to the synchronous loop below. MLHIP_LAGGED=0: off.
+    static const bool lagged_allowed = [] { const char* e = std::getenv("MLHIP_LAGGED"); return !(e && e[0] == '0'); }();
+    const bool lagged = lagged_allowed && data->estep_variant != 2 && (!ctx->reduce_fn || ctx->reduce_on_device) && max_steps >= 2;
+    uint32_t first_sync_step = 0;
+    if (lagged) {
+        const size_t copy_doubles = diag ? n_pack : n_info;
+        for (int b = 0; b < 3; ++b) {
+            data->it_info_slot[b].reserve(sizeof(double) * n_pack);
+            if (!data->it_event[b]) HIP_CHECK(hipEventCreateWithFlags(&data->it_event[b], hipEventDisableTiming));
+        }
+        data->params_prev.reserve(data->params_dev.bytes);
+        data->params_next.reserve(data->params_dev.bytes);
+        std::vector<double> shadow_of[3];                        // diag: host copy of pack b's parameters (inputs of an E-step)
+        if (diag) {
+            // the neutral padding records must live in all three record buffers (params_next may just have been re-allocated)
+            upload_diag_records(data, K, mixing, means, covs, data->params_next);
+            upload_diag_records(data, K, mixing, means, covs, data->params_prev);
+            shadow_of[0].assign(mixing, mixing + K);
+            shadow_of[0].insert(shadow_of[0].end(), means, means + (size_t)K * d);
+            shadow_of[0].insert(shadow_of[0].end(), covs, covs + n_cov);
+        }
+        auto launch = [&](uint32_t i) {                          // iteration i: records R_i (params_dev) -> R_(i+1), pack (i+1) % 3
+            const int out = (int)((i + 1) % 3);
+            launch_iteration(out);
+            HIP_CHECK(hipMemcpyAsync(data->it_info_slot[out].p, data->it_pack[out].p, sizeof(double) * copy_doubles, hipMemcpyDeviceToHost,
+                                     ctx->stream));
+            HIP_CHECK(hipEventRecord(data->it_event[out], ctx->stream));
+            // rotate: params_dev <- R_(i+1), params_prev <- R_i, params_next <- the buffer of R_(i-1) (evaluated, free)
+            std::swap(data->params_prev, data->params_dev);      // prev = R_i, dev = old prev
+            std::swap(data->params_dev, data->params_next);      // dev = R_(i+1), next = old prev
+        };
+        launch(0);
+        uint32_t launched = 1;
+        bool handed_over = false, stopped = false;
+        uint32_t last = 0;
+        for (uint32_t i = 0; i < max_steps; ++i) {
+            if (i + 1 < max_steps) { launch(i + 1); launched = i + 2; }
+            const int slot = (int)((i + 1) % 3);
+            HIP_CHECK(hipEventSynchronize(data->it_event[slot]));
+            const double* inf = data->it_info_slot[slot].as<double>();
+            const double ll = inf[0] / (double)data->n_global - (double)d * log_two_pi() / 2;   // ML/EM.cpp:197-198, 211
+            bool flagged = false;
+            for (int k = 0; k < K; ++k) flagged = flagged || inf[1 + k] != 0.0;
+            if (diag) shadow_of[slot].assign(inf + n_info, inf + n_info + K + (size_t)K * d + n_cov);
+            last = i;
+            if (flagged) {
+                // roll back to the start of iteration i: records R_i into params_dev, parameters P_i into the caller's arrays
+                ctx->sync();
+                if (launched == i + 2) std::swap(data->params_dev, data->params_next);     // (next holds R_i after two rotations)
+                else std::swap(data->params_dev, data->params_prev);
+                if (i > 0) {
+                    const int in = (int)(i % 3);
+                    HIP_CHECK(hipMemcpyAsync(mixing, pack_mixing(in), sizeof(double) * K, hipMemcpyDeviceToHost, ctx->stream));
+                    HIP_CHECK(hipMemcpyAsync(means, pack_means(in), sizeof(double) * K * d, hipMemcpyDeviceToHost, ctx->stream));
+                    HIP_CHECK(hipMemcpyAsync(covs, pack_covs(in), sizeof(double) * n_cov, hipMemcpyDeviceToHost, ctx->stream));
+                    ctx->sync();
+                }
+                if (diag) {
+                    const std::vector<double>& sh = shadow_of[i % 3];
+                    data->diag_mixing.assign(sh.begin(), sh.begin() + K);
+                    data->diag_means.assign(sh.begin() + K, sh.begin() + K + (size_t)K * d);
+                    data->diag_vars.assign(sh.begin() + K + (size_t)K * d, sh.end());
+                    upload_diag_records(data, K, mixing, means, covs, data->params_next);   // (its neutral padding records)
+                }
+                first_sync_step = i;
+                handed_over = true;
+                break;
+            }
+            if (test(i, ll) || i + 1 == max_steps) { stopped = true; break; }
+        }
+        if (!handed_over) {
+            (void)stopped;
+            ctx->sync();                                         // a speculative iteration may still be running: let it finish
+            // device state as the synchronous loop leaves it: the records of the LAST evaluated E-step in params_dev; what the
+            // speculative iteration overwrote (log-responsibilities, lse) is rebuilt from them on demand
+            const bool speculated = launched == last + 2;
+            if (speculated) { std::swap(data->params_dev, data->params_next); data->lw_valid = false; }
+            else std::swap(data->params_dev, data->params_prev);
+            const int res = (int)((last + 1) % 3);               // P_(last+1): the newest parameters
+            HIP_CHECK(hipMemcpyAsync(mixing, pack_mixing(res), sizeof(double) * K, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_CHECK(hipMemcpyAsync(means, pack_means(res), sizeof(double) * K * d, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_CHECK(hipMemcpyAsync(covs, pack_covs(res), sizeof(double) * n_cov, hipMemcpyDeviceToHost, ctx->stream));
+            ctx->sync();
+            if (diag) {                                          // ensure_lw rebuilds the block from the inputs of the last E-step
+                const std::vector<double>& sh = shadow_of[last % 3];
+                data->diag_mixing.assign(sh.begin(), sh.begin() + K);
+                data->diag_means.assign(sh.begin() + K, sh.begin() + K + (size_t)K * d);
+                data->diag_vars.assign(sh.begin() + K + (size_t)K * d, sh.end());
+            }
+            return;
+        }
+    }
+
+    for (uint32_t step = first_sync_step; step < max_steps; ++step) {
+        PhaseTrace tr;
+        const int nxt = cur ^ 1;
+        launch_iteration(nxt);
         // one read-back: the info block and, in diagonal mode (small), a host shadow of the newest parameters right behind it
         // (ensure_lw needs the inputs of the last E-step)
         HIP_CHECK(hipMemcpyAsync(info, data->it_pack[nxt].p, sizeof(double) * (diag ? n_pack : n_info), hipMemcpyDeviceToHost, ctx->stream));

@@ -101,12 +101,13 @@ def test_iterate_equals_the_step_loop(ctx, oracle, d, K, n, diagonal):
     dt.close()
 
 
+@pytest.mark.parametrize("d", [12, 8, 4])     # 12: matrix-core E-step (synchronous loop); 8, 4: the lagged loop ROLLS BACK to the flagged iteration
 @pytest.mark.parametrize("diagonal", [False, True])
-def test_iterate_with_a_far_tight_cluster_takes_the_refinement_route(ctx, oracle, diagonal):
+def test_iterate_with_a_far_tight_cluster_takes_the_refinement_route(ctx, oracle, diagonal, d):
     """A component 1000 sigma away from the data mean is flagged by the device closing; that iteration is closed on the host
     with the refinement pass, and the loop goes on. Checked against the oracle's two-pass arithmetic."""
     from ml_amd import _lib
-    d, K, n = 12, 3, 24000
+    K, n = 3, 24000
     rng = np.random.default_rng(11)
     centres = np.array([[0.0] * d, [300.0] * d, [-200.0] * d])
     sig = np.array([1.0, 1e-3, 1e-2])
