@@ -17,7 +17,7 @@
 #include "ML/LinearRegression.hpp"
 #include "mlhip.h"
 
-extern "C" void mlhip_set_last_error_(const char* msg);   // defined in mlhip_abi.cpp
+extern "C" void mlhip_set_last_error_(const char* msg);   // defined in runtime/context.cpp
 
 using namespace ml;
 

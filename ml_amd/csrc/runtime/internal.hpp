@@ -1,0 +1,468 @@
+// Internal to the runtime (runtime/*.cpp): the context and data objects behind the C ABI of include/mlhip.h, error mapping,
+// and the functions the ABI entry points of the four families (context / data / EM / K-means) share. Not installed.
+#pragma once
+#include "mlhip.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types only: the library is dlopen'ed on first use (librccl is 570 MB; single-GPU users never pay for it)
+
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <initializer_list>
+#include <ctime>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "device/device.hpp"
+#include "host/em_math.hpp"
+
+namespace mlhip_rt {
+
+extern thread_local std::string g_error;   // context.cpp
+
+struct InvalidArgument : std::runtime_error { using std::runtime_error::runtime_error; };
+struct NoDevice : std::runtime_error { using std::runtime_error::runtime_error; };
+struct Unsupported : std::runtime_error { using std::runtime_error::runtime_error; };
+struct DomainError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#define HIP_CHECK(expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr);  \
+    } while (0)
+
+template <class F> int guarded(F&& f)
+{
+    try { f(); return MLHIP_OK; }
+    catch (const InvalidArgument& e) { g_error = e.what(); return MLHIP_E_INVALID_ARGUMENT; }
+    catch (const DomainError& e) { g_error = e.what(); return MLHIP_E_DOMAIN; }
+    catch (const NoDevice& e) { g_error = e.what(); return MLHIP_E_NO_DEVICE; }
+    catch (const Unsupported& e) { g_error = e.what(); return MLHIP_E_UNSUPPORTED; }
+    catch (const std::exception& e) { g_error = e.what(); return MLHIP_E_RUNTIME; }
+}
+
+/// Growable device buffer.
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    void reserve(size_t b)
+    {
+        if (b <= bytes) return;
+        if (p) HIP_CHECK(hipFree(p));
+        p = nullptr; bytes = 0;
+        HIP_CHECK(hipMalloc(&p, b));
+        bytes = b;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+struct PinnedBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    void reserve(size_t b)
+    {
+        if (b <= bytes) return;
+        if (p) HIP_CHECK(hipHostFree(p));
+        p = nullptr; bytes = 0;
+        HIP_CHECK(hipHostMalloc(&p, b, hipHostMallocDefault));
+        bytes = b;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct Timer {
+    double total_ms = 0;
+    uint64_t launches = 0;
+};
+
+/// RCCL entry points, resolved from librccl.so.1 the first time a communicator is asked for. A process that already
+/// holds an RCCL (e.g. the copy bundled with PyTorch-ROCm, same soname) gets that one back from dlopen.
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+
+    static Rccl& get()
+    {
+        static Rccl r = [] {
+            Rccl x;
+            const char* env = std::getenv("MLHIP_RCCL_LIBRARY");
+            const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+            for (const char* n : names) {
+                if (!n || !*n) continue;
+                x.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+                if (x.handle) break;
+            }
+            if (!x.handle) return x;
+            auto sym = [&](const char* name) { return dlsym(x.handle, name); };
+            x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(sym("ncclGetUniqueId"));
+            x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(sym("ncclCommInitRank"));
+            x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
+            x.CommCount = reinterpret_cast<decltype(x.CommCount)>(sym("ncclCommCount"));
+            x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(sym("ncclAllReduce"));
+            x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
+            x.GetVersion = reinterpret_cast<decltype(x.GetVersion)>(sym("ncclGetVersion"));
+            if (!(x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.CommCount && x.AllReduce && x.GetErrorString)) {
+                dlclose(x.handle);
+                x.handle = nullptr;
+            }
+            return x;
+        }();
+        if (!r.handle)
+            throw std::runtime_error("RCCL is not available: librccl.so.1 could not be loaded (set MLHIP_RCCL_LIBRARY)");
+        return r;
+    }
+    void check(ncclResult_t rc, const char* what) const
+    {
+        if (rc != ncclSuccess) throw std::runtime_error(std::string("RCCL error in ") + what + ": " + GetErrorString(rc));
+    }
+};
+
+}  // namespace mlhip_rt
+using namespace mlhip_rt;   // (internal header: the runtime's own translation units only)
+
+struct mlhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    // all-reduce hook
+    mlhip_allreduce_fn reduce_fn = nullptr;
+    void* reduce_user = nullptr;
+    int reduce_on_device = 0, world_size = 1, rank = 0;
+    ncclComm_t comm = nullptr;   // library-owned RCCL communicator (mlhip_ctx_init_rccl); its all-reduce is the hook then
+    // scratch
+    DevBuf small_dev;        // for all-reducing short host vectors through a device hook
+    PinnedBuf small_host;
+    DevBuf up_stage[2];      // upload staging (kept across uploads: pinned allocations are slow)
+    PinnedBuf up_pin[2];
+    // timing
+    bool timing = false;
+    typedef std::pair<hipEvent_t, hipEvent_t> EventPair;
+    std::vector<EventPair> spare_events;
+    std::vector<std::pair<const char*, EventPair>> pending;     // (names are string literals)
+    std::map<std::string, Timer> timers;
+
+    void use() const { HIP_CHECK(hipSetDevice(device)); }
+    void sync() const { HIP_CHECK(hipStreamSynchronize(stream)); }
+
+    /// Device time of a launch by a pair of HIP events on the stream the kernel goes to. The pair is only RECORDED here;
+    /// the elapsed times are read when somebody asks (resolve_timers), so a timed region runs as it does untimed: no
+    /// synchronisation between launches, the clocks the chip holds under a back-to-back stream of kernels.
+    template <class F> void timed(const char* name, F&& launch)
+    {
+        if (!timing) { launch(); return; }
+        if (pending.size() >= 4096) resolve_timers();
+        EventPair e;
+        if (!spare_events.empty()) { e = spare_events.back(); spare_events.pop_back(); }
+        else { HIP_CHECK(hipEventCreate(&e.first)); HIP_CHECK(hipEventCreate(&e.second)); }
+        HIP_CHECK(hipEventRecord(e.first, stream));
+        launch();
+        HIP_CHECK(hipEventRecord(e.second, stream));
+        pending.push_back({name, e});
+    }
+
+    void resolve_timers()
+    {
+        if (pending.empty()) return;
+        HIP_CHECK(hipEventSynchronize(pending.back().second.second));
+        for (auto& p : pending) {
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, p.second.first, p.second.second));
+            Timer& t = timers[p.first];
+            t.total_ms += ms;
+            t.launches += 1;
+            spare_events.push_back(p.second);
+        }
+        pending.clear();
+    }
+
+    /// The installed hook on a DEVICE buffer, on the context's stream. Timed as "allreduce" (event pair around the collective
+    /// on the stream: on a rank that arrives early this includes the wait for the slowest rank -- what a first multi-GPU run
+    /// needs to see).
+    void reduce_device(double* buf, size_t count)
+    {
+        int rc = 0;
+        timed("allreduce", [&] { rc = reduce_fn(reduce_user, buf, count, 1, stream); });
+        if (rc != 0) throw std::runtime_error("all-reduce hook failed");
+    }
+
+    /// End-of-fit guard of a row-sharded job: parameters are never broadcast -- every rank applies the same closing arithmetic
+    /// to the same all-reduced sums -- so ranks that received different sums (a collective that is not bitwise reproducible
+    /// across ranks, a rank on different data) would drift apart silently. Every rank puts a 48-bit checksum of its results
+    /// (three exactly representable 16-bit pieces) into its own slot of a zero vector, the vector is summed across ranks,
+    /// and every rank compares all slots. One small collective per fit. MLHIP_RANK_CHECK=0 disables.
+    void check_ranks_agree(const char* what, std::initializer_list<std::pair<const double*, size_t>> blocks)
+    {
+        if (!reduce_fn || world_size <= 1) return;
+        static const bool on = [] { const char* e = std::getenv("MLHIP_RANK_CHECK"); return !(e && e[0] == '0'); }();
+        if (!on) return;
+        uint64_t h = 1469598103934665603ull;                         // FNV-1a over the bytes of the blocks
+        for (const auto& b : blocks) {
+            const unsigned char* p = reinterpret_cast<const unsigned char*>(b.first);
+            for (size_t i = 0; i < b.second * sizeof(double); ++i) { h ^= p[i]; h *= 1099511628211ull; }
+        }
+        std::vector<double> v(3 * (size_t)world_size, 0.0);
+        for (int j = 0; j < 3; ++j) v[3 * (size_t)rank + j] = (double)((h >> (16 * j)) & 0xffffu);
+        allreduce_host(v.data(), v.size());
+        for (int r = 1; r < world_size; ++r)
+            for (int j = 0; j < 3; ++j)
+                if (v[3 * (size_t)r + j] != v[j])
+                    throw std::runtime_error(std::string("ranks disagree on ") + what + " at the end of the fit (rank " + std::to_string(r) +
+                                             " differs from rank 0): the statistics all-reduce did not give every rank the same sums");
+    }
+
+    /// Sum `count` host doubles across ranks (no-op single rank).
+    void allreduce_host(double* v, size_t count)
+    {
+        if (!reduce_fn) return;
+        if (reduce_on_device) {
+            small_dev.reserve(count * sizeof(double));
+            HIP_CHECK(hipMemcpyAsync(small_dev.p, v, count * sizeof(double), hipMemcpyHostToDevice, stream));
+            reduce_device(small_dev.as<double>(), count);
+            HIP_CHECK(hipMemcpyAsync(v, small_dev.p, count * sizeof(double), hipMemcpyDeviceToHost, stream));
+            sync();
+        } else {
+            if (reduce_fn(reduce_user, v, count, 0, stream) != 0) throw std::runtime_error("all-reduce hook failed");
+        }
+    }
+};
+
+struct mlhip_data {
+    mlhip_ctx* ctx = nullptr;
+    int d = 0, D = 0;
+    uint32_t n = 0, n_pad = 0;
+    uint64_t n_global = 0;
+    size_t ldx = 0;
+    DevBuf xt;                    // [D][ldx]
+    DevBuf shift_dev;             // d doubles
+    std::vector<double> shift;    // host copy
+    // EM workspace (sized for em_K)
+    int em_K = 0;
+    size_t ldr = 0;
+    DevBuf lw, lse, esum, ll_partials, params_dev, partials, stats_dev, resp_dev, labels_dev;
+    PinnedBuf params_host, stats_host;
+    int n_ll = 0;
+    bool have_estep = false;
+    bool lw_valid = false;        // false after a fused step: lw is rebuilt from params_dev on demand (ensure_lw)
+    int estep_variant = 0;        // record layout currently in params_dev: 0 = valu, 1 = mfma16, 2 = mfma4
+    bool estep_fold = false;      // mfma4 records in FOLD form (vector slot = -W (mu - shift)): layout.hpp kEstepFoldLimit
+    // diagonal-covariance extension: parameters of the last mlhip_em_step_diag (the N x K block is rebuilt from them on demand)
+    bool diag_step = false;
+    std::vector<double> diag_mixing, diag_means, diag_vars;
+    // mlhip_em_iterate: parameters and the next E-step's records stay on the device between iterations
+    DevBuf params_next, it_pack[3];      // it_pack: [info (1 + 2K) | mixing (K) | means (K d) | covariances], one D2H covers it
+    PinnedBuf it_info_host;
+    // ... and, for the lagged (speculative) loop of small shapes: a third record buffer, one read-back slot and event per pack
+    DevBuf params_prev;
+    PinnedBuf it_info_slot[3];
+    hipEvent_t it_event[3] = {nullptr, nullptr, nullptr};
+    // source of the last statistics pass (for the per-component refinement pass)
+    int stats_mode = 0;
+    const double* stats_resp = nullptr;
+    size_t stats_ld = 0;
+    DevBuf refine_shift, refine_stats;
+    uint64_t refined_components = 0;   // diagnostic counter
+    // K-means workspace
+    DevBuf km_labels[2], km_cent, km_cent_next, km_partials, km_out, km_mind, km_probe, km_scale, km_cnorm, km_xt_pad;
+    PinnedBuf km_host;
+    int km_cur = 0;
+    bool km_have_old = false;
+
+    ~mlhip_data()
+    {
+        for (DevBuf* b : {&xt, &shift_dev, &lw, &lse, &esum, &ll_partials, &params_dev, &partials, &stats_dev, &resp_dev,
+                          &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_cent_next, &km_partials, &km_out, &km_mind, &km_probe, &km_scale, &km_cnorm, &km_xt_pad,
+                          &refine_shift, &refine_stats, &params_next, &params_prev, &it_pack[0], &it_pack[1], &it_pack[2]})
+            b->release();
+        it_info_host.release();
+        for (auto& sl : it_info_slot) sl.release();
+        for (auto& e : it_event) if (e) (void)hipEventDestroy(e);
+        params_host.release(); stats_host.release(); km_host.release();
+    }
+};
+
+namespace mlhip_rt {
+
+using namespace mlhip;
+
+
+constexpr int kMaxLlPartials = 2048;
+
+/// MLHIP_TRACE=1: wall-clock microseconds of the host-visible phases of one EM iteration on stderr.
+struct PhaseTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    PhaseTrace() : on([] { const char* e = std::getenv("MLHIP_TRACE"); return e && e[0] == '1'; }()), t(std::chrono::steady_clock::now()) {}
+    void mark(const char* name)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[mlhip] %-22s %8.1f us\n", name, std::chrono::duration<double, std::micro>(now - t).count());
+        t = now;
+    }
+};
+
+inline void require(bool ok, const char* msg) { if (!ok) throw InvalidArgument(msg); }
+
+/// What one K-means pass runs on: the data block (a zero-padded copy where the matrix-core kernel needs one) and its rows.
+struct KmBlock {
+    const double* xt;
+    int D;
+};
+
+// ---- shared between the families (definitions: context.cpp, data.cpp, em.cpp, kmeans.cpp) ----
+
+int env_int(const char* name, int fallback);
+
+/// memcpy split over a few threads: one core moves ~10 GB/s (less into untouched pages), below the PCIe rate it feeds.
+void copy_bytes(void* dst, const void* src, size_t bytes);
+
+void finish_upload(mlhip_data* dt);
+
+mlhip_data* upload_common(mlhip_ctx* ctx, const double* x, bool on_device, uint32_t d, uint64_t n, int64_t ld);
+
+/// Device -> pageable host copy of `cols` columns of `col_bytes` bytes each (source / destination pitches given), staged through
+/// the context's two pinned buffers: the CPU unpacks chunk i while the DMA engine fetches chunk i+1. A direct copy into
+/// pageable memory runs at ~3 GB/s on this platform; this one at PCIe rate.
+void download_columns(mlhip_ctx* ctx, char* dst, size_t dst_pitch, const char* src, size_t src_pitch, size_t col_bytes, size_t cols);
+
+void ensure_em_workspace(mlhip_data* dt, int K);
+
+/// Builds the per-component records for the E-step kernel that fits (d, env) and uploads them to params_dev.
+void prepare_estep(mlhip_data* dt, int K, const double* mixing, const double* means, const double* covs, DevBuf* target = nullptr);
+
+/// E-step kernel on the records in params_dev: fills lw and -- unless the statistics kernel is going to normalise the
+/// log-responsibilities itself (`with_lse` false, matrix-core kernel only) -- lse and the log-likelihood partials.
+void launch_estep(mlhip_data* dt, int K, bool with_lse = true);
+
+void run_estep(mlhip_data* dt, int K, const double* mixing, const double* means, const double* covs, bool with_lse = true);
+
+/// After a fused step only lse exists on the device; whoever needs the log-responsibility block (labels,
+/// responsibilities, a separate M-step, the refinement pass) gets it rebuilt from the same parameter records.
+void ensure_lw(mlhip_data* dt, int K);
+
+/// All-reduces the reduced statistics buffer [K*F stats, ll_sum] and leaves it in stats_host.
+void collect_stats(mlhip_data* dt, int K, size_t count = 0);
+
+/// One EM iteration's device work in a single kernel where the shape allows (d <= 6, K <= 32 or d <= 4, K <= 64: em_fused_small.hip): no
+/// N x K block in HBM. MLHIP_FUSED=0 keeps the two-kernel path. Returns false when the shape is not covered.
+bool fused_step_applies(const mlhip_data* dt, int K);
+
+/// The fused kernel + reduction on the records already in params_dev; statistics end in stats_dev (and, with `collect`, all-
+/// reduced in stats_host).
+void launch_fused_step(mlhip_data* dt, int K, bool collect);
+
+bool run_fused_step(mlhip_data* dt, int K, const double* mixing, const double* means, const double* covs);
+
+/// Runs the statistics kernel on log-responsibilities (mode kFromLogResp: the E-step's lw/lse) or on plain
+/// responsibilities `resp_dev` ([K][ld_resp], ld_resp >= n_pad), all-reduces, leaves [K*F stats, ll_sum] in stats_host.
+void run_mstats(mlhip_data* dt, int K, int mode, const double* resp_dev, size_t ld_resp, bool with_ll, bool collect = true);
+
+double log_two_pi();
+
+double ll_from_stats(const mlhip_data* dt, int K);
+
+void check_em_args(mlhip_ctx* ctx, mlhip_data* dt, uint32_t K);
+
+/// Ratio (mean offset from the shared shift)^2 / variance above which a component's covariance is recomputed about its
+/// own mean. The one-GEMM statistics share one shift (the global mean), so Sigma_k = M2'/S0 - m m^T cancels
+/// ~log10(ratio) digits: measured relative error ~3e-15 * ratio. 1e4 keeps every covariance within ~3e-11 of the
+/// two-pass form the reference uses (ML/EM.cpp:245-250). MLHIP_REFINE_RATIO overrides; <= 0 disables the refinement.
+double refine_ratio();
+
+/// Second statistics pass for ONE component with the shift at that component's new mean (K = 1 launch of the same
+/// kernels on column k of the responsibilities of the last pass), all-reduced like the first; replaces covariance k
+/// (and adds the tiny mean correction). Tight clusters far from the global mean need it; the headline shapes never do.
+void refine_component(mlhip_data* dt, int k, double* mean_k, double* cov_k);
+
+void finalize_out(mlhip_data* dt, int K, double* mixing_out, double* means_out, double* cov_out);
+
+/// One diagonal-covariance EM iteration's device work (em_diag.hip) with the statistics shift at `shift_dev`; leaves the
+/// all-reduced [K * (2d+1) statistics, ll_sum] in stats_host. The records must already be in params_dev.
+void run_diag_kernel(mlhip_data* dt, int K, const double* shift_dev, bool collect = true);
+
+void ensure_km_workspace(mlhip_data* dt, int K);
+
+KmBlock km_block(mlhip_data* dt, int K);
+
+/// Host centroids [K][d] -> the device table km_cent [K][D] (padded coordinates zero).
+void km_upload_centroids(mlhip_data* dt, int K, const KmBlock& b, const double* centroids);
+
+/// Assignment (+ optional accumulation) against the table in km_cent, partials reduced into km_out =
+/// [inertia, changed, counts, sums] and summed across ranks there when the all-reduce works on device memory.
+void km_launch(mlhip_data* dt, int K, const KmBlock& b, bool accumulate, double* min_dist_out);
+
+/// km_out -> km_host (`count` doubles), summed across ranks on the host when the all-reduce works on host memory.
+void km_fetch(mlhip_data* dt, size_t count);
+
+/// Assignment (+ optional accumulation); leaves all-reduced [inertia, changed, counts, sums] in km_host.
+void run_kmeans(mlhip_data* dt, int K, const double* centroids, bool accumulate, double* min_dist_out = nullptr);
+
+/// update_step's closing arithmetic on the host (ML/KMeans.cpp:180-192 as sums / counts; empty cluster -> origin, :184).
+void km_close_host(const double* r, int K, int d, double* counts, double* centroids_out);
+
+/// The step loop of KMeans::fit_once (ML/KMeans.cpp:80-110). With the all-reduce on device memory (or none) the centroid
+/// table never leaves the device between trips: sums -> means -> next table by launch_kmeans_close, one read-back per trip
+/// for the two stopping tests. With a host-memory all-reduce (gloo rehearsals) every trip goes through run_kmeans.
+void km_iterate(mlhip_data* dt, int K, double* centroids, double* old_centroids, uint32_t max_steps, double atol,
+                uint32_t* steps_done, int* converged, double* inertia, double* counts);
+
+/// K within one row-block group of the wide statistics kernel: the matrix-core E-step writes the log-responsibilities only and
+/// the statistics kernel normalises them (one exp per pair in the iteration); otherwise the E-step keeps its online
+/// log-sum-exp. MLHIP_SELF_NORM=0 forces the latter (A/B runs).
+bool self_norm_applies(const mlhip_data* dt, int K);
+
+/// One full-covariance EM iteration with the closing arithmetic on the HOST (the body of mlhip_em_step).
+void em_step_full(mlhip_data* data, int K, const double* mixing, const double* means, const double* covariances,
+                  double* log_likelihood, double* mixing_out, double* means_out, double* covariances_out);
+
+/// Sums `count` doubles at the head of stats_dev across ranks, whatever kind of hook is installed (device buffer on the
+/// stream, or a host buffer: down, hook, up). No-op on a single rank.
+void allreduce_stats_dev(mlhip_data* dt, size_t count);
+
+/// Records of a diagonal-covariance parameter set -> `target` (padded to whole 16-component row blocks with neutral records).
+void upload_diag_records(mlhip_data* data, int K, const double* mixing, const double* means, const double* variances, DevBuf& target);
+
+/// Same cancellation guard as the full-covariance path (refine_ratio): a component whose mean sits far from the shared shift,
+/// measured in its own standard deviations, gets its variances from a second pass with the shift at its new mean (the E part of
+/// that pass re-evaluates the SAME input parameters, still in params_dev).
+void refine_diag(mlhip_data* data, int K, const double* mixing_out, double* means_out, double* variances_out);
+
+void em_step_diag(mlhip_data* data, int K, const double* mixing, const double* means, const double* variances,
+                  double* log_likelihood, double* mixing_out, double* means_out, double* variances_out);
+
+/// The loop of EM::fit (ML/EM.cpp:143-170) with everything between two convergence tests on the device: E-step, statistics,
+/// all-reduce, closing arithmetic + next records (em_close.hip); per iteration the host reads back 1 + 2K doubles (log-
+/// likelihood sum, refinement flags, FOLD criterion) and decides. A flagged component (far, tight cluster) sends that one
+/// iteration through the host closing with its refinement pass, exactly as mlhip_em_step would. MLHIP_DEVICE_CLOSE=0, or
+/// d > 64, runs the whole loop through the per-step functions.
+void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* means, double* covs, uint32_t max_steps, double atol,
+                double rtol, uint32_t* steps_done, int* converged, double* log_likelihood, double* history);
+
+/// The all-reduce hook of a context that owns an RCCL communicator: one ncclAllReduce(double, sum), in place, on the
+/// context's stream -- ordered with the kernels before it and the copies after it, no host synchronisation.
+int rccl_allreduce_hook(void* user, double* buf, size_t count, int on_device, void* stream);
+
+void drop_rccl(mlhip_ctx* ctx);
+
+void init_rccl(mlhip_ctx* ctx, const ncclUniqueId& id, int world_size, int rank);
+
+}  // namespace mlhip_rt

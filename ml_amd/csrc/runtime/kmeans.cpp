@@ -1,0 +1,311 @@
+// K-means family of the C ABI: assignment + exact update sums per step, the step loop of KMeans::fit_once in one call.
+#include "internal.hpp"
+
+namespace mlhip_rt {
+
+
+void ensure_km_workspace(mlhip_data* dt, int K)
+{
+    mlhip_ctx* ctx = dt->ctx;
+    for (int b = 0; b < 2; ++b) dt->km_labels[b].reserve(sizeof(uint32_t) * dt->n_pad);
+    dt->km_mind.reserve(sizeof(double) * dt->n_pad);
+    if (!dt->km_scale.p) {
+        // Per-dimension power-of-two scale of the exact fixed-point sums: |x_j| * scale_j < 2^94 (device/kmeans.hip).
+        DevBuf scratch, mx;
+        scratch.reserve(sizeof(double) * 1024 * dt->d);
+        mx.reserve(sizeof(double) * dt->d);
+        launch_column_maxabs(dt->xt.as<double>(), dt->ldx, dt->d, dt->n, scratch.as<double>(), mx.as<double>(), ctx->stream);
+        std::vector<double> m(dt->d);
+        HIP_CHECK(hipMemcpyAsync(m.data(), mx.p, sizeof(double) * dt->d, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->sync();
+        scratch.release(); mx.release();
+        // Every rank must cut its coordinates on the SAME fixed-point grid (the limb sums are added across ranks): the
+        // column maxima are exchanged through the sum hook, one slot per rank, and every rank takes the maximum.
+        if (ctx->world_size > 1) {
+            std::vector<double> all((size_t)ctx->world_size * dt->d, 0.0);
+            for (int j = 0; j < dt->d; ++j) all[(size_t)ctx->rank * dt->d + j] = m[j];
+            ctx->allreduce_host(all.data(), all.size());
+            for (int r = 0; r < ctx->world_size; ++r)
+                for (int j = 0; j < dt->d; ++j) {
+                    const double v = all[(size_t)r * dt->d + j];
+                    if (!(v <= m[j])) m[j] = v;                            // (keeps a NaN / inf of any rank)
+                }
+        }
+        for (int j = 0; j < dt->d; ++j) {
+            if (!std::isfinite(m[j]))
+                throw DomainError("K-means: the data contain non-finite values (the exact fixed-point update sums need finite coordinates)");
+            int e = 0;
+            if (m[j] > 0) (void)std::frexp(m[j], &e);   // m < 2^e
+            m[j] = std::ldexp(1.0, 94 - e);
+        }
+        dt->km_scale.reserve(sizeof(double) * dt->d);
+        HIP_CHECK(hipMemcpyAsync(dt->km_scale.p, m.data(), sizeof(double) * dt->d, hipMemcpyHostToDevice, ctx->stream));
+        ctx->sync();
+    }
+    const int Dp = (dt->D + 3) & ~3;                              // (the K-means kernels may run on a zero-padded copy)
+    dt->km_cent.reserve(sizeof(double) * (size_t)K * Dp);
+    dt->km_cnorm.reserve(sizeof(double) * (size_t)((K + 15) & ~15));
+    dt->km_partials.reserve(sizeof(double) * kmeans_scratch_doubles(dt->d, K, ctx->num_cus));
+    const size_t ob = sizeof(double) * (2 + (size_t)K * (dt->d + 1));
+    dt->km_out.reserve(ob);
+    const size_t hb = ob > sizeof(double) * (size_t)K * Dp ? ob : sizeof(double) * (size_t)K * Dp;
+    dt->km_host.reserve(hb);
+}
+
+
+KmBlock km_block(mlhip_data* dt, int K)
+{
+    mlhip_ctx* ctx = dt->ctx;
+    ensure_km_workspace(dt, K);
+    // The matrix-core kernel needs a multiple of 4 dimensions. For d = 1, 2, 3, 5, 6 (stored with D = d or 6 rows) and many
+    // clusters it still beats the direct-form kernel (d = 6, K = 256: 1.9 -> 1.2 ms at N = 10M), so such blocks get a copy
+    // padded with zero rows once: zero coordinates add exactly 0 to every distance, labels and sums are unchanged.
+    KmBlock b{dt->xt.as<double>(), dt->D};
+    if (b.D % 4 != 0 && K >= 128 && !std::getenv("MLHIP_KMEANS")) {
+        const int Dp = (b.D + 3) & ~3;
+        if (!dt->km_xt_pad.p) {
+            dt->km_xt_pad.reserve(sizeof(double) * dt->ldx * Dp);
+            HIP_CHECK(hipMemsetAsync(dt->km_xt_pad.p, 0, sizeof(double) * dt->ldx * Dp, ctx->stream));
+            HIP_CHECK(hipMemcpyAsync(dt->km_xt_pad.p, dt->xt.p, sizeof(double) * dt->ldx * b.D, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        b.D = Dp;
+        b.xt = dt->km_xt_pad.as<double>();
+    }
+    return b;
+}
+
+
+/// Host centroids [K][d] -> the device table km_cent [K][D] (padded coordinates zero).
+void km_upload_centroids(mlhip_data* dt, int K, const KmBlock& b, const double* centroids)
+{
+    mlhip_ctx* ctx = dt->ctx;
+    double* ch = dt->km_host.as<double>();
+    for (int k = 0; k < K; ++k)
+        for (int j = 0; j < b.D; ++j) ch[(size_t)k * b.D + j] = j < dt->d ? centroids[(size_t)k * dt->d + j] : 0.0;
+    HIP_CHECK(hipMemcpyAsync(dt->km_cent.p, ch, sizeof(double) * (size_t)K * b.D, hipMemcpyHostToDevice, ctx->stream));
+    ctx->sync();   // km_host is reused for the results
+}
+
+
+/// Assignment (+ optional accumulation) against the table in km_cent, partials reduced into km_out =
+/// [inertia, changed, counts, sums] and summed across ranks there when the all-reduce works on device memory.
+void km_launch(mlhip_data* dt, int K, const KmBlock& b, bool accumulate, double* min_dist_out)
+{
+    mlhip_ctx* ctx = dt->ctx;
+    const int nxt = dt->km_cur ^ 1;
+    KmeansArgs a{};
+    a.xt = b.xt; a.ldx = dt->ldx; a.n = dt->n; a.D = b.D; a.d = dt->d;
+    a.centroids = dt->km_cent.as<double>(); a.K = K;
+    a.scale = dt->km_scale.as<double>();
+    a.labels = dt->km_labels[nxt].as<uint32_t>();
+    a.old_labels = dt->km_labels[dt->km_cur].as<uint32_t>();
+    a.have_old = dt->km_have_old ? 1 : 0;
+    a.min_dist = min_dist_out ? min_dist_out : dt->km_mind.as<double>();   // a distance-only probe writes elsewhere
+    a.accumulate = accumulate ? 1 : 0;
+    a.partials = dt->km_partials.as<double>(); a.partials_capacity = dt->km_partials.bytes / sizeof(double);
+    a.cnorm = dt->km_cnorm.as<double>();
+    a.out = dt->km_out.as<double>();
+    int rc = 0;
+    ctx->timed("kmeans_assign", [&] { rc = launch_kmeans_assign(a, ctx->num_cus, ctx->stream); });
+    if (rc == -1) throw Unsupported("K-means kernel not instantiated for this dimension");
+    if (rc <= 0) throw std::runtime_error("K-means kernel launch failed");
+    launch_kmeans_reduce(a, rc, ctx->stream);
+    HIP_CHECK(hipGetLastError());
+    dt->km_cur = nxt;
+    dt->km_have_old = true;
+    if (ctx->reduce_fn && ctx->reduce_on_device) {
+        const size_t count = 2 + (accumulate ? (size_t)K * (dt->d + 1) : 0);
+        ctx->reduce_device(dt->km_out.as<double>(), count);
+    }
+}
+
+
+/// km_out -> km_host (`count` doubles), summed across ranks on the host when the all-reduce works on host memory.
+void km_fetch(mlhip_data* dt, size_t count)
+{
+    mlhip_ctx* ctx = dt->ctx;
+    double* ch = dt->km_host.as<double>();
+    HIP_CHECK(hipMemcpyAsync(ch, dt->km_out.p, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+    if (ctx->reduce_fn && !ctx->reduce_on_device) {
+        if (ctx->reduce_fn(ctx->reduce_user, ch, count, 0, ctx->stream) != 0) throw std::runtime_error("all-reduce hook failed");
+    }
+}
+
+
+/// Assignment (+ optional accumulation); leaves all-reduced [inertia, changed, counts, sums] in km_host.
+void run_kmeans(mlhip_data* dt, int K, const double* centroids, bool accumulate, double* min_dist_out)
+{
+    const KmBlock b = km_block(dt, K);
+    km_upload_centroids(dt, K, b, centroids);
+    km_launch(dt, K, b, accumulate, min_dist_out);
+    km_fetch(dt, 2 + (accumulate ? (size_t)K * (dt->d + 1) : 0));
+}
+
+
+/// update_step's closing arithmetic on the host (ML/KMeans.cpp:180-192 as sums / counts; empty cluster -> origin, :184).
+void km_close_host(const double* r, int K, int d, double* counts, double* centroids_out)
+{
+    for (int k = 0; k < K; ++k) {
+        const double c = r[2 + k];
+        if (counts) counts[k] = c;
+        for (int j = 0; j < d; ++j) centroids_out[(size_t)k * d + j] = c > 0 ? r[2 + K + (size_t)k * d + j] / c : 0.0;
+    }
+}
+
+
+/// The step loop of KMeans::fit_once (ML/KMeans.cpp:80-110). With the all-reduce on device memory (or none) the centroid
+/// table never leaves the device between trips: sums -> means -> next table by launch_kmeans_close, one read-back per trip
+/// for the two stopping tests. With a host-memory all-reduce (gloo rehearsals) every trip goes through run_kmeans.
+void km_iterate(mlhip_data* dt, int K, double* centroids, double* old_centroids, uint32_t max_steps, double atol,
+                uint32_t* steps_done, int* converged, double* inertia, double* counts)
+{
+    mlhip_ctx* ctx = dt->ctx;
+    const int d = dt->d;
+    const size_t kd = (size_t)K * d;
+    const bool device_route = !(ctx->reduce_fn && !ctx->reduce_on_device) && !std::getenv("MLHIP_KMEANS_HOST_LOOP");
+    const KmBlock b = km_block(dt, K);
+    std::vector<double> cur(centroids, centroids + kd), old(kd, 0.0), upd(kd);
+    if (device_route) {
+        dt->km_cent_next.reserve(sizeof(double) * (size_t)K * b.D);
+        km_upload_centroids(dt, K, b, cur.data());
+    }
+    *converged = 0;
+    *steps_done = 0;
+    for (uint32_t step = 0; step < max_steps; ++step) {
+        if (device_route) {
+            km_launch(dt, K, b, true, nullptr);
+            launch_kmeans_close(dt->km_out.as<double>(), K, d, b.D, dt->km_cent_next.as<double>(), ctx->stream);
+            km_fetch(dt, 2 + (size_t)K * (d + 1));
+            const double* r = dt->km_host.as<double>();
+            if (counts) std::copy(r + 2, r + 2 + K, counts);
+            std::copy(r + 2 + K, r + 2 + K + kd, upd.begin());
+        } else {
+            run_kmeans(dt, K, cur.data(), true);
+            km_close_host(dt->km_host.as<double>(), K, d, counts, upd.data());
+        }
+        const double* r = dt->km_host.as<double>();
+        *inertia = r[0];
+        const uint64_t changed = (uint64_t)std::llround(r[1]);
+        ++*steps_done;
+        if (step > 0 && changed == 0) {   // same labels twice (:84-89): the centroids stay as they are
+            *converged = 1;
+            break;
+        }
+        old.swap(cur);                    // update_step (:180-192)
+        cur.swap(upd);
+        if (device_route) std::swap(dt->km_cent, dt->km_cent_next);
+        if (step > 0) {
+            double shift = 0;
+            for (size_t t = 0; t < kd; ++t) {
+                const double delta = cur[t] - old[t];
+                shift += delta * delta;
+            }
+            if (shift < atol) {           // (:103-108) one more assignment under the final centroids
+                if (device_route) {
+                    km_launch(dt, K, b, false, nullptr);
+                    km_fetch(dt, 2);
+                } else {
+                    run_kmeans(dt, K, cur.data(), false);
+                }
+                *inertia = dt->km_host.as<double>()[0];
+                *converged = 1;
+                break;
+            }
+        }
+    }
+    std::copy(cur.begin(), cur.end(), centroids);
+    if (old_centroids) std::copy(old.begin(), old.end(), old_centroids);
+}
+
+}  // namespace mlhip_rt
+
+extern "C" {
+
+
+int mlhip_kmeans_step(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* centroids, double* inertia,
+                      uint64_t* n_changed, double* counts, double* centroids_out)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, K);
+        require(centroids && inertia && n_changed && counts && centroids_out, "null argument");
+        run_kmeans(data, (int)K, centroids, true);
+        const double* r = data->km_host.as<double>();
+        *inertia = r[0];
+        *n_changed = (uint64_t)std::llround(r[1]);
+        km_close_host(r, (int)K, data->d, counts, centroids_out);
+    });
+}
+
+int mlhip_kmeans_iterate(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, double* centroids, double* old_centroids,
+                         uint32_t max_steps, double absolute_tolerance, uint32_t* steps_done, int* converged,
+                         double* inertia, double* counts)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, K);
+        require(centroids && steps_done && converged && inertia, "null argument");
+        require(max_steps >= 1, "at least one step");
+        require(absolute_tolerance >= 0, "negative tolerance");
+        km_iterate(data, (int)K, centroids, old_centroids, max_steps, absolute_tolerance, steps_done, converged, inertia, counts);
+        ctx->check_ranks_agree("the K-means centroids", {{centroids, (size_t)K * data->d}, {inertia, 1}});
+    });
+}
+
+int mlhip_kmeans_assign(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* centroids, double* inertia,
+                        uint64_t* n_changed)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, K);
+        require(centroids && inertia && n_changed, "null argument");
+        run_kmeans(data, (int)K, centroids, false);
+        const double* r = data->km_host.as<double>();
+        *inertia = r[0];
+        *n_changed = (uint64_t)std::llround(r[1]);
+    });
+}
+
+int mlhip_kmeans_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t* labels)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, 1);
+        require(labels || data->n == 0, "null argument");
+        require(data->km_have_old, "no K-means assignment on the device yet");
+        ctx->sync();
+        download_columns(ctx, reinterpret_cast<char*>(labels), 0, data->km_labels[data->km_cur].as<char>(), 0,
+                         sizeof(uint32_t) * data->n, 1);
+    });
+}
+
+int mlhip_kmeans_distances(mlhip_ctx* ctx, mlhip_data* data, double* dist2)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, 1);
+        require(dist2 || data->n == 0, "null argument");
+        require(data->km_have_old, "no K-means assignment on the device yet");
+        ctx->sync();
+        download_columns(ctx, reinterpret_cast<char*>(dist2), 0, data->km_mind.as<char>(), 0, sizeof(double) * data->n, 1);
+    });
+}
+
+int mlhip_min_squared_distances(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* centroids, double* dist2)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, K);
+        require(centroids && (dist2 || data->n == 0), "null argument");
+        // Must disturb neither the label history used for n_changed nor the per-sample distances of the last assignment
+        // (mlhip_kmeans_distances): the labels go to the spare buffer, the distances to a buffer of their own.
+        const int cur = data->km_cur;
+        const bool have = data->km_have_old;
+        data->km_probe.reserve(sizeof(double) * data->n_pad);
+        run_kmeans(data, (int)K, centroids, false, data->km_probe.as<double>());
+        if (have) {
+            // The assignment wrote labels into the *other* buffer; keep the previous labels current.
+            data->km_cur = cur;
+        }
+        data->km_have_old = have;
+        ctx->sync();
+        download_columns(ctx, reinterpret_cast<char*>(dist2), 0, data->km_probe.as<char>(), 0, sizeof(double) * data->n, 1);
+    });
+}
+
+}  // extern "C"
