@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64 * NW, D <= 32 ? 8 / SB : 2) void em_estep_mfma4_
 
     // The waves of a workgroup walk the components in lockstep (they share the staged record), each on its own
     // GS-sample group: a workgroup iteration covers NWV consecutive groups = 256 samples (n_pad is a multiple of 256).
-    for (uint32_t grp = blockIdx.x * NWV + wave; grp < n_groups; grp += gridDim.x * NWV) {
+    auto process = [&](uint32_t grp, int k_begin, int k_end) {
         const uint32_t base = grp * GS;
         // coordinates in B-operand layout: xb[C][sb] = x[dim 4C + g][sample base + 16sb + s]
         double xb[Q][SB];
@@ -124,19 +124,19 @@ __global__ __launch_bounds__(64 * NW, D <= 32 ? 8 / SB : 2) void em_estep_mfma4_
 
         double m = -__builtin_inf(), ssum = 0.0;
 
-        // record 0 -> LDS buffer 0 (the barrier at the top of the component loop publishes it)
+        // first record -> its LDS buffer (the barrier at the top of the component loop publishes it)
         double stage[NLD];
 #pragma unroll
-        for (int it = 0; it < NLD; ++it) stage[it] = params[min(tid + NT * it, PS - 1)];
+        for (int it = 0; it < NLD; ++it) stage[it] = params[(size_t)k_begin * PS + min(tid + NT * it, PS - 1)];
         __syncthreads();                            // everyone is done with the previous group's last record
 #pragma unroll
-        for (int it = 0; it < NLD; ++it) recs[0][tid + NT * it] = stage[it];
+        for (int it = 0; it < NLD; ++it) recs[k_begin & 1][tid + NT * it] = stage[it];
 
-        for (int k = 0; k < K; ++k) {
+        for (int k = k_begin; k < k_end; ++k) {
             const double* __restrict__ rec = recs[k & 1];
             __syncthreads();                        // record k visible; every wave has finished component k-1
             // record k+1: global -> registers now (in flight during the MFMA phase), registers -> LDS at the end
-            const double* __restrict__ nxt = params + (size_t)(k + 1 < K ? k + 1 : k) * PS;
+            const double* __restrict__ nxt = params + (size_t)(k + 1 < k_end ? k + 1 : k) * PS;
 #pragma unroll
             for (int it = 0; it < NLD; ++it) stage[it] = nxt[min(tid + NT * it, PS - 1)];
 
@@ -226,6 +226,23 @@ __global__ __launch_bounds__(64 * NW, D <= 32 ? 8 / SB : 2) void em_estep_mfma4_
                 lse_out[base + lane] = lse;
                 if (base + lane < n) ll_acc += lse;
             }
+        }
+    };
+    // Whole tiles (NWV consecutive groups = 256 samples, all K components) round after round; what is left for the last, partial
+    // round is cut into (tile, component range) units when the log-sum-exp is formed elsewhere (!LSE: the components of a sample
+    // are then independent here): with R < gridDim tiles left, R kTailChunks units of K / kTailChunks components fill the
+    // workgroups evenly instead of leaving gridDim - R of them idle for a whole tile (one 8-GPU shard of the headline: 4 883
+    // tiles over 512 workgroups = 9.54 rounds, 10 without the split, 9.63 with it).
+    constexpr int kTailChunks = 8;
+    const uint32_t n_tiles = n_groups / NWV;                       // (n_pad is a multiple of the workgroup's sweep)
+    const bool split_tail = !LSE && K >= 2 * kTailChunks;
+    const uint32_t full_tiles = split_tail ? n_tiles / gridDim.x * gridDim.x : n_tiles;
+    for (uint32_t tile = blockIdx.x; tile < full_tiles; tile += gridDim.x) process(tile * NWV + wave, 0, K);
+    if (split_tail) {
+        const uint32_t units = (n_tiles - full_tiles) * kTailChunks;
+        for (uint32_t u = blockIdx.x; u < units; u += gridDim.x) {
+            const int c = (int)(u % kTailChunks);
+            process((full_tiles + u / kTailChunks) * NWV + wave, c * K / kTailChunks, (c + 1) * K / kTailChunks);
         }
     }
     if constexpr (LSE) {
