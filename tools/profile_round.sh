@@ -27,6 +27,10 @@ done
 python3 "$R/bench.py" --workload kmeans --steps 10 --warmup 2 > "$O/${TAG}_kmeans_bench.json" 2> "$O/${TAG}_kmeans_bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_kmstats" -- python3 "$R/bench.py" --workload kmeans --steps 5 --warmup 1 --no-cpu-baseline > "$O/${TAG}_kmstats.txt" 2>&1
 find "$O/${TAG}_kmstats" -name '*kernel_stats.csv' -exec cp {} "$O/${TAG}_kmeans_kernel_stats.csv" \;
+# SQ counters of the K-means scoring kernel at one GPU's share of config E (the `secondary[0]` shape)
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU --output-format csv -d "$O/${TAG}_kmpmc" -- python3 "$R/bench.py" --workload kmeans --samples 12500000 --steps 3 --warmup 1 --no-cpu-baseline > "$O/${TAG}_kmpmc.txt" 2>&1
+find "$O/${TAG}_kmpmc" -name '*counter_collection.csv' -exec cp {} "$O/${TAG}_kmeans_pmc_sq.csv" \;
+rm -rf "$O/${TAG}_kmpmc"
 echo "[profile] kmeans done"
 rm -rf "$O/${TAG}_kmstats"
 # third workload: diagonal-covariance EM (BASELINE.json configs[1]): bench line + kernel trace

@@ -4,7 +4,7 @@ TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/${TAG}_shapes.jsonl
 : > "$O"
-for cfg in "10000000 2 8" "10000000 4 16" "10000000 8 32" "1000000 16 16" "5000000 16 64" "5000000 24 64" "10000000 32 64" "2500000 48 64" "2500000 64 64" "1000000 128 32"; do
+for cfg in "10000000 2 8" "10000000 4 16" "10000000 8 32" "1000000 16 16" "5000000 16 64" "5000000 24 64" "10000000 32 64" "2500000 48 64" "2500000 64 64" "1000000 128 32" "2500000 32 256" "2500000 32 128" "1250000 32 64"; do
     set -- $cfg
     python3 "$R/bench.py" --samples $1 --dim $2 --components $3 --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null >> "$O"
 done

@@ -39,12 +39,13 @@ def main():
         if os.path.exists(os.path.join(src, f"{tag}_{name}")):
             shutil.copy(os.path.join(src, f"{tag}_{name}"), os.path.join(dst, f"{tag}_{name}"))
     summary = {}
-    for p in ("fetch", "write", "sq", "stall"):
-        if not os.path.exists(os.path.join(src, f"{tag}_pmc_{p}.csv")):
+    for p in ("fetch", "write", "sq", "stall", "kmeans_sq"):
+        raw = f"{tag}_kmeans_pmc_sq.csv" if p == "kmeans_sq" else f"{tag}_pmc_{p}.csv"
+        if not os.path.exists(os.path.join(src, raw)):
             continue
-        c = condense(os.path.join(src, f"{tag}_pmc_{p}.csv"))
+        c = condense(os.path.join(src, raw))
         summary[p] = c
-        with open(os.path.join(dst, f"{tag}_pmc_{p}.csv"), "w") as f:
+        with open(os.path.join(dst, raw), "w") as f:
             f.write("kernel,counter,average_per_dispatch,dispatches\n")
             for k in sorted(c):
                 for cn in sorted(c[k]):
