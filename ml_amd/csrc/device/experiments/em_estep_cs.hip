@@ -71,28 +71,8 @@ __device__ __forceinline__ double reduce_scatter_groups(double v0, double v1, do
 
 using double2_t = double __attribute__((ext_vector_type(2)));
 
-/// Every lane of a 16-lane row gets the value of the row's lane N (DPP row_newbcast, 32-bit halves: these moves do not
-/// compete with the fp64 matrix instructions for their pipe).
-template <int N> __device__ __forceinline__ double row_bcast(double v)
-{
-    // volatile asm: the compiler would otherwise keep one copy per N alive (common subexpressions) -- the registers this
-    // packing is there to save. The source register is written by a load long before: no VALU -> DPP hazard to pad.
-    int lo, hi;
-    asm volatile("v_mov_b32_dpp %0, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_mov_b32_dpp %1, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
-                 : "=&v"(lo), "=&v"(hi)
-                 : "v"(__double2loint(v)), "v"(__double2hiint(v)), "n"(N));
-    return __hiloint2double(hi, lo);
-}
-
-/// q (+)= a^2, pinned where it is written (volatile): left to the compiler, the squares of one of the two components sink to the
-/// end of the unit and its accumulators stay alive (64 registers). The operand was written by a matrix instruction at least four
-/// matrix instructions (64 cycles) earlier -- see the placement in the kernel -- so no wait states are needed here.
-template <bool FIRST> __device__ __forceinline__ void square_add(double& q, double a)
-{
-    if constexpr (FIRST) asm volatile("v_mul_f64 %0, %1, %1" : "=v"(q) : "v"(a));
-    else asm volatile("v_fma_f64 %0, %1, %1, %0" : "+v"(q) : "v"(a));
-}
+// (An earlier version kept the accumulator initialisers packed in one register pair per component and unpacked them with DPP
+// row_newbcast moves -- 64 more vector instructions per unit, each ~12 cycles when it sits between matrix instructions: 3.72 ms.)
 
 /// w = *(base + voff + OFF bytes), into the register w lives in (see reload_W_column in the kernel).
 template <int OFF> __device__ __forceinline__ void load_in_place(double& w, int voff, const double* base)
@@ -139,8 +119,8 @@ __global__ __launch_bounds__(64 * kWaves, 2) void em_estep_cs_kernel(
         v.y -= sh;
         *reinterpret_cast<double2_t*>(&tile_dyn[buf * TILE + (4 * c + crow) * kTilePitch + ccol]) = v;
     };
-    // The records of a component pair: W blocks in A-operand layout, the packed accumulator initialisers -W (mu - s) (lane
-    // (g, s) holds row 4 s + g; row_bcast<R> unpacks row quad R) and coef. Every load of them is IN PLACE and pinned where it
+    // The records of a component pair: W blocks in A-operand layout, the accumulator initialisers -W (mu - s) (one register pair
+    // per row quad) and coef. Every load of them is IN PLACE and pinned where it
     // is written (volatile asm, "+v": the destination is the very register the value lives in); left to the compiler, the
     // blocks of the next pair get registers of their own (+56 .. 90 registers), and its wait-count bookkeeping -- which
     // cannot tell which unit issued a load -- makes every unit wait for everything outstanding (the chunk just requested, the
