@@ -74,6 +74,15 @@ using double2_t = double __attribute__((ext_vector_type(2)));
 // (An earlier version kept the accumulator initialisers packed in one register pair per component and unpacked them with DPP
 // row_newbcast moves -- 64 more vector instructions per unit, each ~12 cycles when it sits between matrix instructions: 3.72 ms.)
 
+/// q (+)= a^2, pinned where it is written (volatile): left to the compiler, the squares of one of the two components sink to the
+/// end of the unit and its accumulators stay alive (64 registers). The operand was written by a matrix instruction at least four
+/// matrix instructions (64 cycles) earlier -- see the placement in the kernel -- so no wait states are needed here.
+template <bool FIRST> __device__ __forceinline__ void square_add(double& q, double a)
+{
+    if constexpr (FIRST) asm volatile("v_mul_f64 %0, %1, %1" : "=v"(q) : "v"(a));
+    else asm volatile("v_fma_f64 %0, %1, %1, %0" : "+v"(q) : "v"(a));
+}
+
 /// w = *(base + voff + OFF bytes), into the register w lives in (see reload_W_column in the kernel).
 template <int OFF> __device__ __forceinline__ void load_in_place(double& w, int voff, const double* base)
 {
