@@ -37,10 +37,11 @@ __global__ __launch_bounds__(256) void fill_resp_kernel(const uint32_t* __restri
 }
 
 /// stats[k*F + f] = sum_b partials[b][k][f], stats[K*F] = sum of the ll partials. Fixed order, hence reproducible run to run
-/// and identical on every rank: 32 outputs per workgroup, each summed by 8 threads over the block slices b = s, s + 8, ...
-/// (ascending), the 8 slice sums added in ascending s. (One thread per output walking all partial blocks, as in round 1, is
-/// latency-bound: 24 us for the 528 outputs of the diagonal configuration, a sixth of its iteration.)
-constexpr int kRedOut = 32, kRedSlices = 8;
+/// and identical on every rank: 8 outputs per workgroup, each summed by 32 threads over the block slices b = s, s + 32, ...
+/// (ascending), the 32 slice sums added in ascending s. (One thread per output walking all partial blocks, as in round 1, is
+/// latency-bound: 24 us for the 528 outputs of the diagonal configuration; 8 slices, round 2: 9.6 us with 768 partial blocks --
+/// the chain of dependent loads per thread is what it costs, so round 3 cuts it to a quarter.)
+constexpr int kRedOut = 8, kRedSlices = 32;
 __global__ __launch_bounds__(256) void em_reduce_kernel(const double* __restrict__ partials, int n_blocks, int KP, int FP,
                                                          int K, int F, const double* __restrict__ ll_partials,
                                                          int n_ll, double* __restrict__ stats)
