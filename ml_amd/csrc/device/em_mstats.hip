@@ -127,11 +127,13 @@ Plan make_plan(int d, int K, int num_cus)
     if (p.wide) {
         // One 512-thread workgroup per CU; its 8 waves take the column blocks round-robin (wave w: w, w+8, ...), every
         // wave holds all (<= 4) row blocks of the group: RBW x CBW <= 20 accumulator tiles.
-        p.RBW = p.RB >= 4 ? 4 : (p.RB >= 2 ? 2 : 1);
+        // ceil(RB / 4) row-block groups of equal height (1..4 blocks: K = 48 is ONE group of 3 [r3] -- it used to be two groups
+        // of 2, each staging the tile and forming the products again, without the self-normalising form)
+        p.n_rbg = (p.RB + 3) / 4;
+        p.RBW = (p.RB + p.n_rbg - 1) / p.n_rbg;
         // <= 5 blocks per wave: a single column group for d <= 32 (CB <= 36), ceil(CB / 40) groups of equal width above
         p.n_cbg = (p.CB + 39) / 40;
         p.CBW = (p.CB + 8 * p.n_cbg - 1) / (8 * p.n_cbg);
-        p.n_rbg = (p.RB + p.RBW - 1) / p.RBW;
         p.KP = p.n_rbg * p.RBW * 16;
         p.FP = p.n_cbg * 8 * p.CBW * 16;
         p.grid_x = num_cus / (p.n_rbg * p.n_cbg);

@@ -18,6 +18,8 @@
 //     xor-shuffle steps inside the wave, no extra barrier; lanes of component group 0 write the sample's maximum and the sum of
 //     its exponentials, which a small follow-up kernel (em_lse_finish_kernel, em_mstats.hip) turns into lse and the log-
 //     likelihood partials. Needs all K components in this workgroup (a single row-block group, K <= 64).
+#include <type_traits>
+
 #include "em_mstats_common.hpp"
 #include "exp_nonpos.hpp"
 
@@ -71,7 +73,20 @@ __device__ __forceinline__ double allreduce_sum_bits345(double v)
     return a + b;
 }
 
-template <int RBW, int CBW, int EXP, int DM>
+template <int N, int I = 0, class F> __device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
+/// CBT > 0 (round 3; single row-block and column-block group, d <= 32): the RBW x CBT accumulator tiles of the GEMM are dealt to
+/// the 8 waves as (column block, row block) UNITS in column-major order, ceil / floor(RBW CBT / 8) each, instead of whole column
+/// blocks with all their row blocks. At d = 16 (10 column blocks) two waves used to hold 2 x 4 tiles and six waves 1 x 4 -- the
+/// contraction ran at the pace of the two; now every wave holds 5. The wave's loop is specialised per wave (switch on the
+/// wave index), so which units share an operand product is known at compile time: one product per column block a wave touches.
+template <int RBW, int CBW, int EXP, int DM, int CBT = 0>
 __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
     const double* __restrict__ xt, size_t ldx, uint32_t n, int d, int D, const double* __restrict__ shift,
     const double* __restrict__ lw, size_t ldr, const double* __restrict__ lse, int K, int n_rbg, int CB_total,
@@ -91,25 +106,41 @@ __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
     const int F = da * (da + 1) / 2;
 
     // column block c of this wave: cbg*8*CBW + c*8 + wave
-    int offa[CBW], offb[CBW];
+    constexpr int NU = CBT > 0 ? (RBW * CBT + NW - 1) / NW : 1;   // balanced form: units per wave (at most)
+    constexpr int NOFF = CBT > 0 ? NU : CBW;
+    int offa[NOFF], offb[NOFF];
+    const int u_lo = CBT > 0 ? wave * (RBW * CBT) / NW : 0, u_hi = CBT > 0 ? (wave + 1) * (RBW * CBT) / NW : 0;
+    if constexpr (CBT > 0) {
+        // unit u = (column block u / RBW, row block u % RBW); slot j of this wave is unit u_lo + j
 #pragma unroll
-    for (int c = 0; c < CBW; ++c) {
-        const int cb = (cbg * CBW + c) * NW + wave;
-        int a, b;
-        feature_pair(cb * 16 + (lane & 15), cb < CB_total ? F : 0, da, a, b);
-        offa[c] = a;
-        offb[c] = b;
+        for (int j = 0; j < NU; ++j) {
+            const int cb = (u_lo + j) / RBW;
+            int a, b;
+            feature_pair(cb * 16 + (lane & 15), u_lo + j < u_hi ? F : 0, da, a, b);
+            offa[j] = a;
+            offb[j] = b;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) {
+            const int cb = (cbg * CBW + c) * NW + wave;
+            int a, b;
+            feature_pair(cb * 16 + (lane & 15), cb < CB_total ? F : 0, da, a, b);
+            offa[c] = a;
+            offb[c] = b;
+        }
     }
     // With CBW = ceil(CB / 8) column blocks per wave and a single column group (d <= 32), only a wave's LAST block can
     // fall outside the matrix (wave-uniform); all others are unconditional, which keeps them in one basic block. With
     // several column groups (d > 32) earlier blocks of the last group may be outside too: they multiply the zero slot.
     const bool last_active = (cbg * CBW + CBW - 1) * NW + wave < CB_total;
 
-    d4 acc[RBW][CBW];
+    constexpr int AR = CBT > 0 ? 1 : RBW, AC = CBT > 0 ? NU : CBW;
+    d4 acc[AR][AC];
 #pragma unroll
-    for (int r = 0; r < RBW; ++r)
+    for (int r = 0; r < AR; ++r)
 #pragma unroll
-        for (int c = 0; c < CBW; ++c) acc[r][c] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int c = 0; c < AC; ++c) acc[r][c] = d4{0.0, 0.0, 0.0, 0.0};
 
     // staging role: sample sS of the tile, rows wave, wave+8, ... For EXP == 2 the responsibilities have their own role:
     // sample sR = 8 wave + (lane & 7), components NRV cg + it with cg = lane >> 3 -- one wave holds all K values of its 8 samples
@@ -198,6 +229,35 @@ __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
         const double* xbase = Xb + 16 * (lane >> 4) * XS;
         const double* rbase = Rb + 16 * (lane >> 4) * RS + (lane & 15);
         __builtin_amdgcn_s_setprio(kMatrixPhasePriority);   // see em_estep_mfma4.hip (11.78 -> 11.59 ms at d = 32, K = 64)
+        if constexpr (CBT > 0) {
+            auto contract = [&](auto w_) {
+                constexpr int W = w_, U = RBW * CBT, LO = W * U / NW, HI = (W + 1) * U / NW, NJ = HI - LO;
+#pragma unroll 2
+                for (int sg = 0; sg < TS / 4; ++sg) {
+                    const double* xr = xbase + sg * XS;
+                    const double* rr = rbase + sg * RS;
+                    double av[RBW];
+#pragma unroll
+                    for (int r = 0; r < RBW; ++r) av[r] = rr[r * 16];
+                    double bv = 0.0;
+                    static_for<NJ>([&](auto j_) {
+                        constexpr int j = j_, u = LO + j;
+                        if constexpr (j == 0 || u / RBW != (u - 1) / RBW) bv = xr[offa[j]] * xr[offb[j]];   // first unit of a column block
+                        acc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u % RBW], bv, acc[0][j], 0, 0, 0);
+                    });
+                }
+            };
+            switch (wave) {
+            case 0: contract(std::integral_constant<int, 0>{}); break;
+            case 1: contract(std::integral_constant<int, 1>{}); break;
+            case 2: contract(std::integral_constant<int, 2>{}); break;
+            case 3: contract(std::integral_constant<int, 3>{}); break;
+            case 4: contract(std::integral_constant<int, 4>{}); break;
+            case 5: contract(std::integral_constant<int, 5>{}); break;
+            case 6: contract(std::integral_constant<int, 6>{}); break;
+            default: contract(std::integral_constant<int, 7>{}); break;
+            }
+        } else {
 #pragma unroll 2
         for (int sg = 0; sg < TS / 4; ++sg) {
             const double* xr = xbase + sg * XS;
@@ -222,11 +282,26 @@ __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
                     acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], bv, acc[r][c], 0, 0, 0);
             }
         }
+        }
         __builtin_amdgcn_s_setprio(0);
     }
 
     // ---- epilogue: partials[blockIdx.x][k][f]; C/D layout of v_mfma_f64_16x16x4: col = lane&15, row = (lane>>4) + 4*reg
     double* out = partials + (size_t)blockIdx.x * KP * FP;
+    if constexpr (CBT > 0) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            const int u = u_lo + j;
+            if (u < u_hi) {
+                const int cb = u / RBW, rb = u % RBW;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int k = rb * 16 + (lane >> 4) + 4 * g;
+                    out[(size_t)k * FP + cb * 16 + (lane & 15)] = acc[0][j][g];
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int r = 0; r < RBW; ++r)
 #pragma unroll
@@ -240,24 +315,25 @@ __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
                 }
             }
         }
+    }
 }
 
-template <int RBW, int CBW, int DM = kRegDim>
+template <int RBW, int CBW, int DM = kRegDim, int CBT = 0>
 void launch_t(const MstatsArgs& a, const Plan& p, int grid_x, hipStream_t stream)
 {
     constexpr int XSD = tile_stride<DM>();
     const size_t smem = (DM <= kMidDim ? 2 : 1) * sizeof(double) * ((size_t)TS * XSD + (size_t)TS * (RBW * 16 + 1));
     const dim3 grid(grid_x, p.n_rbg * p.n_cbg);
     if (a.mode == kFromLogRespSelfNorm)
-        hipLaunchKernelGGL((em_mstats_wide_kernel<RBW, CBW, 2, DM>), grid, dim3(512), smem, stream, a.xt, a.ldx, a.n, a.d,
+        hipLaunchKernelGGL((em_mstats_wide_kernel<RBW, CBW, 2, DM, CBT>), grid, dim3(512), smem, stream, a.xt, a.ldx, a.n, a.d,
                            padded_dim(a.d), a.shift, a.lw, a.ldr, a.lse, a.K, p.n_rbg, p.CB, a.partials, p.KP, p.FP,
                            a.lse_out, a.ll_out);
     else if (a.mode == kFromLogResp)
-        hipLaunchKernelGGL((em_mstats_wide_kernel<RBW, CBW, 1, DM>), grid, dim3(512), smem, stream, a.xt, a.ldx, a.n, a.d,
+        hipLaunchKernelGGL((em_mstats_wide_kernel<RBW, CBW, 1, DM, CBT>), grid, dim3(512), smem, stream, a.xt, a.ldx, a.n, a.d,
                            padded_dim(a.d), a.shift, a.lw, a.ldr, a.lse, a.K, p.n_rbg, p.CB, a.partials, p.KP, p.FP,
                            nullptr, nullptr);
     else
-        hipLaunchKernelGGL((em_mstats_wide_kernel<RBW, CBW, 0, DM>), grid, dim3(512), smem, stream, a.xt, a.ldx, a.n, a.d,
+        hipLaunchKernelGGL((em_mstats_wide_kernel<RBW, CBW, 0, DM, CBT>), grid, dim3(512), smem, stream, a.xt, a.ldx, a.n, a.d,
                            padded_dim(a.d), a.shift, a.lw, a.ldr, a.lse, a.K, p.n_rbg, p.CB, a.partials, p.KP, p.FP,
                            nullptr, nullptr);
 }
@@ -273,15 +349,26 @@ int launch_wide(const MstatsArgs& a, const Plan& p, int grid_x, hipStream_t stre
         if (a.d <= kMidDim) launch_t<R, C, kMidDim>(a, p, grid_x, stream); else launch_t<R, C, kMaxDim>(a, p, grid_x, stream); \
     } else
         MLHIP_BIG(1, 3) MLHIP_BIG(1, 4) MLHIP_BIG(1, 5) MLHIP_BIG(2, 3) MLHIP_BIG(2, 4) MLHIP_BIG(2, 5)
-        MLHIP_BIG(4, 3) MLHIP_BIG(4, 4) MLHIP_BIG(4, 5)
+        MLHIP_BIG(3, 3) MLHIP_BIG(3, 4) MLHIP_BIG(3, 5) MLHIP_BIG(4, 3) MLHIP_BIG(4, 4) MLHIP_BIG(4, 5)
         { return -1; }
 #undef MLHIP_BIG
         return grid_x;
+    }
+    // balanced dealing of (column block, row block) units where whole column blocks leave the waves unevenly loaded
+    // (MLHIP_MSTATS_BALANCED=0: off)
+    static const bool balanced = [] { const char* e = std::getenv("MLHIP_MSTATS_BALANCED"); return !(e && e[0] == '0'); }();
+    if (balanced && p.n_rbg == 1 && p.n_cbg == 1) {
+        if (p.RBW == 4 && p.CB == 6) { launch_t<4, 1, kRegDim, 6>(a, p, grid_x, stream); return grid_x; }      // d = 12
+        if (p.RBW == 4 && p.CB == 10) { launch_t<4, 2, kRegDim, 10>(a, p, grid_x, stream); return grid_x; }    // d = 16
+        if (p.RBW == 3 && p.CB == 10) { launch_t<3, 2, kRegDim, 10>(a, p, grid_x, stream); return grid_x; }
+        if (p.RBW == 2 && p.CB == 10) { launch_t<2, 2, kRegDim, 10>(a, p, grid_x, stream); return grid_x; }
+        if (p.RBW == 3 && p.CB == 6) { launch_t<3, 1, kRegDim, 6>(a, p, grid_x, stream); return grid_x; }
     }
 #define MLHIP_CASE(R, C) \
     if (p.RBW == R && p.CBW == C) { launch_t<R, C>(a, p, grid_x, stream); } else
     MLHIP_CASE(1, 1) MLHIP_CASE(1, 2) MLHIP_CASE(1, 3) MLHIP_CASE(1, 4) MLHIP_CASE(1, 5)
     MLHIP_CASE(2, 1) MLHIP_CASE(2, 2) MLHIP_CASE(2, 3) MLHIP_CASE(2, 4) MLHIP_CASE(2, 5)
+    MLHIP_CASE(3, 1) MLHIP_CASE(3, 2) MLHIP_CASE(3, 3) MLHIP_CASE(3, 4) MLHIP_CASE(3, 5)
     MLHIP_CASE(4, 1) MLHIP_CASE(4, 2) MLHIP_CASE(4, 3) MLHIP_CASE(4, 4) MLHIP_CASE(4, 5)
     { return -1; }
 #undef MLHIP_CASE
