@@ -154,7 +154,9 @@ int launch_kmeans_assign(const KmeansArgs& a, int num_cus, hipStream_t stream);
 void launch_kmeans_reduce(const KmeansArgs& a, int n_partials, hipStream_t stream);
 /// update_step's closing arithmetic on the (all-reduced) output block [inertia, changed, counts(K), sums(K*d)]: the sums
 /// become the means IN PLACE (empty cluster -> origin, ML/KMeans.cpp:184) and are written as the next centroid table
-/// next[K][D] (padded coordinates zero).
-void launch_kmeans_close(double* out, int K, int d, int D, double* next, hipStream_t stream);
+/// next[K][D] (padded coordinates zero). `mirror` (may be null): host-visible pinned memory that receives a copy of the whole block
+/// from the same kernel -- the host then only waits for the stream; a separate hipMemcpyAsync of these 2 + K (d + 1) doubles goes
+/// through a copy engine and costs more than the kernel itself.
+void launch_kmeans_close(double* out, int K, int d, int D, double* next, double* mirror, hipStream_t stream);
 
 }  // namespace mlhip

@@ -232,8 +232,7 @@ __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
         if constexpr (CBT > 0) {
             auto contract = [&](auto w_) {
                 constexpr int W = w_, U = RBW * CBT, LO = W * U / NW, HI = (W + 1) * U / NW, NJ = HI - LO;
-#pragma unroll 2
-                for (int sg = 0; sg < TS / 4; ++sg) {
+                auto step = [&](int sg) {
                     const double* xr = xbase + sg * XS;
                     const double* rr = rbase + sg * RS;
                     double av[RBW];
@@ -245,6 +244,10 @@ __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
                         if constexpr (j == 0 || u / RBW != (u - 1) / RBW) bv = xr[offa[j]] * xr[offb[j]];   // first unit of a column block
                         acc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u % RBW], bv, acc[0][j], 0, 0, 0);
                     });
+                };
+                for (int sg = 0; sg < TS / 4; sg += 2) {     // two sample groups per trip (written out: `#pragma unroll 2` is refused
+                    step(sg);                                // on some of the eight specialisations)
+                    step(sg + 1);
                 }
             };
             switch (wave) {

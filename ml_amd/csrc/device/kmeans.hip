@@ -325,9 +325,11 @@ int launch_kmeans_assign(const KmeansArgs& a_in, int num_cus, hipStream_t stream
 
 namespace {
 /// One thread per (cluster, padded coordinate): the same IEEE division as the host's closing loop (mlhip_kmeans_step).
-__global__ __launch_bounds__(256) void kmeans_close_kernel(double* __restrict__ out, int K, int d, int D, double* __restrict__ next)
+__global__ __launch_bounds__(256) void kmeans_close_kernel(double* __restrict__ out, int K, int d, int D, double* __restrict__ next,
+                                                            double* __restrict__ mirror)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
+    if (mirror && e < 2 + K) mirror[e] = out[e];          // inertia, changed, counts: as they are
     if (e >= K * D) return;
     const int k = e / D, j = e - k * D;
     double v = 0.0;
@@ -336,14 +338,16 @@ __global__ __launch_bounds__(256) void kmeans_close_kernel(double* __restrict__ 
         double* sum = out + 2 + K + (size_t)k * d + j;
         v = c > 0 ? *sum / c : 0.0;
         *sum = v;
+        if (mirror) mirror[2 + K + (size_t)k * d + j] = v;
     }
     next[e] = v;
 }
 }  // namespace
 
-void launch_kmeans_close(double* out, int K, int d, int D, double* next, hipStream_t stream)
+void launch_kmeans_close(double* out, int K, int d, int D, double* next, double* mirror, hipStream_t stream)
 {
-    hipLaunchKernelGGL(kmeans_close_kernel, dim3((K * D + 255) / 256), dim3(256), 0, stream, out, K, d, D, next);
+    const int threads = K * D > K + 2 ? K * D : K + 2;
+    hipLaunchKernelGGL(kmeans_close_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, out, K, d, D, next, mirror);
 }
 
 void launch_kmeans_reduce(const KmeansArgs& a, int n_partials, hipStream_t stream)

@@ -9,7 +9,7 @@
 //      VGPRs in operand layout), accumulator initialised with -|c|^2/2; every lane tracks best and second-best over the
 //      4 x (K/16) clusters it sees. For large K (QUAD) the tracking runs on 32-bit integer keys -- the high dword of the
 //      biased, hence positive, score -- and the four scores of an accumulator enter it through their maximum
-//      (track_quad_keys): 1.75 integer operations per score instead of 3 fp64 ones plus a compare and a select. The four
+//      (track_quad_keys): 1.5 integer operations per score instead of 3 fp64 ones plus a compare and a select. The four
 //      lane groups are merged by shuffles;
 //   2. one lane per sample re-reads the sample's row and evaluates the EXACT direct-form distance to the winner with the
 //      same fma chain as the host point query (this is the min distance / inertia contribution that is stored); QUAD: the
@@ -57,8 +57,8 @@ __device__ __forceinline__ void track_top2(double& best, double& second, double 
 /// dword of a positive double orders like the double itself as a signed integer (negative scores -- clusters far behind, or the
 /// padding rows -- are negative integers: never ahead of a positive one). The four scores one accumulator holds for a sample
 /// (rows r = 0..3: clusters 16 b + g + 4 r) enter the top-2 tracking through the maximum of their keys, and only the BLOCK of
-/// the running best is remembered: 7 integer operations per four scores (v_max3_i32, v_max_i32, v_min_i32, v_max_i32,
-/// v_cmp_gt_i32, v_cndmask_b32, v_max_i32) instead of 4 byte permutes + 6 fp64 min / max -- next to the matrix
+/// the running best is remembered: 6 integer operations per four scores (v_max3_i32, v_max_i32, v_med3_i32, v_cmp_gt_i32,
+/// v_cndmask_b32, v_max_i32) instead of 4 byte permutes + 6 fp64 min / max -- next to the matrix
 /// instructions a vector instruction costs its issue slot whatever its width (tools/microbench_issue), and these are 30 %
 /// fewer. The key keeps 20 mantissa bits: the exact phase turns (best, runner-up) back into a lower / upper bound of the two
 /// scores and demands their distance to exceed the rounding margin; the winner's quad (4 clusters) is then settled by exact
@@ -67,7 +67,7 @@ __device__ __forceinline__ void track_quad_keys(int& best, int& second, int& blo
 {
     const int k0 = __double2hiint(acc[0]), k1 = __double2hiint(acc[1]), k2 = __double2hiint(acc[2]), k3 = __double2hiint(acc[3]);
     const int m = max(max(k0, k1), max(k2, k3));
-    second = max(second, min(best, m));
+    asm("v_med3_i32 %0, %1, %2, %0" : "+v"(second) : "v"(best), "v"(m));   // second <= best: max(second, min(best, m)) is the median
     block = m > best ? this_block : block;
     best = max(best, m);
 }

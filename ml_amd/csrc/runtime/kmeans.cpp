@@ -175,8 +175,12 @@ void km_iterate(mlhip_data* dt, int K, double* centroids, double* old_centroids,
     for (uint32_t step = 0; step < max_steps; ++step) {
         if (device_route) {
             km_launch(dt, K, b, true, nullptr);
-            launch_kmeans_close(dt->km_out.as<double>(), K, d, b.D, dt->km_cent_next.as<double>(), ctx->stream);
-            km_fetch(dt, 2 + (size_t)K * (d + 1));
+            // (the closing kernel writes the block into the pinned km_host as well: no copy-engine transfer in the loop)
+            static const bool mirror = [] { const char* e = std::getenv("MLHIP_KMEANS_MIRROR"); return !(e && e[0] == '0'); }();
+            launch_kmeans_close(dt->km_out.as<double>(), K, d, b.D, dt->km_cent_next.as<double>(), mirror ? dt->km_host.as<double>() : nullptr,
+                                ctx->stream);
+            HIP_CHECK(hipGetLastError());
+            if (mirror) ctx->sync(); else km_fetch(dt, 2 + (size_t)K * (d + 1));
             const double* r = dt->km_host.as<double>();
             if (counts) std::copy(r + 2, r + 2 + K, counts);
             std::copy(r + 2 + K, r + 2 + K + kd, upd.begin());

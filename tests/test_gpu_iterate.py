@@ -232,3 +232,27 @@ def test_kmeans_iterate_equals_the_step_loop(ctx, oracle, d, K, n, max_steps, at
         assert km.steps_done == a[0]
         assert np.array_equal(km.labels, la)
         assert relerr(a[4], km.centroids) < 1e-12
+
+
+@pytest.mark.parametrize("d,K,n", [(8, 16, 6000), (2, 7, 5000), (8, 256, 20000)])
+def test_kmeans_iterate_entered_again_after_convergence(ctx, d, K, n):
+    """The lagged loop launches a step ahead of the host's stopping test; when the test fires, that step must have left nothing
+    behind: a second call from the converged centroids sees the same labels twice at once (2 steps), and labels, distances,
+    centroids, counts and inertia are bit-identical before and after it."""
+    from ml_amd import _lib
+    rng = np.random.default_rng(5 * d + K)
+    means = 3.0 * rng.standard_normal((K, d))
+    X = np.ascontiguousarray(means[rng.integers(0, K, n)] + rng.standard_normal((n, d)))
+    C0 = X[rng.choice(n, K, replace=False)].copy()
+    dt = _lib.Data(ctx, X)
+    a = dt.kmeans_iterate(C0, 500, 0.0)
+    assert a[1]                                           # converged on identical labels
+    la, da = dt.kmeans_labels(), dt.kmeans_distances()
+    b = dt.kmeans_iterate(a[4], 500, 0.0)
+    assert b[0] == 2 and b[1]
+    assert b[2] == a[2] and np.array_equal(b[3], a[3]) and np.array_equal(b[4], a[4])
+    assert np.array_equal(dt.kmeans_labels(), la) and np.array_equal(dt.kmeans_distances(), da)
+    # ... and a plain assignment under the same centroids changes no label
+    inertia, changed = dt.kmeans_assign(a[4])
+    assert changed == 0 and inertia == a[2]
+    dt.close()
