@@ -581,7 +581,12 @@ void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* mean
 
     // One iteration's device work: E-step + statistics from the records in params_dev, all-reduce, closing arithmetic into
     // it_pack[out] and the next records into params_next. Nothing here waits for the device.
-    auto launch_iteration = [&](int out) {
+    // Full covariances: the closing kernel writes its 1 + 2K info doubles (log-likelihood sum, refinement flags, FOLD bounds) straight
+    // into pinned host memory -- no hipMemcpyAsync in the loop (one API call and one copy-engine round trip less per iteration;
+    // MLHIP_INFO_PINNED=0: the copy). Diagonal mode reads its parameter shadow back with the info and keeps the copy.
+    static const bool info_pinned_allowed = [] { const char* e = std::getenv("MLHIP_INFO_PINNED"); return !(e && e[0] == '0'); }();
+    const bool info_pinned = info_pinned_allowed && !diag;
+    auto launch_iteration = [&](int out, double* info_host) {
         if (diag) {
             run_diag_kernel(data, K, data->shift_dev.as<double>(), false);
         } else if (fused) {
@@ -599,7 +604,7 @@ void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* mean
         ca.layout = data->estep_variant; ca.refine_limit = limit;
         ca.mixing = pack_mixing(out); ca.means = pack_means(out);
         ca.covs = pack_covs(out); ca.records = data->params_next.as<double>();
-        ca.info = data->it_pack[out].as<double>();
+        ca.info = info_pinned ? info_host : data->it_pack[out].as<double>();
         ctx->timed("em_close", [&] { if (diag) launch_em_close_diag(ca, ctx->stream); else launch_em_close(ca, ctx->stream); });
         HIP_CHECK(hipGetLastError());
     };
@@ -638,9 +643,10 @@ void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* mean
         }
         auto launch = [&](uint32_t i) {                          // iteration i: records R_i (params_dev) -> R_(i+1), pack (i+1) % 3
             const int out = (int)((i + 1) % 3);
-            launch_iteration(out);
-            HIP_CHECK(hipMemcpyAsync(data->it_info_slot[out].p, data->it_pack[out].p, sizeof(double) * copy_doubles, hipMemcpyDeviceToHost,
-                                     ctx->stream));
+            launch_iteration(out, data->it_info_slot[out].as<double>());
+            if (!info_pinned)
+                HIP_CHECK(hipMemcpyAsync(data->it_info_slot[out].p, data->it_pack[out].p, sizeof(double) * copy_doubles, hipMemcpyDeviceToHost,
+                                         ctx->stream));
             HIP_CHECK(hipEventRecord(data->it_event[out], ctx->stream));
             // rotate: params_dev <- R_(i+1), params_prev <- R_i, params_next <- the buffer of R_(i-1) (evaluated, free)
             std::swap(data->params_prev, data->params_dev);      // prev = R_i, dev = old prev
@@ -711,10 +717,11 @@ void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* mean
     for (uint32_t step = first_sync_step; step < max_steps; ++step) {
         PhaseTrace tr;
         const int nxt = cur ^ 1;
-        launch_iteration(nxt);
+        launch_iteration(nxt, info);
         // one read-back: the info block and, in diagonal mode (small), a host shadow of the newest parameters right behind it
         // (ensure_lw needs the inputs of the last E-step)
-        HIP_CHECK(hipMemcpyAsync(info, data->it_pack[nxt].p, sizeof(double) * (diag ? n_pack : n_info), hipMemcpyDeviceToHost, ctx->stream));
+        if (!info_pinned)
+            HIP_CHECK(hipMemcpyAsync(info, data->it_pack[nxt].p, sizeof(double) * (diag ? n_pack : n_info), hipMemcpyDeviceToHost, ctx->stream));
         ctx->sync();
         tr.mark("iteration (device close)");
         const double ll = info[0] / (double)data->n_global - (double)d * log_two_pi() / 2;   // ML/EM.cpp:197-198, 211
