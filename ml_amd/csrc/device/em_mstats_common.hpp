@@ -33,6 +33,7 @@ struct Plan {
     int RB, CB;         // total 16-blocks
     int n_rbg, n_cbg;   // grid.y decomposition
     int grid_x;
+    int wg_per_cu;      // wide: 1, or 2 for the few-component shapes (see make_plan)
     int KP, FP;         // padded extents of one partial block
 };
 Plan make_plan(int d, int K, int num_cus);

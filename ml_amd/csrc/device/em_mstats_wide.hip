@@ -364,7 +364,9 @@ int launch_wide(const MstatsArgs& a, const Plan& p, int grid_x, hipStream_t stre
         if (p.RBW == 4 && p.CB == 6) { launch_t<4, 1, kRegDim, 6>(a, p, grid_x, stream); return grid_x; }      // d = 12
         if (p.RBW == 4 && p.CB == 10) { launch_t<4, 2, kRegDim, 10>(a, p, grid_x, stream); return grid_x; }    // d = 16
         if (p.RBW == 3 && p.CB == 10) { launch_t<3, 2, kRegDim, 10>(a, p, grid_x, stream); return grid_x; }
-        if (p.RBW == 2 && p.CB == 10) { launch_t<2, 2, kRegDim, 10>(a, p, grid_x, stream); return grid_x; }
+        // (K <= 32 at d = 16: the plain form with two workgroups per CU -- the balanced one needs 130 registers -- unless the plan
+        //  kept one workgroup per CU)
+        if (p.RBW == 2 && p.CB == 10 && p.wg_per_cu == 1) { launch_t<2, 2, kRegDim, 10>(a, p, grid_x, stream); return grid_x; }
         if (p.RBW == 3 && p.CB == 6) { launch_t<3, 1, kRegDim, 6>(a, p, grid_x, stream); return grid_x; }
     }
 #define MLHIP_CASE(R, C) \
