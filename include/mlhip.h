@@ -92,7 +92,7 @@ int mlhip_ctx_world(const mlhip_ctx* ctx, int* world_size, int* rank);
 /* Copies this rank's d x n block to HBM (stored dimension-major for coalesced per-sample access) and
  * computes the statistics shift (global column mean; all-reduced when a hook is set). The host block is
  * only read during the call (the reference borrows `data` for the duration of fit, ML/EM.cpp:91).
- * 1 <= d <= 128 (MLHIP_E_UNSUPPORTED above), n < 2^32 - 256 per rank. */
+ * 1 <= d <= 4096 (MLHIP_E_UNSUPPORTED above; d > 128 runs plain, untuned kernels: device/generic_dim.hip), n < 2^32 - 256 per rank. */
 int mlhip_data_upload(mlhip_ctx* ctx, const double* x, uint32_t d, uint64_t n, int64_t ld, mlhip_data** out);
 /* Same, from a sample-major block already in device memory (e.g. a torch tensor's data_ptr()). */
 int mlhip_data_upload_dev(mlhip_ctx* ctx, const double* x_dev, uint32_t d, uint64_t n, int64_t ld, mlhip_data** out);
@@ -117,7 +117,7 @@ int mlhip_em_step(mlhip_ctx* ctx, mlhip_data* data, uint32_t K,
 /* EXTENSION (no counterpart in the reference, whose ml::EM is full-covariance only, ML/EM.hpp:175; BASELINE.json configs[1]):
  * one EM iteration with DIAGONAL covariances -- the loops of mlhip_em_step restricted to the diagonal, in one kernel
  * (X read once, no N x K block in HBM). variances / variances_out: K*d doubles, variances[k*d + j] = sigma_kj^2 (ridge 1e-15
- * included on output, ML/EM.cpp:252). One fused kernel for d <= 32, K <= 64; other shapes (d <= 128) run the full-covariance kernels on diagonal matrices. mlhip_em_responsibilities /
+ * included on output, ML/EM.cpp:252). One fused kernel for d <= 32, K <= 64; other shapes run the full-covariance kernels on diagonal matrices. mlhip_em_responsibilities /
  * mlhip_em_labels afterwards work as after mlhip_em_step (the block is rebuilt from the same parameters on demand). */
 int mlhip_em_step_diag(mlhip_ctx* ctx, mlhip_data* data, uint32_t K,
                        const double* mixing, const double* means, const double* variances,

@@ -8,21 +8,22 @@ namespace {
 // Tile of 64 samples x d dims through LDS so that both the global read (consecutive doubles of a sample
 // row) and the global write (consecutive samples of one dimension) are coalesced.
 __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ src, int64_t lds_, int d, uint64_t n,
-                                                         double* __restrict__ dst, size_t ldd, uint64_t i0)
+                                                         double* __restrict__ dst, size_t ldd, uint64_t i0, int dc)
 {
-    extern __shared__ double tile[];   // [64][d+1]
-    const int DS = d + 1;
+    extern __shared__ double tile[];   // [64][dc+1]: dimensions j0 .. j0 + dw of the tile's 64 samples (blockIdx.y: the chunk)
+    const int j0 = blockIdx.y * dc, dw = min(dc, d - j0);
+    const int DS = dc + 1;
     const uint64_t base = (uint64_t)blockIdx.x * 64;
-    for (int e = threadIdx.x; e < 64 * d; e += 256) {
-        const int s = e / d, j = e - s * d;
+    for (int e = threadIdx.x; e < 64 * dw; e += 256) {
+        const int s = e / dw, j = e - s * dw;
         const uint64_t i = base + s;
-        tile[s * DS + j] = i < n ? src[(int64_t)i * lds_ + j] : 0.0;
+        tile[s * DS + j] = i < n ? src[(int64_t)i * lds_ + j0 + j] : 0.0;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 64 * d; e += 256) {
+    for (int e = threadIdx.x; e < 64 * dw; e += 256) {
         const int s = e & 63, j = e >> 6;
         const uint64_t i = base + s;
-        if (i < n) dst[(size_t)j * ldd + i0 + i] = tile[s * DS + j];
+        if (i < n) dst[(size_t)(j0 + j) * ldd + i0 + i] = tile[s * DS + j];
     }
 }
 
@@ -108,12 +109,14 @@ __global__ __launch_bounds__(128) void random_partition_kernel(const double* __r
                                                                 const uint32_t* __restrict__ offsets, double* __restrict__ means,
                                                                 double* __restrict__ sizes)
 {
-    const int k = blockIdx.x, j = threadIdx.x;
+    const int k = blockIdx.x;
     const uint32_t lo = offsets[k], hi = offsets[k + 1];
-    double count = sizes[k];
-    if (j < d) {
+    const double count0 = sizes[k];
+    double count = count0;
+    for (int j = threadIdx.x; j < d; j += blockDim.x) {          // (one trip for d <= 128)
         const double* __restrict__ row = xt + (size_t)j * ldx;
         double c = means[(size_t)k * d + j];
+        count = count0;
         uint32_t t = lo;
         for (; t + 8 <= hi; t += 8) {
             double x[8];
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(128) void random_partition_kernel(const double* __r
         means[(size_t)k * d + j] = c;
     }
     __syncthreads();                      // every thread of the block has read sizes[k]
-    if (j == 0) sizes[k] = count;
+    if (threadIdx.x == 0) sizes[k] = count0 + (double)(hi - lo);   // (= the count every chain ended with: integers, exact)
 }
 
 }  // namespace
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(128) void random_partition_kernel(const double* __r
 void launch_random_partition(const double* xt, size_t ldx, int d, int K, const uint32_t* order, const uint32_t* offsets,
                              double* means, double* sizes, hipStream_t stream)
 {
-    hipLaunchKernelGGL(random_partition_kernel, dim3(K), dim3(64 * ((d + 63) / 64)), 0, stream, xt, ldx, d, order, offsets, means, sizes);
+    hipLaunchKernelGGL(random_partition_kernel, dim3(K), dim3(d <= 64 ? 64 : 128), 0, stream, xt, ldx, d, order, offsets, means, sizes);
 }
 
 void launch_transpose_to_dim_major(const double* src, int64_t lds, int d, uint64_t n, double* dst, size_t ldd,
@@ -148,8 +151,9 @@ void launch_transpose_to_dim_major(const double* src, int64_t lds, int d, uint64
 {
     if (n == 0) return;
     const unsigned blocks = (unsigned)((n + 63) / 64);
-    hipLaunchKernelGGL(transpose_kernel, dim3(blocks), dim3(256), sizeof(double) * 64 * (d + 1), stream, src, lds, d, n, dst,
-                       ldd, i0);
+    const int dc = d <= 128 ? d : 128;                          // dimensions per tile: at most 66 KB of LDS
+    hipLaunchKernelGGL(transpose_kernel, dim3(blocks, (d + dc - 1) / dc), dim3(256), sizeof(double) * 64 * (dc + 1), stream, src, lds, d,
+                       n, dst, ldd, i0, dc);
 }
 
 void launch_column_maxabs(const double* xt, size_t ldx, int d, uint64_t n, double* scratch, double* maxabs, hipStream_t stream)

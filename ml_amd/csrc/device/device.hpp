@@ -38,6 +38,8 @@ struct EstepArgs {
 };
 /// Returns the grid size used (= number of ll partials written), or <0 if D is not instantiated.
 int launch_em_estep(const EstepArgs& a, hipStream_t stream);
+/// d > kMaxDim (generic_dim.hip): the same passes in a plain form, any dimension.
+int launch_em_estep_generic(const EstepArgs& a, hipStream_t stream);
 #ifdef MLHIP_EXPERIMENTS
 /// 16x16x4 block-triangular variant (experiments/em_estep_mfma16.hip); params use the estep_mfma_param_stride(D) layout.
 int launch_em_estep_mfma(const EstepArgs& a, int num_cus, hipStream_t stream);
@@ -67,6 +69,7 @@ struct MstatsArgs {
     double* ll_scratch;                                      // kFromLogRespSelfNorm: >= 1024 doubles for the ll partials
     double* lse_out; double* ll_out;                         // kFromLogRespSelfNorm: per-sample max (-> lse) and exp-sum (n_pad each)
 };
+int launch_em_mstats_generic(const MstatsArgs& a, hipStream_t stream);   // d > kMaxDim: writes ONE partial block [K][F]
 /// Whether the statistics kernel chosen for (d, K) can normalise log-responsibilities itself (mode kFromLogRespSelfNorm).
 bool em_mstats_self_norm_supported(int d, int K, int num_cus);
 /// Fused E-step + statistics for small shapes (em_fused_small.hip): params are the estep_param_stride(D) records.
@@ -151,6 +154,7 @@ struct KmeansArgs {
 size_t kmeans_scratch_doubles(int d, int K, int num_cus);
 /// Assignment kernel; returns the number of per-workgroup partials (>0) or <0 on error.
 int launch_kmeans_assign(const KmeansArgs& a, int num_cus, hipStream_t stream);
+void launch_kmeans_assign_generic(const KmeansArgs& a, int grid, size_t pstride, hipStream_t stream);   // d > kMaxDim (generic_dim.hip)
 void launch_kmeans_reduce(const KmeansArgs& a, int n_partials, hipStream_t stream);
 /// update_step's closing arithmetic on the (all-reduced) output block [inertia, changed, counts(K), sums(K*d)]: the sums
 /// become the means IN PLACE (empty cluster -> origin, ML/KMeans.cpp:184) and are written as the next centroid table

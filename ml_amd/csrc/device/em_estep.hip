@@ -111,7 +111,7 @@ int launch_em_estep(const EstepArgs& a, hipStream_t stream)
     case 24: return launch_t<24>(a, stream);
     case 28: return launch_t<28>(a, stream);
     case 32: return launch_t<32>(a, stream);
-    default: return -1;
+    default: return a.D > kMaxDim ? launch_em_estep_generic(a, stream) : -1;
     }
 }
 

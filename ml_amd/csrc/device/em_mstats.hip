@@ -123,6 +123,16 @@ Plan make_plan(int d, int K, int num_cus)
 #else
     constexpr bool force_narrow = false;     // the workgroup-tile variant (experiments/em_mstats_narrow.hip) is not built
 #endif
+    if (d > kMaxDim) {
+        // generic_dim.hip: one workgroup per (row of the packed triangle, component), ONE partial block [K][F]
+        p.RBW = p.CBW = 1;
+        p.n_rbg = p.n_cbg = 1;
+        p.KP = K;
+        p.FP = F;
+        p.grid_x = 1;
+        p.wg_per_cu = 1;
+        return p;
+    }
     p.wide = p.CB >= 5 && !force_narrow;
     if (p.wide) {
         // One 512-thread workgroup per CU; its 8 waves take the column blocks round-robin (wave w: w, w+8, ...), every
@@ -197,6 +207,7 @@ size_t em_mstats_scratch_doubles(int d, int K, int num_cus)
 
 int launch_em_mstats(const MstatsArgs& a, int num_cus, hipStream_t stream)
 {
+    if (a.d > kMaxDim) return launch_em_mstats_generic(a, stream);
     const Plan p = make_plan(a.d, a.K, num_cus);
     const uint32_t n_tiles = (a.n + TS - 1) / TS;
     int grid_x = p.grid_x;

@@ -290,6 +290,16 @@ int launch_kmeans_assign(const KmeansArgs& a_in, int num_cus, hipStream_t stream
     // (above d = 64 only the matrix-core kernel exists)
     if ((!force_valu || a_in.D > kMidDim) && kmeans_mfma_supported(a_in.D, a_in.K)) return launch_kmeans_mfma(a_in, num_cus, stream);
     const size_t pstride = 2 + (size_t)a_in.K * (3 * a_in.d + 1);
+    if (a_in.D > kMaxDim) {
+        // generic_dim.hip: plain assignment, update sums by the separate sweep
+        int grid = kmeans_grid(num_cus);
+        const uint32_t need = (a_in.n + 255) / 256;
+        if ((uint32_t)grid > need) grid = (int)(need ? need : 1);
+        if ((size_t)grid * pstride > a_in.partials_capacity) return -2;
+        launch_kmeans_assign_generic(a_in, grid, pstride, stream);
+        if (a_in.accumulate) launch_kmeans_update(a_in, grid, pstride, stream);
+        return grid;
+    }
     int grid = kmeans_grid(num_cus);
     const uint32_t bs = a_in.D <= kRegDim ? BS : BS_BIG;
     const uint32_t blocks_needed = (a_in.n + bs - 1) / bs;

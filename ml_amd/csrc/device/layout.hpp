@@ -25,6 +25,7 @@ constexpr double kDiagAbLimit = 64.0;
 /// s_setprio level of a wave while it streams matrix instructions (0 elsewhere): see em_estep_mfma4.hip.
 constexpr int kMatrixPhasePriority = 2;
 constexpr int kMaxDim = 128;
+constexpr int kGenericMaxDim = 4096;   // d > kMaxDim: correctness tier (device/generic_dim.hip)
 constexpr int kMidDim = 64;
 constexpr int kRegDim = 32;
 
@@ -34,7 +35,8 @@ inline int padded_dim(int d)
     static const int sizes[] = {1, 2, 3, 4, 6, 8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64, 72, 80, 88, 96, 104, 112, 120, 128};
     for (int s : sizes)
         if (d <= s) return s;
-    return -1;
+    // beyond kMaxDim: the plain kernels of generic_dim.hip (any multiple of 4; the bound keeps the packed-triangle indices in int)
+    return d <= kGenericMaxDim ? (d + 3) & ~3 : -1;
 }
 
 /// E-step parameter record of one component, PS(D) doubles:

@@ -56,7 +56,7 @@ mlhip_data* upload_common(mlhip_ctx* ctx, const double* x, bool on_device, uint3
     require(ld >= (int64_t)d, "ld must be >= d");
     require(n < 0xffffff00ull, "shard too large (n must fit 32 bits, like the reference's unsigned int)");
     const int D = padded_dim((int)d);
-    if (D < 0) throw Unsupported("dimension d > 128 is not supported by the register-resident kernels yet");
+    if (D < 0) throw Unsupported("dimension d > 4096 is not supported");
     ctx->use();
     auto* dt = new mlhip_data;
     try {

@@ -230,7 +230,7 @@ def test_bad_arguments(ctx):
     with pytest.raises(TypeError):
         _lib.Data(ctx, np.zeros((10, 3), dtype=np.float32))
     with pytest.raises(_lib.MlhipError):
-        _lib.Data(ctx, np.zeros((10, 129)))   # d > 128 unsupported (yet)
+        _lib.Data(ctx, np.zeros((10, 4097)))  # d > 4096 unsupported (129..4096: the plain kernels of generic_dim.hip)
     dt.close()
 
 

@@ -1,4 +1,4 @@
-"""Seeded random sweep over shapes (d = 1..128, K = 1..70, ragged N) comparing one E+M iteration, labels, sample covariance and
+"""Seeded random sweep over shapes (d = 1..128 and a few beyond, K = 1..70, ragged N) comparing one E+M iteration, labels, sample covariance and
 one K-means step of the HIP path against the CPU oracle -- exercises every kernel variant (padded dimensions, VALU / MFMA E-step,
 narrow / wide statistics kernels, K not a multiple of 16, tiles with a ragged tail). Needs a GPU: `pytest -m gpu`."""
 import numpy as np
@@ -19,7 +19,9 @@ def _cases():
         n = int(rng.integers(max(8 * K, 70), 2600))
         cases.append((d, K, n, int(rng.integers(1 << 30))))
     # many components; tiny samples (fewer rows than a tile, a wave, or the padded dimension)
-    for d, K, n in ((5, 200, 3000), (16, 130, 2100), (32, 257, 2600), (3, 2, 5), (16, 3, 17), (40, 2, 9), (8, 1, 2)):
+    # ... and dimensions beyond 128 (device/generic_dim.hip)
+    for d, K, n in ((5, 200, 3000), (16, 130, 2100), (32, 257, 2600), (3, 2, 5), (16, 3, 17), (40, 2, 9), (8, 1, 2), (140, 3, 700), (177, 17, 1500),
+                    (256, 2, 600), (131, 1, 300)):
         cases.append((d, K, n, int(rng.integers(1 << 30))))
     return cases
 
