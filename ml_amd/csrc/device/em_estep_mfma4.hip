@@ -271,7 +271,20 @@ int launch_sb(const EstepArgs& a, int num_cus, hipStream_t stream)
     const uint32_t n_pad = padded_samples(a.n);
     const uint32_t n_groups = n_pad / GS;
     uint32_t grid = (n_groups + NWV - 1) / NWV;
-    const uint32_t cap = (uint32_t)num_cus * 2 * default_waves<SB>() / NW;   // the CU's resident waves, persistent
+    uint32_t per_cu = 2 * default_waves<SB>() / NW;                          // the CU's resident workgroups, persistent
+    if constexpr (SB == 4 && D <= 24) {
+        // small d: a component is 6 - 21 blocks short, the per-component barrier and the epilogue weigh more, and the kernel needs
+        // few registers (92 - 160): as many workgroups per CU as fit, up to 4 [r3] (MLHIP_ESTEP_WGS=2: the two of larger d)
+        static const int fit = [] {
+            int blocks = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, em_estep_mfma4_kernel<D, SB, FOLD, LSE, NW>, NT, sizeof(double) * 2 * NLD * NT) != hipSuccess) blocks = 2;
+            const char* e = std::getenv("MLHIP_ESTEP_WGS");
+            const int want = e ? std::atoi(e) : 4;
+            return blocks < 2 ? 2 : (blocks > want ? want : blocks);
+        }();
+        if ((uint32_t)fit > per_cu) per_cu = (uint32_t)fit;
+    }
+    const uint32_t cap = (uint32_t)num_cus * per_cu;
     if (grid > cap) grid = cap;
     if (grid > (uint32_t)a.n_ll_partials) grid = (uint32_t)a.n_ll_partials;
     hipLaunchKernelGGL((em_estep_mfma4_kernel<D, SB, FOLD, LSE, NW>), dim3(grid), dim3(NT), smem, stream, a.xt, a.ldx, a.n, n_groups,
