@@ -272,9 +272,10 @@ int launch_sb(const EstepArgs& a, int num_cus, hipStream_t stream)
     const uint32_t n_groups = n_pad / GS;
     uint32_t grid = (n_groups + NWV - 1) / NWV;
     uint32_t per_cu = 2 * default_waves<SB>() / NW;                          // the CU's resident workgroups, persistent
-    if constexpr (SB == 4 && D <= 24) {
+    if constexpr (SB == 4 && D <= 20) {
         // small d: a component is 6 - 21 blocks short, the per-component barrier and the epilogue weigh more, and the kernel needs
-        // few registers (92 - 160): as many workgroups per CU as fit, up to 4 [r3] (MLHIP_ESTEP_WGS=2: the two of larger d)
+        // few registers (92 - 138): as many workgroups per CU as fit, up to 4 [r3] (MLHIP_ESTEP_WGS=2: the two of larger d; at d = 24
+        // three fit, the E-step gains 1 % and the statistics kernel behind it loses 2 %: not used there)
         static const int fit = [] {
             int blocks = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, em_estep_mfma4_kernel<D, SB, FOLD, LSE, NW>, NT, sizeof(double) * 2 * NLD * NT) != hipSuccess) blocks = 2;
