@@ -556,7 +556,17 @@ void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* mean
     const size_t n_pack = n_info + K + (size_t)K * d + n_cov;
     for (int b = 0; b < 3; ++b) data->it_pack[b].reserve(sizeof(double) * n_pack);
     data->it_info_host.reserve(sizeof(double) * n_pack);          // info, then (diagonal mode) a shadow of the newest parameters
-    auto pack_mixing = [&](int b) { return data->it_pack[b].as<double>() + n_info; };
+    // Full covariances: the closing kernel writes its 1 + 2K info doubles (log-likelihood sum, refinement flags, FOLD bounds) straight
+    // into pinned host memory -- no hipMemcpyAsync in the loop (one API call and one copy-engine round trip less per iteration).
+    // Diagonal mode: its whole pack (info + the K (2d + 1) parameters the host shadows every iteration, a few KB) lives in pinned
+    // memory. MLHIP_INFO_PINNED=0: device packs and the copy.
+    static const bool info_pinned_allowed = [] { const char* e = std::getenv("MLHIP_INFO_PINNED"); return !(e && e[0] == '0'); }();
+    const bool info_pinned = info_pinned_allowed && !diag;
+    const bool pack_pinned = info_pinned_allowed && diag;
+    if (pack_pinned)
+        for (int b = 0; b < 3; ++b) data->it_info_slot[b].reserve(sizeof(double) * n_pack);
+    auto pack_base = [&](int b) { return pack_pinned ? data->it_info_slot[b].as<double>() : data->it_pack[b].as<double>(); };
+    auto pack_mixing = [&](int b) { return pack_base(b) + n_info; };
     auto pack_means = [&](int b) { return pack_mixing(b) + K; };
     auto pack_covs = [&](int b) { return pack_means(b) + (size_t)K * d; };
     if (diag) {
@@ -581,11 +591,6 @@ void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* mean
 
     // One iteration's device work: E-step + statistics from the records in params_dev, all-reduce, closing arithmetic into
     // it_pack[out] and the next records into params_next. Nothing here waits for the device.
-    // Full covariances: the closing kernel writes its 1 + 2K info doubles (log-likelihood sum, refinement flags, FOLD bounds) straight
-    // into pinned host memory -- no hipMemcpyAsync in the loop (one API call and one copy-engine round trip less per iteration;
-    // MLHIP_INFO_PINNED=0: the copy). Diagonal mode reads its parameter shadow back with the info and keeps the copy.
-    static const bool info_pinned_allowed = [] { const char* e = std::getenv("MLHIP_INFO_PINNED"); return !(e && e[0] == '0'); }();
-    const bool info_pinned = info_pinned_allowed && !diag;
     auto launch_iteration = [&](int out, double* info_host) {
         if (diag) {
             run_diag_kernel(data, K, data->shift_dev.as<double>(), false);
@@ -604,7 +609,7 @@ void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* mean
         ca.layout = data->estep_variant; ca.refine_limit = limit;
         ca.mixing = pack_mixing(out); ca.means = pack_means(out);
         ca.covs = pack_covs(out); ca.records = data->params_next.as<double>();
-        ca.info = info_pinned ? info_host : data->it_pack[out].as<double>();
+        ca.info = info_pinned ? info_host : pack_base(out);
         ctx->timed("em_close", [&] { if (diag) launch_em_close_diag(ca, ctx->stream); else launch_em_close(ca, ctx->stream); });
         HIP_CHECK(hipGetLastError());
     };
@@ -644,7 +649,7 @@ void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* mean
         auto launch = [&](uint32_t i) {                          // iteration i: records R_i (params_dev) -> R_(i+1), pack (i+1) % 3
             const int out = (int)((i + 1) % 3);
             launch_iteration(out, data->it_info_slot[out].as<double>());
-            if (!info_pinned)
+            if (!info_pinned && !pack_pinned)
                 HIP_CHECK(hipMemcpyAsync(data->it_info_slot[out].p, data->it_pack[out].p, sizeof(double) * copy_doubles, hipMemcpyDeviceToHost,
                                          ctx->stream));
             HIP_CHECK(hipEventRecord(data->it_event[out], ctx->stream));
@@ -673,9 +678,9 @@ void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* mean
                 else std::swap(data->params_dev, data->params_prev);
                 if (i > 0) {
                     const int in = (int)(i % 3);
-                    HIP_CHECK(hipMemcpyAsync(mixing, pack_mixing(in), sizeof(double) * K, hipMemcpyDeviceToHost, ctx->stream));
-                    HIP_CHECK(hipMemcpyAsync(means, pack_means(in), sizeof(double) * K * d, hipMemcpyDeviceToHost, ctx->stream));
-                    HIP_CHECK(hipMemcpyAsync(covs, pack_covs(in), sizeof(double) * n_cov, hipMemcpyDeviceToHost, ctx->stream));
+                    HIP_CHECK(hipMemcpyAsync(mixing, pack_mixing(in), sizeof(double) * K, hipMemcpyDefault, ctx->stream));
+                    HIP_CHECK(hipMemcpyAsync(means, pack_means(in), sizeof(double) * K * d, hipMemcpyDefault, ctx->stream));
+                    HIP_CHECK(hipMemcpyAsync(covs, pack_covs(in), sizeof(double) * n_cov, hipMemcpyDefault, ctx->stream));
                     ctx->sync();
                 }
                 if (diag) {
@@ -700,9 +705,9 @@ void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* mean
             if (speculated) { std::swap(data->params_dev, data->params_next); data->lw_valid = false; }
             else std::swap(data->params_dev, data->params_prev);
             const int res = (int)((last + 1) % 3);               // P_(last+1): the newest parameters
-            HIP_CHECK(hipMemcpyAsync(mixing, pack_mixing(res), sizeof(double) * K, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_CHECK(hipMemcpyAsync(means, pack_means(res), sizeof(double) * K * d, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_CHECK(hipMemcpyAsync(covs, pack_covs(res), sizeof(double) * n_cov, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_CHECK(hipMemcpyAsync(mixing, pack_mixing(res), sizeof(double) * K, hipMemcpyDefault, ctx->stream));
+            HIP_CHECK(hipMemcpyAsync(means, pack_means(res), sizeof(double) * K * d, hipMemcpyDefault, ctx->stream));
+            HIP_CHECK(hipMemcpyAsync(covs, pack_covs(res), sizeof(double) * n_cov, hipMemcpyDefault, ctx->stream));
             ctx->sync();
             if (diag) {                                          // ensure_lw rebuilds the block from the inputs of the last E-step
                 const std::vector<double>& sh = shadow_of[last % 3];
@@ -720,7 +725,8 @@ void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* mean
         launch_iteration(nxt, info);
         // one read-back: the info block and, in diagonal mode (small), a host shadow of the newest parameters right behind it
         // (ensure_lw needs the inputs of the last E-step)
-        if (!info_pinned)
+        if (pack_pinned) { info = pack_base(nxt); shadow = info + n_info; }        // (read in place)
+        else if (!info_pinned)
             HIP_CHECK(hipMemcpyAsync(info, data->it_pack[nxt].p, sizeof(double) * (diag ? n_pack : n_info), hipMemcpyDeviceToHost, ctx->stream));
         ctx->sync();
         tr.mark("iteration (device close)");
@@ -773,9 +779,9 @@ void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* mean
     }
     // the caller's arrays receive the newest parameters; the device keeps the records of the LAST E-step in params_dev
     if (!latest_on_host) {
-        HIP_CHECK(hipMemcpyAsync(mixing, pack_mixing(cur), sizeof(double) * K, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_CHECK(hipMemcpyAsync(means, pack_means(cur), sizeof(double) * K * d, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_CHECK(hipMemcpyAsync(covs, pack_covs(cur), sizeof(double) * n_cov, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(mixing, pack_mixing(cur), sizeof(double) * K, hipMemcpyDefault, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(means, pack_means(cur), sizeof(double) * K * d, hipMemcpyDefault, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(covs, pack_covs(cur), sizeof(double) * n_cov, hipMemcpyDefault, ctx->stream));
         ctx->sync();
     }
     if (diag && !prev_mixing.empty()) {   // ensure_lw rebuilds the block from the inputs of the last E-step
