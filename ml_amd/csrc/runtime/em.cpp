@@ -626,8 +626,14 @@ void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* mean
     // once per fit (and the log-responsibilities it overwrote are rebuilt on demand), which a long iteration never earns back
     // (N = 10M, d = 8, K = 32: 2.2 ms per iteration against ~10 us saved per iteration).
     const double pair_work = (double)data->n * K * (diag ? d : d * d);
-    const bool lagged = lagged_allowed && data->estep_variant != 2 && (!ctx->reduce_fn || ctx->reduce_on_device) && max_steps >= 2 &&
-                        pair_work <= (diag ? 1.0e9 : 2.0e9);
+    // The matrix-core E-step (d >= 12) joins it in its EXACT form: the FOLD form is a per-iteration decision of the host (from the
+    // closing kernel's bound on |W (mu - shift)|), which a loop that does not wait for the host cannot take; the records carry both
+    // vectors, so no FOLD simply means a.fold = 0 (32 more subtractions per 64 samples and component at d = 32: a few per cent of
+    // an E-step that is short here by construction). MLHIP_LAGGED_WORK overrides the bound on N K d^2.
+    static const double work_limit = [] { const char* e = std::getenv("MLHIP_LAGGED_WORK"); return e ? std::atof(e) : 2.0e9; }();
+    const bool lagged = lagged_allowed && (!ctx->reduce_fn || ctx->reduce_on_device) && max_steps >= 2 &&
+                        pair_work <= (diag ? 1.0e9 : work_limit);
+    if (lagged && !diag && data->estep_variant == 2) data->estep_fold = false;
     uint32_t first_sync_step = 0;
     if (lagged) {
         const size_t copy_doubles = diag ? n_pack : n_info;

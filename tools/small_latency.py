@@ -7,7 +7,7 @@ from ml_amd import _lib, synth
 
 out = {}
 ctx = _lib.Context()
-for n, d, K in ((10_000, 4, 3), (100_000, 8, 8), (1_000_000, 16, 16)):
+for n, d, K in ((10_000, 4, 3), (100_000, 8, 8), (100_000, 16, 8), (20_000, 32, 4), (1_000_000, 16, 16)):
     mix = synth.Mixture(d, K, seed=3)
     X, _ = mix.sample(n)
     dt = _lib.Data(ctx, X)
