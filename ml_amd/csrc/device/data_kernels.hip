@@ -138,7 +138,134 @@ __global__ __launch_bounds__(128) void random_partition_kernel(const double* __r
     if (threadIdx.x == 0) sizes[k] = count0 + (double)(hi - lo);   // (= the count every chain ended with: integers, exact)
 }
 
+// ---- K-means++ draw on the device (KPP::init, reference ML/Clustering.cpp:39-59) ----------------------------------------------
+// std::discrete_distribution turns the N weights into p_i = w_i / sum (sum: a sequential floating-point sum), their sequential
+// cumulative sums cp_i, and returns the first i with cp_i >= u (the last one forced to 1). The sequential sums cannot be
+// reproduced in parallel bit for bit -- but the INDEX can be certified: every quantity involved is a sum of non-negative terms
+// bounded by 1, so |cp_i - c~_i| <= delta = (4 N + 16384) 2^-53 for the tree-summed c~_i formed here, whatever the order. With
+// lo = first i with c~_i >= u - delta and hi = first i with c~_i >= u + delta the reference's index lies in [lo, hi]; lo == hi
+// (all but ~2 delta N of the draws) settles it, otherwise the caller evaluates the reference's sequential sums on the host.
+constexpr int kKppChunk = 4096;   // weights per workgroup
+
+/// weights = first ? dist : min(weights, dist); block sums of the new weights (fixed-order tree).
+__global__ __launch_bounds__(256) void kpp_update_kernel(double* __restrict__ weights, const double* __restrict__ dist, uint32_t n,
+                                                          int first, double* __restrict__ bsum)
+{
+    __shared__ double red[256];
+    const uint32_t base = blockIdx.x * (uint32_t)kKppChunk;
+    double acc = 0.0;
+#pragma unroll 4
+    for (int t = 0; t < kKppChunk / 256; ++t) {
+        const uint32_t i = base + t * 256u + threadIdx.x;
+        if (i < n) {
+            const double dv = dist[i];
+            const double w = first ? dv : fmin(weights[i], dv);
+            weights[i] = w;
+            acc += w;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bsum[blockIdx.x] = red[0];
+}
+
+/// Exclusive prefix of the block sums (one workgroup, 1024 sums per trip) and the total: out[0] = sum, out[1] = lo, out[2] = hi
+/// (the latter two initialised to n - 1, as doubles: exact below 2^53).
+__global__ __launch_bounds__(1024) void kpp_scan_kernel(const double* __restrict__ bsum, int nb, double* __restrict__ boff, uint32_t n,
+                                                         double* __restrict__ out)
+{
+    __shared__ double buf[1024];
+    double carry = 0.0;
+    for (int b0 = 0; b0 < nb; b0 += 1024) {
+        const int b = b0 + threadIdx.x;
+        const double v = b < nb ? bsum[b] : 0.0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {                     // inclusive Hillis-Steele scan
+            const double add = (int)threadIdx.x >= off ? buf[threadIdx.x - off] : 0.0;
+            __syncthreads();
+            buf[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (b < nb) boff[b] = carry + (buf[threadIdx.x] - v);
+        const double total = buf[1023];
+        __syncthreads();
+        carry += total;
+    }
+    if (threadIdx.x == 0) {
+        out[0] = carry;
+        out[1] = out[2] = (double)(n - 1);
+    }
+}
+
+__device__ __forceinline__ void atomic_min_index(double* slot, uint32_t i)
+{
+    // indices are stored as doubles (exact); their bit patterns order like the values for non-negative doubles
+    atomicMin(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)__double_as_longlong((double)i));
+}
+
+/// lo / hi over the rows i <= n - 2 (see above); u and delta are scaled by the total, so no division per row.
+__global__ __launch_bounds__(256) void kpp_find_kernel(const double* __restrict__ weights, uint32_t n, const double* __restrict__ bsum,
+                                                        const double* __restrict__ boff, double u, double delta, double* __restrict__ out)
+{
+    __shared__ double pre[256];
+    const double total = out[0];
+    const double t_lo = (u - delta) * total, t_hi = (u + delta) * total;       // thresholds on the unnormalised prefix sums
+    const double slack = 4.0 * kKppChunk * 0x1p-53 * total;
+    const uint32_t base = blockIdx.x * (uint32_t)kKppChunk;
+    const double b_lo = boff[blockIdx.x], b_hi = b_lo + bsum[blockIdx.x];
+    if (base >= n - 1) return;                                                 // only the forced last row (or nothing) here
+    if (b_hi + slack < t_lo) return;                                           // every prefix of this chunk is below both thresholds
+    if (b_lo - slack > t_hi) {                                                 // every prefix is above both: the chunk's first row
+        if (threadIdx.x == 0) { atomic_min_index(out + 1, base); atomic_min_index(out + 2, base); }
+        return;
+    }
+    // 16 consecutive rows per thread; exclusive prefix over the 256 thread sums, then every thread walks its rows
+    constexpr int PER = kKppChunk / 256;
+    const uint32_t first = base + threadIdx.x * PER;
+    double w[PER], acc = 0.0;
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        w[t] = first + t < n ? weights[first + t] : 0.0;
+        acc += w[t];
+    }
+    pre[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const double add = (int)threadIdx.x >= off ? pre[threadIdx.x - off] : 0.0;
+        __syncthreads();
+        pre[threadIdx.x] += add;
+        __syncthreads();
+    }
+    double c = b_lo + (pre[threadIdx.x] - acc);
+    bool seen_lo = false;
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const uint32_t i = first + t;
+        c += w[t];
+        if (i + 1 < n) {                                                       // rows 0 .. n-2 (the last one is the default)
+            if (!seen_lo && c >= t_lo) { atomic_min_index(out + 1, i); seen_lo = true; }
+            if (c >= t_hi) { atomic_min_index(out + 2, i); break; }
+        }
+    }
+}
+
 }  // namespace
+
+int kpp_blocks(uint32_t n) { return (int)((n + kKppChunk - 1) / kKppChunk); }
+
+void launch_kpp_draw(double* weights, const double* dist, uint32_t n, int first, double u, double delta, double* bsum, double* boff,
+                     double* out, hipStream_t stream)
+{
+    const int nb = kpp_blocks(n);
+    hipLaunchKernelGGL(kpp_update_kernel, dim3(nb), dim3(256), 0, stream, weights, dist, n, first, bsum);
+    hipLaunchKernelGGL(kpp_scan_kernel, dim3(1), dim3(1024), 0, stream, bsum, nb, boff, n, out);
+    hipLaunchKernelGGL(kpp_find_kernel, dim3(nb), dim3(256), 0, stream, weights, n, bsum, boff, u, delta, out);
+}
 
 void launch_random_partition(const double* xt, size_t ldx, int d, int K, const uint32_t* order, const uint32_t* offsets,
                              double* means, double* sizes, hipStream_t stream)

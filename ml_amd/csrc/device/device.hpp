@@ -24,6 +24,13 @@ void launch_column_sums(const double* xt, size_t ldx, int d, uint64_t n, double*
 void launch_random_partition(const double* xt, size_t ldx, int d, int K, const uint32_t* order, const uint32_t* offsets,
                              double* means, double* sizes, hipStream_t stream);
 
+/// One K-means++ draw on the device (data_kernels.hip): weights = first ? dist : min(weights, dist) over n rows, then the bounds
+/// [lo, hi] of the row std::discrete_distribution would return for the canonical uniform u: out[0] = sum of the weights, out[1] = lo,
+/// out[2] = hi (as doubles). bsum / boff: kpp_blocks(n) doubles of scratch each.
+int kpp_blocks(uint32_t n);
+void launch_kpp_draw(double* weights, const double* dist, uint32_t n, int first, double u, double delta, double* bsum, double* boff,
+                     double* out, hipStream_t stream);
+
 // ---- EM ----------------------------------------------------------------------------------------------
 struct EstepArgs {
     const double* xt; size_t ldx; uint32_t n; int D;      // D = padded dimension

@@ -242,8 +242,45 @@ void init_centroids(const CentroidsInitialiser& initialiser, ConstMatrixRef data
     // cumulative scan stops at the drawn index.
     const Index n = data.cols(), d = data.rows();
     const std::size_t count = static_cast<std::size_t>(n);
-    std::vector<double> weights(count, 1.0), latest;
+    // Large samples: the draw itself on the device (mlhip_kpp_draw) -- the running-minimum weights never leave it, and the index
+    // is certified against the reference's sequential sums by an error bound; only a draw that falls between two rows closer
+    // than that bound (about 8 N^2 2^-53 of them) comes back for the sequential evaluation below. The N-long host passes per
+    // centroid were 50x the K-means iterations they prepare at N = 1M, K = 64.
+    const bool device_draw = count >= 32768;
+    std::vector<double> weights(device_draw ? 0 : count, 1.0), latest;
     for (unsigned int chosen = 0; chosen < number_components; ++chosen) {
+        if (device_draw) {
+            std::size_t pick = count - 1;
+            const double p = std::generate_canonical<double, std::numeric_limits<double>::digits>(prng);
+            if (chosen == 0) {
+                // all weights 1: sum = N exactly, p_i = fl(1 / N), cp_i = the sequential sum of i + 1 of them
+                const double q = 1.0 / static_cast<double>(count);
+                double cumulative = 0.0;
+                for (std::size_t i = 0; i + 1 < count; ++i) {
+                    cumulative += q;
+                    if (cumulative >= p) { pick = i; break; }
+                }
+            } else {
+                uint64_t index = 0;
+                int certain = 0;
+                weights.resize(count);
+                device::check(mlhip_kpp_draw(ctx, device_data, centroids.col(chosen - 1), chosen == 1 ? 1 : 0, p, &index, &certain,
+                                             weights.data()));
+                if (certain) {
+                    pick = static_cast<std::size_t>(index);
+                } else {
+                    double sum = 0.0;
+                    for (std::size_t i = 0; i < count; ++i) sum += weights[i];
+                    double cumulative = 0.0;
+                    for (std::size_t i = 0; i + 1 < count; ++i) {
+                        cumulative += weights[i] / sum;
+                        if (cumulative >= p) { pick = i; break; }
+                    }
+                }
+            }
+            std::copy_n(data.col(static_cast<Index>(pick)), d, centroids.col(chosen));
+            continue;
+        }
         double sum = 0.0;
         if (chosen == 0) {
             sum = static_cast<double>(count);     // == the sequential sum of `count` ones (exact below 2^53)

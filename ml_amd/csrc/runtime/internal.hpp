@@ -283,13 +283,14 @@ struct mlhip_data {
     // K-means workspace
     DevBuf km_labels[2], km_cent, km_cent_next, km_partials, km_out, km_mind, km_probe, km_scale, km_cnorm, km_xt_pad;
     PinnedBuf km_host;
+    DevBuf kpp_w, kpp_scr;               // mlhip_kpp_draw: the running-minimum weights, block sums / offsets / result
     int km_cur = 0;
     bool km_have_old = false;
 
     ~mlhip_data()
     {
         for (DevBuf* b : {&xt, &shift_dev, &lw, &lse, &esum, &ll_partials, &params_dev, &partials, &stats_dev, &resp_dev,
-                          &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_cent_next, &km_partials, &km_out, &km_mind, &km_probe, &km_scale, &km_cnorm, &km_xt_pad,
+                          &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_cent_next, &km_partials, &km_out, &km_mind, &km_probe, &km_scale, &km_cnorm, &km_xt_pad, &kpp_w, &kpp_scr,
                           &refine_shift, &refine_stats, &params_next, &params_prev, &it_pack[0], &it_pack[1], &it_pack[2]})
             b->release();
         it_info_host.release();

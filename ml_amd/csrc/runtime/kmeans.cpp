@@ -1,4 +1,6 @@
 // K-means family of the C ABI: assignment + exact update sums per step, the step loop of KMeans::fit_once in one call.
+#include <cmath>
+
 #include "internal.hpp"
 
 namespace mlhip_rt {
@@ -288,6 +290,49 @@ int mlhip_kmeans_distances(mlhip_ctx* ctx, mlhip_data* data, double* dist2)
         require(data->km_have_old, "no K-means assignment on the device yet");
         ctx->sync();
         download_columns(ctx, reinterpret_cast<char*>(dist2), 0, data->km_mind.as<char>(), 0, sizeof(double) * data->n, 1);
+    });
+}
+
+int mlhip_kpp_draw(mlhip_ctx* ctx, mlhip_data* data, const double* centroid, int first, double u, uint64_t* index, int* certain,
+                   double* weights_out)
+{
+    return guarded([&] {
+        check_em_args(ctx, data, 1);
+        require(centroid && index && certain, "null argument");
+        require(data->n >= 2, "at least two rows");
+        require(u >= 0.0 && u < 1.0, "u must be a canonical uniform draw");
+        // distances to the new centroid -> km_probe (as mlhip_min_squared_distances, label history untouched)
+        const int cur = data->km_cur;
+        const bool have = data->km_have_old;
+        data->km_probe.reserve(sizeof(double) * data->n_pad);
+        const KmBlock b = km_block(data, 1);
+        km_upload_centroids(data, 1, b, centroid);
+        km_launch(data, 1, b, false, data->km_probe.as<double>());
+        if (have) data->km_cur = cur;
+        data->km_have_old = have;
+        const int nb = kpp_blocks(data->n);
+        data->kpp_w.reserve(sizeof(double) * data->n_pad);
+        data->kpp_scr.reserve(sizeof(double) * (2 * (size_t)nb + 4));
+        double* bsum = data->kpp_scr.as<double>();
+        double* boff = bsum + nb;
+        double* out = boff + nb;
+        // |cp_i - c~_i| <= (4 N + 16384) 2^-53 (data_kernels.hip); MLHIP_KPP_DELTA_SCALE widens it (tests: forces the host path)
+        static const double scale = [] { const char* e = std::getenv("MLHIP_KPP_DELTA_SCALE"); return e ? std::atof(e) : 1.0; }();
+        const double delta = scale * (4.0 * (double)data->n + 16384.0) * 0x1p-53;
+        ctx->timed("kpp_draw", [&] {
+            launch_kpp_draw(data->kpp_w.as<double>(), data->km_probe.as<double>(), data->n, first ? 1 : 0, u, delta, bsum, boff, out,
+                            ctx->stream);
+        });
+        HIP_CHECK(hipGetLastError());
+        double* res = data->km_host.as<double>();
+        HIP_CHECK(hipMemcpyAsync(res, out, sizeof(double) * 3, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->sync();
+        const bool ok = std::isfinite(res[0]) && res[0] > 0.0 && res[1] == res[2];
+        *certain = ok ? 1 : 0;
+        *index = ok ? (uint64_t)res[1] : 0;
+        if (!ok && weights_out) {
+            download_columns(ctx, reinterpret_cast<char*>(weights_out), 0, data->kpp_w.as<char>(), 0, sizeof(double) * data->n, 1);
+        }
     });
 }
 

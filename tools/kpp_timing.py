@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Wall time of KMeans.fit with the K-means++ initialiser (2 Lloyd steps): the initialiser dominates. MLHIP_KPP_DELTA_SCALE=1e9
+forces every draw back to the host's sequential sums (the path before mlhip_kpp_draw)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ml_amd.cppyml import clustering as cl
+from ml_amd import synth
+
+scale = os.environ.get("MLHIP_KPP_DELTA_SCALE", "1")
+for n, d, K in ((1_000_000, 8, 64), (12_500_000, 8, 64)):
+    X, _ = synth.Mixture(d, K, seed=3).sample(n)
+    for rep in range(2):
+        km = cl.KMeans(K)
+        km.set_centroids_initialiser(cl.KPP())
+        km.set_seed(5)
+        km.set_maximum_steps(2)
+        t0 = time.perf_counter()
+        km.fit(X)
+        t = time.perf_counter() - t0
+    print("N=%d d=%d K=%d: KMeans.fit with KPP, 2 steps: %.1f ms (bound scale %s)" % (n, d, K, t * 1e3, scale))
