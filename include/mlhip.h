@@ -209,13 +209,16 @@ int mlhip_kmeans_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t* labels);
 /* Per-sample squared distance to the assigned centroid from the last assignment (n_local doubles): the very values
  * KMeans::assign_label returns (:153-165), so a caller can re-create the reference's sequential inertia sum (:176). */
 int mlhip_kmeans_distances(mlhip_ctx* ctx, mlhip_data* data, double* dist2);
-/* One draw of KPP::init (ML/Clustering.cpp:44-58) on the resident block, single rank: the weights become min(weights, |x_i - centroid|^2)
+/* One draw of KPP::init (ML/Clustering.cpp:44-58) on the resident block(s): the weights become min(weights, |x_i - centroid|^2)
  * (first != 0: the distances themselves), and the row that std::discrete_distribution returns for the canonical uniform draw u is
- * located from tree-summed cumulative weights with a rigorous error bound. *certain != 0: *index is that row, bit for bit what the
- * sequential sums of the reference give. *certain == 0 (two rows closer than the bound, or a zero / non-finite weight sum): the
- * weights have been copied to weights_out (n doubles; may be NULL) for the caller's sequential evaluation. n >= 2. */
-int mlhip_kpp_draw(mlhip_ctx* ctx, mlhip_data* data, const double* centroid, int first, double u, uint64_t* index, int* certain,
-                   double* weights_out);
+ * located from tree-summed cumulative weights with a rigorous error bound. Row-sharded jobs: every rank calls it with the same
+ * centroid and u and the global index of its first row (first_row; 0 on a single rank); the ranks exchange their weight sums and
+ * candidates through the context's all-reduce. *certain != 0: *index is that row of the WHOLE sample, bit for bit what the
+ * sequential sums of the reference give (the same on every rank). *certain == 0 (two rows closer than the bound, or a zero /
+ * non-finite weight sum): this rank's weights have been copied to weights_out (n_local doubles; may be NULL) for the caller's
+ * sequential evaluation. At least two rows in the whole sample. */
+int mlhip_kpp_draw(mlhip_ctx* ctx, mlhip_data* data, const double* centroid, int first, double u, uint64_t first_row, uint64_t* index,
+                   int* certain, double* weights_out);
 /* min_k |x_i - c_k|^2 per sample of this rank's shard (the weights of KPP::init, ML/Clustering.cpp:44-51). */
 int mlhip_min_squared_distances(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* centroids, double* dist2);
 

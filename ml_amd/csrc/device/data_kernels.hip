@@ -174,9 +174,9 @@ __global__ __launch_bounds__(256) void kpp_update_kernel(double* __restrict__ we
 }
 
 /// Exclusive prefix of the block sums (one workgroup, 1024 sums per trip) and the total: out[0] = sum, out[1] = lo, out[2] = hi
-/// (the latter two initialised to n - 1, as doubles: exact below 2^53).
-__global__ __launch_bounds__(1024) void kpp_scan_kernel(const double* __restrict__ bsum, int nb, double* __restrict__ boff, uint32_t n,
-                                                         double* __restrict__ out)
+/// (the latter two initialised to the last row of the WHOLE sample, as doubles: exact below 2^53).
+__global__ __launch_bounds__(1024) void kpp_scan_kernel(const double* __restrict__ bsum, int nb, double* __restrict__ boff,
+                                                         double default_index, double* __restrict__ out)
 {
     __shared__ double buf[1024];
     double carry = 0.0;
@@ -198,30 +198,32 @@ __global__ __launch_bounds__(1024) void kpp_scan_kernel(const double* __restrict
     }
     if (threadIdx.x == 0) {
         out[0] = carry;
-        out[1] = out[2] = (double)(n - 1);
+        out[1] = out[2] = default_index;
     }
 }
 
-__device__ __forceinline__ void atomic_min_index(double* slot, uint32_t i)
+__device__ __forceinline__ void atomic_min_index(double* slot, uint64_t i)
 {
     // indices are stored as doubles (exact); their bit patterns order like the values for non-negative doubles
     atomicMin(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)__double_as_longlong((double)i));
 }
 
-/// lo / hi over the rows i <= n - 2 (see above); u and delta are scaled by the total, so no division per row.
+/// lo / hi over the rows of this block (global indices row0 + i; the last row of the whole sample is the default and never a
+/// candidate). `offset`: the weight sum of the ranks before this one, `total`: that of all ranks (single rank: 0 and out[0]);
+/// u and delta are scaled by the total, so there is no division per row.
 __global__ __launch_bounds__(256) void kpp_find_kernel(const double* __restrict__ weights, uint32_t n, const double* __restrict__ bsum,
-                                                        const double* __restrict__ boff, double u, double delta, double* __restrict__ out)
+                                                        const double* __restrict__ boff, double offset, double total, double u, double delta,
+                                                        uint64_t row0, uint64_t n_global, double* __restrict__ out)
 {
     __shared__ double pre[256];
-    const double total = out[0];
     const double t_lo = (u - delta) * total, t_hi = (u + delta) * total;       // thresholds on the unnormalised prefix sums
     const double slack = 4.0 * kKppChunk * 0x1p-53 * total;
     const uint32_t base = blockIdx.x * (uint32_t)kKppChunk;
-    const double b_lo = boff[blockIdx.x], b_hi = b_lo + bsum[blockIdx.x];
-    if (base >= n - 1) return;                                                 // only the forced last row (or nothing) here
+    const double b_lo = offset + boff[blockIdx.x], b_hi = b_lo + bsum[blockIdx.x];
+    if (base >= n || row0 + base + 1 >= n_global) return;                      // only the forced last row (or nothing) here
     if (b_hi + slack < t_lo) return;                                           // every prefix of this chunk is below both thresholds
     if (b_lo - slack > t_hi) {                                                 // every prefix is above both: the chunk's first row
-        if (threadIdx.x == 0) { atomic_min_index(out + 1, base); atomic_min_index(out + 2, base); }
+        if (threadIdx.x == 0) { atomic_min_index(out + 1, row0 + base); atomic_min_index(out + 2, row0 + base); }
         return;
     }
     // 16 consecutive rows per thread; exclusive prefix over the 256 thread sums, then every thread walks its rows
@@ -247,9 +249,9 @@ __global__ __launch_bounds__(256) void kpp_find_kernel(const double* __restrict_
     for (int t = 0; t < PER; ++t) {
         const uint32_t i = first + t;
         c += w[t];
-        if (i + 1 < n) {                                                       // rows 0 .. n-2 (the last one is the default)
-            if (!seen_lo && c >= t_lo) { atomic_min_index(out + 1, i); seen_lo = true; }
-            if (c >= t_hi) { atomic_min_index(out + 2, i); break; }
+        if (i < n && row0 + i + 1 < n_global) {                                // (the last row of the sample is the default)
+            if (!seen_lo && c >= t_lo) { atomic_min_index(out + 1, row0 + i); seen_lo = true; }
+            if (c >= t_hi) { atomic_min_index(out + 2, row0 + i); break; }
         }
     }
 }
@@ -258,13 +260,20 @@ __global__ __launch_bounds__(256) void kpp_find_kernel(const double* __restrict_
 
 int kpp_blocks(uint32_t n) { return (int)((n + kKppChunk - 1) / kKppChunk); }
 
-void launch_kpp_draw(double* weights, const double* dist, uint32_t n, int first, double u, double delta, double* bsum, double* boff,
-                     double* out, hipStream_t stream)
+void launch_kpp_update(double* weights, const double* dist, uint32_t n, int first, double default_index, double* bsum, double* boff,
+                       double* out, hipStream_t stream)
 {
     const int nb = kpp_blocks(n);
-    hipLaunchKernelGGL(kpp_update_kernel, dim3(nb), dim3(256), 0, stream, weights, dist, n, first, bsum);
-    hipLaunchKernelGGL(kpp_scan_kernel, dim3(1), dim3(1024), 0, stream, bsum, nb, boff, n, out);
-    hipLaunchKernelGGL(kpp_find_kernel, dim3(nb), dim3(256), 0, stream, weights, n, bsum, boff, u, delta, out);
+    if (nb > 0) hipLaunchKernelGGL(kpp_update_kernel, dim3(nb), dim3(256), 0, stream, weights, dist, n, first, bsum);   // (an empty shard: sum 0)
+    hipLaunchKernelGGL(kpp_scan_kernel, dim3(1), dim3(1024), 0, stream, bsum, nb, boff, default_index, out);
+}
+
+void launch_kpp_find(const double* weights, uint32_t n, const double* bsum, const double* boff, double offset, double total, double u,
+                     double delta, uint64_t row0, uint64_t n_global, double* out, hipStream_t stream)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(kpp_find_kernel, dim3(kpp_blocks(n)), dim3(256), 0, stream, weights, n, bsum, boff, offset, total, u, delta, row0,
+                       n_global, out);
 }
 
 void launch_random_partition(const double* xt, size_t ldx, int d, int K, const uint32_t* order, const uint32_t* offsets,

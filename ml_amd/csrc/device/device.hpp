@@ -24,12 +24,17 @@ void launch_column_sums(const double* xt, size_t ldx, int d, uint64_t n, double*
 void launch_random_partition(const double* xt, size_t ldx, int d, int K, const uint32_t* order, const uint32_t* offsets,
                              double* means, double* sizes, hipStream_t stream);
 
-/// One K-means++ draw on the device (data_kernels.hip): weights = first ? dist : min(weights, dist) over n rows, then the bounds
-/// [lo, hi] of the row std::discrete_distribution would return for the canonical uniform u: out[0] = sum of the weights, out[1] = lo,
-/// out[2] = hi (as doubles). bsum / boff: kpp_blocks(n) doubles of scratch each.
+/// One K-means++ draw on the device (data_kernels.hip), in two launches around the ranks' exchange of their weight sums:
+/// update: weights = first ? dist : min(weights, dist) over this rank's n rows, block sums / offsets, out[0] = this rank's sum,
+///         out[1] = out[2] = default_index (the last row of the whole sample);
+/// find:   the bounds [lo, hi] (global row indices, out[1] / out[2], as doubles) of the row std::discrete_distribution would return
+///         for the canonical uniform u, given the sum of the ranks before this one (offset) and of all ranks (total).
+/// bsum / boff: kpp_blocks(n) doubles of scratch each.
 int kpp_blocks(uint32_t n);
-void launch_kpp_draw(double* weights, const double* dist, uint32_t n, int first, double u, double delta, double* bsum, double* boff,
-                     double* out, hipStream_t stream);
+void launch_kpp_update(double* weights, const double* dist, uint32_t n, int first, double default_index, double* bsum, double* boff,
+                       double* out, hipStream_t stream);
+void launch_kpp_find(const double* weights, uint32_t n, const double* bsum, const double* boff, double offset, double total, double u,
+                     double delta, uint64_t row0, uint64_t n_global, double* out, hipStream_t stream);
 
 // ---- EM ----------------------------------------------------------------------------------------------
 struct EstepArgs {

@@ -144,7 +144,68 @@ void kpp_sharded(const Shard& sh, ConstMatrixRef data, std::default_random_engin
     const std::size_t count = static_cast<std::size_t>(data.cols());
     std::vector<double> weights(count, 1.0), latest;
     std::vector<double> pick(static_cast<std::size_t>(d));
+    // The sequential evaluation over the rank-ordered rows: sum = ((0 + w_0) + w_1) + ..., then the cumulative probabilities up to
+    // the drawn one, the ranks taking turns.
+    auto sequential_pick = [&](double p) {
+        double sum = 0.0;
+        for (int r = 0; r < sh.world; ++r) {
+            if (r == sh.rank)
+                for (std::size_t i = 0; i < count; ++i) sum += weights[i];
+            broadcast_from(ctx, r, sh.rank, &sum, 1);
+        }
+        double carry[2] = {0.0, 0.0};              // [cumulative probability so far, found flag]
+        for (int r = 0; r < sh.world; ++r) {
+            if (r == sh.rank && carry[1] == 0.0) {
+                double cumulative = carry[0];
+                for (std::size_t i = 0; i < count; ++i) {
+                    if (sh.lo + static_cast<Index>(i) == sh.n_global - 1) {   // the last probability is forced to 1
+                        carry[1] = 1.0;
+                        std::copy_n(data.col(static_cast<Index>(i)), d, pick.data());
+                        break;
+                    }
+                    cumulative += weights[i] / sum;
+                    if (cumulative >= p) {
+                        carry[1] = 1.0;
+                        std::copy_n(data.col(static_cast<Index>(i)), d, pick.data());
+                        break;
+                    }
+                }
+                carry[0] = cumulative;
+            }
+            broadcast_from(ctx, r, sh.rank, carry, 2);
+        }
+    };
+    // Large samples: the draws on the devices (mlhip_kpp_draw: certified index, see the single-rank route below); the ranks'
+    // weights stay on their devices unless a draw has to be settled by the sequential evaluation.
+    const bool device_draw = sh.n_global >= 32768;
     for (unsigned int chosen = 0; chosen < K; ++chosen) {
+        if (device_draw) {
+            std::fill(pick.begin(), pick.end(), 0.0);
+            const double p = std::generate_canonical<double, std::numeric_limits<double>::digits>(prng);
+            Index global = sh.n_global - 1;
+            bool settled = true;
+            if (chosen == 0) {
+                // all weights 1: sum = N exactly, p_i = fl(1 / N), cp_i = the sequential sum of i + 1 of them (every rank runs it)
+                const double q = 1.0 / static_cast<double>(sh.n_global);
+                double cumulative = 0.0;
+                for (Index i = 0; i + 1 < sh.n_global; ++i) {
+                    cumulative += q;
+                    if (cumulative >= p) { global = i; break; }
+                }
+            } else {
+                uint64_t index = 0;
+                int certain = 0;
+                weights.resize(count);
+                device::check(mlhip_kpp_draw(ctx, device_data, centroids.col(chosen - 1), chosen == 1 ? 1 : 0, p,
+                                             static_cast<uint64_t>(sh.lo), &index, &certain, weights.data()));
+                if (certain) global = static_cast<Index>(index);
+                else { sequential_pick(p); settled = false; }          // (every rank got the same verdict)
+            }
+            if (settled && global >= sh.lo && global < sh.hi) std::copy_n(data.col(global - sh.lo), d, pick.data());
+            device::check(mlhip_ctx_allreduce(ctx, pick.data(), pick.size()));   // only the owner's copy is non-zero
+            std::copy_n(pick.data(), d, centroids.col(chosen));
+            continue;
+        }
         if (chosen > 0) {
             std::vector<double>& target = chosen == 1 ? weights : latest;
             target.resize(count);
@@ -152,37 +213,10 @@ void kpp_sharded(const Shard& sh, ConstMatrixRef data, std::default_random_engin
             if (chosen > 1)
                 for (std::size_t i = 0; i < count; ++i) weights[i] = std::min(weights[i], latest[i]);
         }
-        // sum = ((0 + w_0) + w_1) + ... over all rows in order
-        double sum = 0.0;
-        for (int r = 0; r < sh.world; ++r) {
-            if (r == sh.rank)
-                for (std::size_t i = 0; i < count; ++i) sum += weights[i];
-            broadcast_from(ctx, r, sh.rank, &sum, 1);
-        }
         std::fill(pick.begin(), pick.end(), 0.0);
         if (sh.n_global >= 2) {
             const double p = std::generate_canonical<double, std::numeric_limits<double>::digits>(prng);
-            double carry[2] = {0.0, 0.0};              // [cumulative probability so far, found flag]
-            for (int r = 0; r < sh.world; ++r) {
-                if (r == sh.rank && carry[1] == 0.0) {
-                    double cumulative = carry[0];
-                    for (std::size_t i = 0; i < count; ++i) {
-                        if (sh.lo + static_cast<Index>(i) == sh.n_global - 1) {   // the last probability is forced to 1
-                            carry[1] = 1.0;
-                            std::copy_n(data.col(static_cast<Index>(i)), d, pick.data());
-                            break;
-                        }
-                        cumulative += weights[i] / sum;
-                        if (cumulative >= p) {
-                            carry[1] = 1.0;
-                            std::copy_n(data.col(static_cast<Index>(i)), d, pick.data());
-                            break;
-                        }
-                    }
-                    carry[0] = cumulative;
-                }
-                broadcast_from(ctx, r, sh.rank, carry, 2);
-            }
+            sequential_pick(p);
         } else if (sh.lo == 0 && count > 0) {
             std::copy_n(data.col(0), d, pick.data());   // fewer than two weights: index 0, no draw (bits/random.tcc)
         }
@@ -264,7 +298,7 @@ void init_centroids(const CentroidsInitialiser& initialiser, ConstMatrixRef data
                 uint64_t index = 0;
                 int certain = 0;
                 weights.resize(count);
-                device::check(mlhip_kpp_draw(ctx, device_data, centroids.col(chosen - 1), chosen == 1 ? 1 : 0, p, &index, &certain,
+                device::check(mlhip_kpp_draw(ctx, device_data, centroids.col(chosen - 1), chosen == 1 ? 1 : 0, p, 0, &index, &certain,
                                              weights.data()));
                 if (certain) {
                     pick = static_cast<std::size_t>(index);

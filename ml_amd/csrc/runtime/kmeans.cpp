@@ -1,5 +1,6 @@
 // K-means family of the C ABI: assignment + exact update sums per step, the step loop of KMeans::fit_once in one call.
 #include <cmath>
+#include <vector>
 
 #include "internal.hpp"
 
@@ -293,14 +294,16 @@ int mlhip_kmeans_distances(mlhip_ctx* ctx, mlhip_data* data, double* dist2)
     });
 }
 
-int mlhip_kpp_draw(mlhip_ctx* ctx, mlhip_data* data, const double* centroid, int first, double u, uint64_t* index, int* certain,
-                   double* weights_out)
+int mlhip_kpp_draw(mlhip_ctx* ctx, mlhip_data* data, const double* centroid, int first, double u, uint64_t first_row, uint64_t* index,
+                   int* certain, double* weights_out)
 {
     return guarded([&] {
         check_em_args(ctx, data, 1);
         require(centroid && index && certain, "null argument");
-        require(data->n >= 2, "at least two rows");
+        require(data->n_global >= 2, "at least two rows");
         require(u >= 0.0 && u < 1.0, "u must be a canonical uniform draw");
+        const uint64_t n_global = data->n_global;
+        require(first_row + data->n <= n_global, "first_row beyond the sample");
         // distances to the new centroid -> km_probe (as mlhip_min_squared_distances, label history untouched)
         const int cur = data->km_cur;
         const bool have = data->km_have_old;
@@ -318,21 +321,48 @@ int mlhip_kpp_draw(mlhip_ctx* ctx, mlhip_data* data, const double* centroid, int
         double* out = boff + nb;
         // |cp_i - c~_i| <= (4 N + 16384) 2^-53 (data_kernels.hip); MLHIP_KPP_DELTA_SCALE widens it (tests: forces the host path)
         static const double scale = [] { const char* e = std::getenv("MLHIP_KPP_DELTA_SCALE"); return e ? std::atof(e) : 1.0; }();
-        const double delta = scale * (4.0 * (double)data->n + 16384.0) * 0x1p-53;
+        const double delta = scale * (4.0 * (double)n_global + 16384.0) * 0x1p-53;
+        double* res = data->km_host.as<double>();
         ctx->timed("kpp_draw", [&] {
-            launch_kpp_draw(data->kpp_w.as<double>(), data->km_probe.as<double>(), data->n, first ? 1 : 0, u, delta, bsum, boff, out,
-                            ctx->stream);
+            launch_kpp_update(data->kpp_w.as<double>(), data->km_probe.as<double>(), data->n, first ? 1 : 0, (double)(n_global - 1), bsum,
+                              boff, out, ctx->stream);
         });
         HIP_CHECK(hipGetLastError());
-        double* res = data->km_host.as<double>();
+        HIP_CHECK(hipMemcpyAsync(res, out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        ctx->sync();
+        // the ranks' sums in rank order: this rank's offset and the total are the same sequence of additions on every rank
+        int world = 1, rank = 0;
+        if (ctx->reduce_fn) { world = ctx->world_size; rank = ctx->rank; }
+        std::vector<double> sums((size_t)world, 0.0);
+        sums[(size_t)rank] = res[0];
+        if (world > 1) ctx->allreduce_host(sums.data(), sums.size());
+        double offset = 0.0, total = 0.0;
+        for (int r = 0; r < world; ++r) {
+            if (r == rank) offset = total;
+            total += sums[(size_t)r];
+        }
+        ctx->timed("kpp_draw", [&] {
+            launch_kpp_find(data->kpp_w.as<double>(), data->n, bsum, boff, offset, total, u, delta, first_row, n_global, out, ctx->stream);
+        });
+        HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(res, out, sizeof(double) * 3, hipMemcpyDeviceToHost, ctx->stream));
         ctx->sync();
-        const bool ok = std::isfinite(res[0]) && res[0] > 0.0 && res[1] == res[2];
-        *certain = ok ? 1 : 0;
-        *index = ok ? (uint64_t)res[1] : 0;
-        if (!ok && weights_out) {
-            download_columns(ctx, reinterpret_cast<char*>(weights_out), 0, data->kpp_w.as<char>(), 0, sizeof(double) * data->n, 1);
+        double lo = res[1], hi = res[2];
+        if (world > 1) {
+            std::vector<double> cand(2 * (size_t)world, 0.0);
+            cand[2 * (size_t)rank] = lo;
+            cand[2 * (size_t)rank + 1] = hi;
+            ctx->allreduce_host(cand.data(), cand.size());
+            for (int r = 0; r < world; ++r) {
+                lo = std::min(lo, cand[2 * (size_t)r]);
+                hi = std::min(hi, cand[2 * (size_t)r + 1]);
+            }
         }
+        const bool ok = std::isfinite(total) && total > 0.0 && lo == hi;
+        *certain = ok ? 1 : 0;
+        *index = ok ? (uint64_t)lo : 0;
+        if (!ok && weights_out && data->n)
+            download_columns(ctx, reinterpret_cast<char*>(weights_out), 0, data->kpp_w.as<char>(), 0, sizeof(double) * data->n, 1);
     });
 }
 

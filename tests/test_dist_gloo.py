@@ -470,3 +470,66 @@ def test_diverging_ranks_fail_the_fit_on_every_rank():
     for r in results:
         assert r[1] != "error", r[2]
         assert len(r[1]) == 2 and all(m and "ranks disagree" in m for m in r[1]), r
+
+
+def _kpp_worker(rank, world, port, q, scale):
+    try:
+        sys.path.insert(0, ROOT)
+        if scale:
+            os.environ["MLHIP_KPP_DELTA_SCALE"] = scale
+        import torch.distributed as dist
+        from ml_amd import cppyml, synth
+        from ml_amd import dist as mldist
+        from ml_amd.cppyml import clustering as cl
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        mldist.install_allreduce(cppyml.device_context(), world, rank, on_device=False)
+        d, K, n = 5, 12, 120001
+        X, _ = synth.Mixture(d, K, seed=8).sample(n)
+        X[1000:1040] = X[7]
+        lo, hi = mldist.shard_bounds(n, world, rank)
+        if world == 3:                                     # uneven shards, the last one small
+            lo, hi = ((0, 70000), (70000, 119990), (119990, n))[rank]
+        km = cl.KMeans(K)
+        km.set_centroids_initialiser(cl.KPP())
+        km.set_seed(123)
+        km.set_maximum_steps(2)
+        km.fit(np.ascontiguousarray(X[lo:hi]))
+        q.put((rank, km.centroids.copy()))
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), str(e)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,scale", [(2, ""), (3, ""), (2, "1e9")])
+def test_sharded_kpp_draws_on_the_devices_match_the_single_process_draws(oracle, world, scale):
+    """N = 120 001 over 2 / 3 row shards: K-means++ takes its draws on the devices (mlhip_kpp_draw with the ranks' weight sums and
+    candidates exchanged through the all-reduce hook) and picks the rows the oracle's sequential std::discrete_distribution picks on the
+    whole sample -- also when the bound is widened until every draw goes back to the sequential evaluation over the ranks."""
+    import torch.multiprocessing as mp
+    from ml_amd import synth
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = _free_port()
+    procs = [mpctx.Process(target=_kpp_worker, args=(r, world, port, q, scale)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+            p.join()
+    for r in results:
+        assert r[1] is not None and not (isinstance(r[1], str) and r[1] == "error"), r[2]
+    d, K, n = 5, 12, 120001
+    X, _ = synth.Mixture(d, K, seed=8).sample(n)
+    X[1000:1040] = X[7]
+    okm = oracle.KMeans(K)
+    okm.set_centroids_initialiser(oracle.KPP)
+    okm.set_seed(123)
+    okm.set_maximum_steps(2)
+    okm.fit(X)
+    for r in results:
+        assert np.max(np.abs(r[1] - okm.centroids)) <= 1e-13 * np.max(np.abs(okm.centroids)), r[0]
