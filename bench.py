@@ -577,6 +577,14 @@ def main():
                 sec["config"]["workload"] += " = one GPU's row shard of BASELINE.json configs[4] (N=100M on 8 GPUs)"
                 diag["config"]["workload"] += " = BASELINE.json configs[1]"
                 out["secondary"] = [sec, diag]
+        elif world > 1 and default_shape and not args.no_secondary:
+            # multi-GPU runs: BASELINE.json configs[4] at 12.5M rows per GPU in the same driver-timed run -- N = 100M at 8 GPUs is
+            # the configuration itself (weak scaling over the driver's 1 / 2 / 4 / 8 series: per-GPU work is fixed)
+            sec = kmeans_measure(job, 12_500_000 * world, 8, 256, args.steps, args.warmup, False, args.cpu_samples)
+            if out is not None and sec is not None:
+                sec["config"]["workload"] += f" = BASELINE.json configs[4] at 12.5M rows per GPU (N=100M on 8 GPUs)"
+                sec["scaling"] = "weak"
+                out["secondary"] = [sec]
     if rank == 0:
         print(json.dumps(out))
     job.close()
