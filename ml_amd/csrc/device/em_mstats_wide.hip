@@ -28,6 +28,7 @@ namespace mstats {
 namespace {
 
 constexpr int NW = 8;   // waves per workgroup
+typedef __attribute__((address_space(3))) const double lds_cdouble;
 
 /// Partner values for all-reductions over lane bits 3, 4, 5 without the LDS pipe (a __shfl_xor of a double is two
 /// ds_bpermute: ~100 cycles of latency each, six of them in a row in the staging phase where every wave of the CU waits):
@@ -260,6 +261,48 @@ __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
             case 6: contract(std::integral_constant<int, 6>{}); break;
             default: contract(std::integral_constant<int, 7>{}); break;
             }
+        } else if constexpr (RBW * CBW < 20 && DM <= kRegDim) {
+        // Every shape but the headline's 4 x 5 tiles per wave (which sits at 256 registers): the lane's operand addresses (tile base +
+        // coordinate offset) are formed ONCE per tile; inside the loop every LDS read is `ds_read base offset:imm` off running
+        // pointers that advance by U sample groups per trip -- otherwise one v_add_u32 per read [r3] (d = 24, K = 64: 4.09 -> 3.97 ms).
+        constexpr int U = 4;
+        lds_cdouble* pa[CBW];
+        lds_cdouble* pb[CBW];
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) {
+            pa[c] = (lds_cdouble*)(xbase + offa[c]);
+            pb[c] = (lds_cdouble*)(xbase + offb[c]);
+        }
+        lds_cdouble* pr = (lds_cdouble*)rbase;
+#pragma unroll 1
+        for (int sg0 = 0; sg0 < TS / 4; sg0 += U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                double av[RBW];
+#pragma unroll
+                for (int r = 0; r < RBW; ++r) av[r] = pr[u * RS + r * 16];
+#pragma unroll
+                for (int c = 0; c < CBW - 1; ++c) {
+                    const double bv = pa[c][u * XS] * pb[c][u * XS];
+#pragma unroll
+                    for (int r = 0; r < RBW; ++r)
+                        acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], bv, acc[r][c], 0, 0, 0);
+                }
+                constexpr int c = CBW - 1;                   // (see the loop below for the last block)
+                const double bv = pa[c][u * XS] * pb[c][u * XS];
+                if (last_active) {
+#pragma unroll
+                    for (int r = 0; r < RBW; ++r)
+                        acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], bv, acc[r][c], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CBW; ++c) {
+                pa[c] += U * XS;
+                pb[c] += U * XS;
+            }
+            pr += U * RS;
+        }
         } else {
 #pragma unroll 2
         for (int sg = 0; sg < TS / 4; ++sg) {
