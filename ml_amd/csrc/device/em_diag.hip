@@ -352,7 +352,16 @@ __global__ __launch_bounds__(256, D <= 8 ? 4 : 3) void em_diag_sgpr_kernel(
     const uint32_t n_tiles = (n + TS - 1) / TS;
     const uint32_t stride = gridDim.x * 4;
     const double* xbase = Xw + 8 * (lane >> 4) * XSS;         // half tile: lane group g reads samples 8 g + sg
-    const double* rbase = Rw + 8 * (lane >> 4) * RSS + (lane & 15);
+    // the wave's tiles sit at fixed LDS addresses: the lane's operand pointers are loop invariants, every read in the statistics
+    // loop is `ds_read base offset:imm` (no address arithmetic in a kernel whose vector instructions are its bound)
+    lds_cdouble* pa[CB];
+    lds_cdouble* pb[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+        pa[c] = (lds_cdouble*)(xbase + offa[c]);
+        pb[c] = (lds_cdouble*)(xbase + offb[c]);
+    }
+    lds_cdouble* rbase = (lds_cdouble*)(Rw + 8 * (lane >> 4) * RSS + (lane & 15));
     double ll_acc = 0.0;
 
     for (uint32_t tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += stride) {
@@ -378,7 +387,8 @@ __global__ __launch_bounds__(256, D <= 8 ? 4 : 3) void em_diag_sgpr_kernel(
                     }
                     const double lw = __builtin_fma(-0.5, q, p[2 * D]);
                     lwv[k4 + u] = lw;
-                    m = lw > m ? lw : m;
+                    asm("v_max_f64 %0, %0, %1" : "+v"(m) : "v"(lw));     // m = max(m, lw); a NaN lw leaves m (as `lw > m ? lw : m` did): one
+                                                                        // instruction instead of a compare and two selects
                     __builtin_amdgcn_sched_barrier(0);        // one record in scalar registers at a time
                 }
             } else {
@@ -407,6 +417,11 @@ __global__ __launch_bounds__(256, D <= 8 ? 4 : 3) void em_diag_sgpr_kernel(
         lse_out[i] = lse;
         if (live) ll_acc += lse;
         const double inv = live ? 1.0 / sum : 0.0;                                  // padding samples contribute nothing
+        // (formed once, in place: the two half-tile passes below run under complementary lane masks but ISSUE for the whole wave)
+#pragma unroll
+        for (int j = 0; j < D; ++j) x[j] -= shift[j];                               // shift is zero-padded to D entries
+#pragma unroll
+        for (int it = 0; it < 16; ++it) lwv[it] *= inv;
 
         // ---- 3. statistics on the matrix cores, the tile in two 32-sample halves through LDS
 #pragma unroll
@@ -415,24 +430,23 @@ __global__ __launch_bounds__(256, D <= 8 ? 4 : 3) void em_diag_sgpr_kernel(
             if ((lane >> 5) == h) {
                 double* xw = Xw + (lane & 31) * XSS;
 #pragma unroll
-                for (int j = 0; j < D; ++j) xw[j] = x[j] - shift[j];               // shift is zero-padded to D entries
+                for (int j = 0; j < D; ++j) xw[j] = x[j];
                 xw[ONE] = 1.0;
                 xw[ZERO] = 0.0;
                 double* rw = Rw + (lane & 31) * RSS;
 #pragma unroll
-                for (int it = 0; it < 16; ++it) rw[it] = lwv[it] * inv;
+                for (int it = 0; it < 16; ++it) rw[it] = lwv[it];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_s_setprio(kMatrixPhasePriority);
-#pragma unroll 4
+#pragma unroll
             for (int sg = 0; sg < HT / 4; ++sg) {
                 const double av = rbase[sg * RSS];               // r of (sample 8 g + sg of the half, component lane & 15)
-                const double* xr = xbase + sg * XSS;
                 s0 += av;
 #pragma unroll
                 for (int c = 0; c < CB; ++c) {
-                    const double bv = xr[offa[c]] * xr[offb[c]];
+                    const double bv = pa[c][sg * XSS] * pb[c][sg * XSS];
                     acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[c], 0, 0, 0);
                 }
             }
