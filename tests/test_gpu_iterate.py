@@ -50,6 +50,9 @@ def _step_loop(dt, pi, mu, S, max_steps, atol, rtol, diagonal):
     (12, 3, 9000, False),
     (8, 5, 9000, False),        # scalar-fed E-step + wide statistics kernel
     (4, 3, 20000, False),       # fused small-shape kernel
+    (4, 3, 9000, False),        # ... with at most 64 partial blocks: their reduction is folded into the closing kernel
+    (2, 8, 12000, False),
+    (6, 5, 700, False),
     (2, 8, 20000, False),
     (48, 9, 6000, False),
     (64, 4, 5000, False),
