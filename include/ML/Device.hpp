@@ -7,7 +7,9 @@ struct mlhip_ctx;
 
 namespace ml {
 namespace device {
-/** Process-wide context used by the facade, created on first use (device: MLHIP_DEVICE, else LOCAL_RANK, else 0).
+/** Process-wide context used by the facade, created on first use: a device GROUP over several GPUs when the environment asks
+for one (MLHIP_DEVICES=0,1,2,3 or MLHIP_NUM_GPUS=8: `fit` then row-shards its one data block over them, mlhip_ctx_create_group),
+else one GPU (MLHIP_DEVICE, else LOCAL_RANK, else 0).
 @throw std::runtime_error If no HIP device is usable -- there is no CPU fallback. */
 DLL_DECLSPEC mlhip_ctx* context();
 /** The context the facade would use right now, WITHOUT creating one: the override, else the default if it already

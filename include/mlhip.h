@@ -14,7 +14,8 @@
  *    `Eigen::Ref<const Eigen::MatrixXd> data` (ML/Clustering.hpp:28-33) == a C-contiguous N x d numpy
  *    array (cppyml/clustering.cpp:27-30). `ld` = distance in doubles between consecutive samples;
  *  - all pointers are HOST pointers owned by the caller unless a name ends in `_dev`;
- *  - one context drives one GPU (one process per GPU); a context is not thread-safe;
+ *  - one context drives one GPU (one process per GPU) -- or, created as a device GROUP (mlhip_ctx_create_group), all the GPUs of
+ *    the node from one process; a context is not thread-safe;
  *  - there is no CPU fallback: without a usable HIP device every compute entry point fails with
  *    MLHIP_E_NO_DEVICE.
  */
@@ -45,7 +46,28 @@ const char* mlhip_version(void);
 int mlhip_device_count(int* count);
 /* device_id < 0: take MLHIP_DEVICE, else LOCAL_RANK, else 0. */
 int mlhip_ctx_create(int device_id, mlhip_ctx** out);
+/* DEVICE GROUP: one context over n_shards shards, shard s on GPU device_ids[s] (NULL: s mod the number of visible GPUs; an id may
+ * repeat -- several shards on one GPU is how a one-GPU box runs the 8-GPU configurations at full size). This is the single-process
+ * multi-GPU form of the reference's API -- `bool EM::fit(Eigen::Ref<const MatrixXd>)` (ML/EM.cpp:91) and KMeans::fit (ML/KMeans.cpp:25)
+ * take ONE d x N block in ONE process: mlhip_data_upload on a group row-shards the caller's block over the shards (contiguous, balanced),
+ * and EVERY entry point below accepts the group's context with the caller's WHOLE arrays (all N rows of labels / responsibilities /
+ * targets / weights; results are those of a single context, up to the summation order of the statistics). Inside, one host thread per
+ * shard drives that shard's GPU with the ordinary per-context code, and the shards' statistics meet once per iteration:
+ *   - shards on distinct GPUs: RCCL (ncclCommInitAll, ncclAllReduce on each shard's stream);
+ *   - otherwise, or with MLHIP_GROUP_REDUCE=direct: an in-process all-reduce -- every shard sums all shards' buffers in shard order with
+ *     the same kernel (peer access over xGMI between GPUs), so the shards hold bit-identical sums and runs are reproducible.
+ * To its caller a group is ONE rank (mlhip_ctx_world: 1, 0); it takes no all-reduce hook or communicator of its own. */
+int mlhip_ctx_create_group(int n_shards, const int* device_ids, mlhip_ctx** out);
+/* What the C++ facade / Python surface use (ml::device::context()): a group when the environment asks for one -- MLHIP_DEVICES=0,1,2,3
+ * (one shard per entry) or MLHIP_NUM_GPUS=n (ignored under a one-process-per-GPU launcher, i.e. when LOCAL_RANK is set) -- else
+ * mlhip_ctx_create(-1). */
+int mlhip_ctx_create_default(mlhip_ctx** out);
 int mlhip_ctx_destroy(mlhip_ctx* ctx);
+/* Shards of a context (1 for an ordinary one), the GPU of a shard, and how the statistics are summed: "none", "hook-host",
+ * "hook-device", "rccl" (mlhip_ctx_init_rccl), "group-rccl", "group-direct" (a string constant). */
+int mlhip_ctx_shards(const mlhip_ctx* ctx, int* n_shards);
+int mlhip_ctx_shard_device(const mlhip_ctx* ctx, int shard, int* device_id);
+int mlhip_ctx_reduce_kind(const mlhip_ctx* ctx, const char** kind);
 int mlhip_ctx_synchronize(mlhip_ctx* ctx);
 int mlhip_ctx_device(const mlhip_ctx* ctx, int* device_id);
 /* The HIP stream (hipStream_t) every kernel of this context is launched on. */
@@ -98,6 +120,8 @@ int mlhip_data_upload(mlhip_ctx* ctx, const double* x, uint32_t d, uint64_t n, i
 int mlhip_data_upload_dev(mlhip_ctx* ctx, const double* x_dev, uint32_t d, uint64_t n, int64_t ld, mlhip_data** out);
 int mlhip_data_free(mlhip_data* data);
 int mlhip_data_shape(const mlhip_data* data, uint32_t* d, uint64_t* n_local, uint64_t* n_global);
+/* Rows [first_row, first_row + n_rows) of the uploaded block that shard `shard` holds (an ordinary context: shard 0, all rows). */
+int mlhip_data_shard_rows(const mlhip_data* data, int shard, uint64_t* first_row, uint64_t* n_rows);
 /* Global column means used as the numerical shift of the second-moment accumulation (d doubles). */
 int mlhip_data_shift(const mlhip_data* data, double* shift);
 
@@ -158,6 +182,11 @@ int mlhip_em_maximisation_from_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t
 /* Normalised responsibilities of the last E-step, this rank's n_local x K block, column-major
  * (EM::responsibilities(), ML/EM.hpp:132-135; rows /= row sum, ML/EM.cpp:214-218). */
 int mlhip_em_responsibilities(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, double* resp, int64_t ldr);
+/* Rows [first_row, first_row + n_rows) of that block only (n_rows x K, column-major, ldr >= n_rows): what a verbose fit prints
+ * (`responsibilities_.topRows(10)`, ML/EM.cpp:155-156) and what a Python slice of the lazy property needs -- 10 rows cost 10 rows,
+ * not the N x K block. */
+int mlhip_em_responsibilities_rows(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, uint64_t first_row, uint64_t n_rows, double* resp,
+                                   int64_t ldr);
 /* argmax_k of those responsibilities, first maximum wins (EM::calculate_labels, ML/EM.cpp:289-304). */
 int mlhip_em_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, uint32_t* labels);
 

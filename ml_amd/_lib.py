@@ -101,7 +101,8 @@ def device_count():
 
 
 class Context:
-    """One GPU + stream (mlhip_ctx)."""
+    """One GPU + stream (mlhip_ctx) -- or, made by Context.group(...), a device GROUP: one context over several shards (GPUs), to
+    which Data uploads row-shard the caller's block and every call fans out (mlhip_ctx_create_group)."""
 
     def __init__(self, device_id=-1):
         self._h = C.c_void_p()
@@ -109,6 +110,49 @@ class Context:
         self._hook = None
         self._owned = True
         self._blocks = weakref.WeakSet()      # live Data objects: they hold a pointer to this context
+
+    @classmethod
+    def group(cls, n_shards=None, device_ids=None):
+        """A device group of n_shards shards, shard s on GPU device_ids[s] (default: s mod the number of GPUs; ids may repeat --
+        8 shards on one GPU rehearse the 8-GPU configurations on a one-GPU box)."""
+        if device_ids is not None:
+            ids = [int(v) for v in device_ids]
+            n_shards = len(ids) if n_shards is None else int(n_shards)
+            if n_shards != len(ids):
+                raise ValueError("device_ids must name one GPU per shard")
+            arr = (C.c_int * n_shards)(*ids)
+        else:
+            n_shards = device_count() if n_shards is None else int(n_shards)
+            arr = None
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        self._hook = None
+        self._owned = True
+        self._blocks = weakref.WeakSet()
+        check(lib.mlhip_ctx_create_group(n_shards, arr, C.byref(self._h)))
+        return self
+
+    @property
+    def shards(self):
+        n = C.c_int()
+        check(lib.mlhip_ctx_shards(self._h, C.byref(n)))
+        return n.value
+
+    @property
+    def shard_devices(self):
+        out = []
+        for s in range(self.shards):
+            d = C.c_int()
+            check(lib.mlhip_ctx_shard_device(self._h, s, C.byref(d)))
+            out.append(d.value)
+        return out
+
+    @property
+    def reduce_kind(self):
+        """How the statistics are summed: none / hook-host / hook-device / rccl / group-rccl / group-direct."""
+        k = C.c_char_p()
+        check(lib.mlhip_ctx_reduce_kind(self._h, C.byref(k)))
+        return k.value.decode()
 
     @classmethod
     def borrow(cls, handle):
@@ -245,6 +289,12 @@ class Data:
         check(lib.mlhip_data_shape(self._h, None, None, C.byref(ng)))
         return ng.value
 
+    def shard_rows(self, shard):
+        """(first_row, n_rows) of the rows shard `shard` of a device group holds."""
+        lo, cnt = C.c_uint64(), C.c_uint64()
+        check(lib.mlhip_data_shard_rows(self._h, int(shard), C.byref(lo), C.byref(cnt)))
+        return lo.value, cnt.value
+
     @property
     def shift(self):
         out = np.empty(self.d)
@@ -335,6 +385,13 @@ class Data:
     def em_responsibilities(self, K):
         out = np.empty((self.n, K), order="F")
         check(lib.mlhip_em_responsibilities(self.ctx.handle, self._h, K, dptr(out), C.c_int64(self.n)))
+        return out
+
+    def em_responsibilities_rows(self, K, first, count):
+        """Rows [first, first + count) of the responsibilities only (mlhip_em_responsibilities_rows)."""
+        out = np.empty((count, K), order="F")
+        check(lib.mlhip_em_responsibilities_rows(self.ctx.handle, self._h, K, C.c_uint64(first), C.c_uint64(count), dptr(out),
+                                                 C.c_int64(max(count, 1))))
         return out
 
     def em_labels(self, K):

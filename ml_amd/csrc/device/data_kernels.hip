@@ -2,6 +2,8 @@
 // ML/Clustering.hpp:28-33) -> dimension-major HBM layout, and deterministic column sums.
 #include "device.hpp"
 
+#include <algorithm>
+
 namespace mlhip {
 namespace {
 
@@ -256,6 +258,18 @@ __global__ __launch_bounds__(256) void kpp_find_kernel(const double* __restrict_
     }
 }
 
+
+// The device group's in-process all-reduce (runtime/group.cpp): out[i] = ((slot_0[i] + slot_1[i]) + slot_2[i]) + ... in shard order --
+// every shard runs this very sum on the same inputs, so all hold bit-identical results (slots of other devices: peer access).
+__global__ __launch_bounds__(256) void group_sum_kernel(GroupSumSlots slots, int n, double* __restrict__ out, size_t count)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        double s = slots.p[0][i];
+        for (int r = 1; r < n; ++r) s += slots.p[r][i];
+        out[i] = s;
+    }
+}
+
 }  // namespace
 
 int kpp_blocks(uint32_t n) { return (int)((n + kKppChunk - 1) / kKppChunk); }
@@ -304,6 +318,13 @@ void launch_column_sums(const double* xt, size_t ldx, int d, uint64_t n, double*
     const int parts = 1024;
     hipLaunchKernelGGL(colsum_stage1, dim3(parts, d), dim3(256), 0, stream, xt, ldx, n, scratch);
     hipLaunchKernelGGL(colsum_stage2, dim3(d), dim3(256), 0, stream, scratch, parts, sums);
+}
+
+void launch_group_sum(const GroupSumSlots& slots, int n, double* out, size_t count, hipStream_t stream)
+{
+    if (!count) return;
+    const unsigned grid = (unsigned)std::min<size_t>((count + 255) / 256, 256);
+    hipLaunchKernelGGL(group_sum_kernel, dim3(grid), dim3(256), 0, stream, slots, n, out, count);
 }
 
 }  // namespace mlhip

@@ -36,6 +36,12 @@ void launch_kpp_update(double* weights, const double* dist, uint32_t n, int firs
 void launch_kpp_find(const double* weights, uint32_t n, const double* bsum, const double* boff, double offset, double total, double u,
                      double delta, uint64_t row0, uint64_t n_global, double* out, hipStream_t stream);
 
+/// Fixed-order sum of the n <= kGroupMaxShards buffers slots.p[0..n) (`count` doubles each) into out: the all-reduce of a device
+/// group whose shards share a process (runtime/group.cpp).
+constexpr int kGroupMaxShards = 64;
+struct GroupSumSlots { const double* p[kGroupMaxShards]; };
+void launch_group_sum(const GroupSumSlots& slots, int n, double* out, size_t count, hipStream_t stream);
+
 // ---- EM ----------------------------------------------------------------------------------------------
 struct EstepArgs {
     const double* xt; size_t ldx; uint32_t n; int D;      // D = padded dimension

@@ -29,7 +29,7 @@ mlhip_ctx* context()
 {
     std::lock_guard<std::mutex> lock(g_mutex);
     if (g_override) return g_override;
-    if (!g_default) check(mlhip_ctx_create(-1, &g_default));
+    if (!g_default) check(mlhip_ctx_create_default(&g_default));   // (MLHIP_DEVICES / MLHIP_NUM_GPUS: a device group)
     return g_default;
 }
 

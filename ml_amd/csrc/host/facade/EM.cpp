@@ -278,8 +278,9 @@ bool EM::fit(ConstMatrixRef data)
                 std::cout << "\n";
             }
             std::cout << "Responsibilities (first 10 rows):\n";
-            MatrixXd r(sample_size, K);
-            check(mlhip_em_responsibilities(ctx, dev.h, K, r.data(), r.rows()));
+            // (only the rows that are printed cross the bus: ML/EM.cpp:155-156 prints topRows(10))
+            MatrixXd r(std::min(sample_size, 10u), K);
+            check(mlhip_em_responsibilities_rows(ctx, dev.h, K, 0, static_cast<uint64_t>(r.rows()), r.data(), r.rows()));
             for (unsigned int i = 0; i < std::min(sample_size, 10u); ++i) {
                 print_row(r.data() + i, K, r.rows());
                 std::cout << "\n";

@@ -9,6 +9,14 @@ thread_local std::string g_error;
 namespace mlhip_rt {
 
 
+/// A device group is ONE rank to its caller (its shards meet inside the library): it takes no hook or communicator of its own.
+static void refuse_group(const mlhip_ctx* ctx)
+{
+    if (ctx->group || ctx->member_of)
+        throw Unsupported("a device group sums its shards' statistics itself: it cannot be given an all-reduce hook or a communicator");
+}
+
+
 int env_int(const char* name, int fallback)
 {
     const char* v = std::getenv(name);
@@ -63,6 +71,40 @@ void init_rccl(mlhip_ctx* ctx, const ncclUniqueId& id, int world_size, int rank)
     host::set_host_ranks(local);
 }
 
+
+mlhip_ctx* create_single_context(int device_id)
+{
+    auto* ctx = new mlhip_ctx;
+    try {
+        ctx->device = device_id;
+        ctx->use();
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+        ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    } catch (...) {
+        delete ctx;
+        throw;
+    }
+    return ctx;
+}
+
+
+void destroy_single_context(mlhip_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm) drop_rccl(ctx);
+    ctx->small_dev.release();
+    ctx->small_host.release();
+    for (int b = 0; b < 2; ++b) { ctx->up_stage[b].release(); ctx->up_pin[b].release(); }
+    for (auto& p : ctx->pending) ctx->spare_events.push_back(p.second);
+    for (auto& e : ctx->spare_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
 }  // namespace mlhip_rt
 
 extern "C" {
@@ -92,19 +134,43 @@ int mlhip_ctx_create(int device_id, mlhip_ctx** out)
             throw NoDevice("no HIP device available: this library has no CPU fallback (needs an AMD GPU, built for gfx950)");
         if (device_id < 0) device_id = env_int("MLHIP_DEVICE", env_int("LOCAL_RANK", 0));
         if (device_id >= n) device_id = device_id % n;
-        auto* ctx = new mlhip_ctx;
-        try {
-            ctx->device = device_id;
-            ctx->use();
-            hipDeviceProp_t prop;
-            HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
-            ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-            HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        } catch (...) {
-            delete ctx;
-            throw;
+        *out = create_single_context(device_id);
+    });
+}
+
+int mlhip_ctx_create_group(int n_shards, const int* device_ids, mlhip_ctx** out)
+{
+    return guarded([&] {
+        require(out != nullptr, "null out");
+        *out = grp::create(n_shards, device_ids);
+    });
+}
+
+int mlhip_ctx_create_default(mlhip_ctx** out)
+{
+    return guarded([&] {
+        require(out != nullptr, "null out");
+        // MLHIP_DEVICES=0,1,2,3 (one shard per entry; an entry may repeat) or MLHIP_NUM_GPUS=n (shard s on GPU s mod the number of
+        // GPUs visible) ask for a device group; a process started by a one-process-per-GPU launcher (LOCAL_RANK set) keeps its one
+        // GPU unless MLHIP_DEVICES names a list.
+        std::vector<int> ids;
+        if (const char* e = std::getenv("MLHIP_DEVICES")) {
+            for (const char* p = e; *p;) {
+                char* end = nullptr;
+                const long v = std::strtol(p, &end, 10);
+                if (end == p) throw InvalidArgument("MLHIP_DEVICES must be a comma-separated list of GPU indices");
+                ids.push_back((int)v);
+                p = end;
+                while (*p == ',' || *p == ' ') ++p;
+            }
         }
-        *out = ctx;
+        int shards = (int)ids.size();
+        if (!shards && !std::getenv("LOCAL_RANK")) shards = env_int("MLHIP_NUM_GPUS", 0);
+        if (shards >= 2 || ids.size() == 1) {
+            *out = grp::create(shards, ids.empty() ? nullptr : ids.data());
+            return;
+        }
+        check_status(mlhip_ctx_create(-1, out));
     });
 }
 
@@ -112,22 +178,20 @@ int mlhip_ctx_destroy(mlhip_ctx* ctx)
 {
     return guarded([&] {
         if (!ctx) return;
-        (void)hipSetDevice(ctx->device);
-        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-        if (ctx->comm) drop_rccl(ctx);
-        ctx->small_dev.release();
-        ctx->small_host.release();
-        for (int b = 0; b < 2; ++b) { ctx->up_stage[b].release(); ctx->up_pin[b].release(); }
-        for (auto& p : ctx->pending) ctx->spare_events.push_back(p.second);
-        for (auto& e : ctx->spare_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-        delete ctx;
+        if (ctx->group) { grp::destroy(ctx); return; }
+        require(!ctx->member_of, "a shard context belongs to its device group");
+        destroy_single_context(ctx);
     });
 }
 
 int mlhip_ctx_synchronize(mlhip_ctx* ctx)
 {
-    return guarded([&] { require(ctx, "null context"); ctx->use(); ctx->sync(); });
+    return guarded([&] {
+        require(ctx, "null context");
+        if (ctx->group) { grp::synchronize(ctx); return; }
+        ctx->use();
+        ctx->sync();
+    });
 }
 int mlhip_ctx_device(const mlhip_ctx* ctx, int* device_id)
 {
@@ -135,13 +199,35 @@ int mlhip_ctx_device(const mlhip_ctx* ctx, int* device_id)
 }
 int mlhip_ctx_stream(const mlhip_ctx* ctx, void** stream)
 {
-    return guarded([&] { require(ctx && stream, "null argument"); *stream = (void*)ctx->stream; });
+    return guarded([&] {
+        require(ctx && stream, "null argument");
+        *stream = (void*)(ctx->group ? grp::shard_context(ctx, 0)->stream : ctx->stream);   // (a group: its first shard's)
+    });
+}
+
+int mlhip_ctx_shards(const mlhip_ctx* ctx, int* n_shards)
+{
+    return guarded([&] { require(ctx && n_shards, "null argument"); *n_shards = grp::shard_count(ctx); });
+}
+int mlhip_ctx_shard_device(const mlhip_ctx* ctx, int shard, int* device_id)
+{
+    return guarded([&] {
+        require(ctx && device_id, "null argument");
+        if (ctx->group) { *device_id = grp::shard_context(ctx, shard)->device; return; }
+        require(shard == 0, "no such shard");
+        *device_id = ctx->device;
+    });
+}
+int mlhip_ctx_reduce_kind(const mlhip_ctx* ctx, const char** kind)
+{
+    return guarded([&] { require(ctx && kind, "null argument"); *kind = grp::reduce_kind(ctx); });
 }
 
 int mlhip_ctx_set_allreduce(mlhip_ctx* ctx, mlhip_allreduce_fn fn, void* user, int on_device, int world_size, int rank)
 {
     return guarded([&] {
         require(ctx, "null context");
+        refuse_group(ctx);
         require(world_size >= 1 && rank >= 0 && rank < world_size, "bad world_size / rank");
         if (ctx->comm) drop_rccl(ctx);          // a caller-supplied hook replaces the library's own communicator
         ctx->reduce_fn = fn;
@@ -180,6 +266,7 @@ int mlhip_ctx_init_rccl(mlhip_ctx* ctx, const void* unique_id, int world_size, i
 {
     return guarded([&] {
         require(ctx && unique_id, "null argument");
+        refuse_group(ctx);
         ncclUniqueId id;
         std::memcpy(&id, unique_id, sizeof id);
         init_rccl(ctx, id, world_size, rank);
@@ -190,6 +277,7 @@ int mlhip_ctx_init_rccl_file(mlhip_ctx* ctx, const char* path, int world_size, i
 {
     return guarded([&] {
         require(ctx && path && *path, "null argument");
+        refuse_group(ctx);
         require(world_size >= 1 && rank >= 0 && rank < world_size, "bad world_size / rank");
         ncclUniqueId id;
         if (rank == 0) {
@@ -228,6 +316,7 @@ int mlhip_ctx_rccl_ranks(const mlhip_ctx* ctx, int* nranks)
     return guarded([&] {
         require(ctx && nranks, "null argument");
         *nranks = 0;
+        if (ctx->group) ctx = grp::shard_context(ctx, 0);       // (a group over distinct GPUs: the communicator of ncclCommInitAll)
         if (!ctx->comm) return;
         const Rccl& r = Rccl::get();
         r.check(r.CommCount(ctx->comm, nranks), "ncclCommCount");
@@ -236,13 +325,14 @@ int mlhip_ctx_rccl_ranks(const mlhip_ctx* ctx, int* nranks)
 
 int mlhip_ctx_finalize_rccl(mlhip_ctx* ctx)
 {
-    return guarded([&] { require(ctx, "null context"); ctx->use(); drop_rccl(ctx); });
+    return guarded([&] { require(ctx, "null context"); refuse_group(ctx); ctx->use(); drop_rccl(ctx); });
 }
 
 int mlhip_ctx_allreduce(mlhip_ctx* ctx, double* buf, size_t count)
 {
     return guarded([&] {
         require(ctx && (buf || count == 0), "null argument");
+        if (ctx->group) return;                 // (a group is one rank to its caller: nothing to sum with)
         ctx->use();
         ctx->allreduce_host(buf, count);
     });
@@ -260,6 +350,7 @@ int mlhip_timing_enable(mlhip_ctx* ctx, int on)
 {
     return guarded([&] {
         require(ctx, "null context");
+        if (ctx->group) { grp::timing_enable(ctx, on); return; }
         ctx->use();
         if (!on) ctx->resolve_timers();
         ctx->timing = on != 0;
@@ -269,6 +360,7 @@ int mlhip_timing_reset(mlhip_ctx* ctx)
 {
     return guarded([&] {
         require(ctx, "null context");
+        if (ctx->group) { grp::timing_reset(ctx); return; }
         ctx->use();
         ctx->resolve_timers();
         ctx->timers.clear();
@@ -278,6 +370,7 @@ int mlhip_timing_get(mlhip_ctx* ctx, const char* name, double* avg_ms, uint64_t*
 {
     return guarded([&] {
         require(ctx && name && avg_ms && launches, "null argument");
+        if (ctx->group) { grp::timing_get(ctx, name, avg_ms, launches); return; }
         ctx->use();
         ctx->resolve_timers();
         auto it = ctx->timers.find(name);

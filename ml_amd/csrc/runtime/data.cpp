@@ -75,20 +75,25 @@ mlhip_data* upload_common(mlhip_ctx* ctx, const double* x, bool on_device, uint3
             // Pageable host memory: the caller's block is packed into two pinned staging buffers by the CPU (this also
             // removes the ld > d padding) while the previous chunk's H2D copy + transpose run on the stream. A direct
             // hipMemcpy from pageable memory reaches only ~3 GB/s on this platform; pinned chunks go at PCIe rate.
-            const uint64_t chunk = 1u << 19;                       // samples per chunk (128 MB at d = 32)
+            // Chunks are sized by BYTES (ctx->stage_bytes, 128 MB: 2^19 samples at d = 32), whatever the dimension: two pinned and
+            // two device buffers of that size, not 8 d 2^19 bytes each (16 GB at d = 4096).
+            const uint64_t chunk = std::max<uint64_t>(256, ctx->stage_bytes / (sizeof(double) * d));
             const uint64_t cap = n < chunk ? (n ? n : 1) : chunk;
             DevBuf* stage = ctx->up_stage;
             PinnedBuf* pin = ctx->up_pin;
-            hipEvent_t done[2];
+            struct Events {
+                hipEvent_t e[2] = {nullptr, nullptr};
+                ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+            } done;
             for (int b = 0; b < 2; ++b) {
                 stage[b].reserve(sizeof(double) * d * cap);
                 pin[b].reserve(sizeof(double) * d * cap);
-                HIP_CHECK(hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
+                HIP_CHECK(hipEventCreateWithFlags(&done.e[b], hipEventDisableTiming));
             }
             int b = 0;
             for (uint64_t i0 = 0; i0 < n; i0 += chunk, b ^= 1) {
                 const uint64_t c = (n - i0 < chunk) ? n - i0 : chunk;
-                if (i0 >= 2 * chunk) HIP_CHECK(hipEventSynchronize(done[b]));   // staging pair b is free again
+                if (i0 >= 2 * chunk) HIP_CHECK(hipEventSynchronize(done.e[b]));   // staging pair b is free again
                 double* dst = pin[b].as<double>();
                 const double* src = x + (int64_t)i0 * ld;
                 if (ld == (int64_t)d) {
@@ -98,10 +103,9 @@ mlhip_data* upload_common(mlhip_ctx* ctx, const double* x, bool on_device, uint3
                 }
                 HIP_CHECK(hipMemcpyAsync(stage[b].p, dst, sizeof(double) * d * c, hipMemcpyHostToDevice, ctx->stream));
                 launch_transpose_to_dim_major(stage[b].as<double>(), d, dt->d, c, dt->xt.as<double>(), dt->ldx, i0, ctx->stream);
-                HIP_CHECK(hipEventRecord(done[b], ctx->stream));
+                HIP_CHECK(hipEventRecord(done.e[b], ctx->stream));
             }
             ctx->sync();
-            for (int k = 0; k < 2; ++k) (void)hipEventDestroy(done[k]);
         }
         finish_upload(dt);
     } catch (...) {
@@ -162,16 +166,24 @@ extern "C" {
 
 int mlhip_data_upload(mlhip_ctx* ctx, const double* x, uint32_t d, uint64_t n, int64_t ld, mlhip_data** out)
 {
-    return guarded([&] { require(out, "null out"); *out = upload_common(ctx, x, false, d, n, ld); });
+    return guarded([&] {
+        require(out && ctx, "null argument");
+        *out = ctx->group ? grp::upload(ctx, x, false, d, n, ld) : upload_common(ctx, x, false, d, n, ld);
+    });
 }
 int mlhip_data_upload_dev(mlhip_ctx* ctx, const double* x_dev, uint32_t d, uint64_t n, int64_t ld, mlhip_data** out)
 {
-    return guarded([&] { require(out, "null out"); *out = upload_common(ctx, x_dev, true, d, n, ld); });
+    return guarded([&] {
+        require(out && ctx, "null argument");
+        // (a group: x_dev must be readable from every shard's GPU -- the same GPU, or peers with access enabled)
+        *out = ctx->group ? grp::upload(ctx, x_dev, true, d, n, ld) : upload_common(ctx, x_dev, true, d, n, ld);
+    });
 }
 int mlhip_data_free(mlhip_data* data)
 {
     return guarded([&] {
         if (!data) return;
+        if (!data->parts.empty() || data->ctx->group) { delete data; return; }       // (a group's block: its parts free themselves)
         (void)hipSetDevice(data->ctx->device);
         (void)hipStreamSynchronize(data->ctx->stream);
         delete data;
@@ -182,8 +194,18 @@ int mlhip_data_shape(const mlhip_data* data, uint32_t* d, uint64_t* n_local, uin
     return guarded([&] {
         require(data, "null data");
         if (d) *d = (uint32_t)data->d;
-        if (n_local) *n_local = data->n;
+        if (n_local) *n_local = data->parts.empty() ? (uint64_t)data->n : data->n_global;   // (a group holds the whole sample)
         if (n_global) *n_global = data->n_global;
+    });
+}
+int mlhip_data_shard_rows(const mlhip_data* data, int shard, uint64_t* first_row, uint64_t* n_rows)
+{
+    return guarded([&] {
+        require(data, "null data");
+        const int shards = data->parts.empty() ? 1 : (int)data->parts.size();
+        require(shard >= 0 && shard < shards, "no such shard");
+        if (first_row) *first_row = data->parts.empty() ? 0 : data->first_row[(size_t)shard];
+        if (n_rows) *n_rows = data->parts.empty() ? (uint64_t)data->n : data->first_row[(size_t)shard + 1] - data->first_row[(size_t)shard];
     });
 }
 int mlhip_data_shift(const mlhip_data* data, double* shift)
@@ -197,6 +219,7 @@ int mlhip_data_shift(const mlhip_data* data, double* shift)
 int mlhip_sample_covariance(mlhip_ctx* ctx, mlhip_data* data, double* mean, double* covariance)
 {
     return guarded([&] {
+        if (ctx && ctx->group) { grp::sample_covariance(ctx, data, mean, covariance); return; }
         check_em_args(ctx, data, 1);
         require(covariance, "null argument");
         const int saved_K = data->em_K;
@@ -226,6 +249,7 @@ int mlhip_sample_covariance(mlhip_ctx* ctx, mlhip_data* data, double* mean, doub
 int mlhip_xxt_xy(mlhip_ctx* ctx, mlhip_data* data, const double* y, double* xxt, double* xy)
 {
     return guarded([&] {
+        if (ctx && ctx->group) { grp::xxt_xy(ctx, data, y, xxt, xy); return; }
         check_em_args(ctx, data, 2);
         require((y || data->n == 0) && xxt && xy, "null argument");
         ensure_em_workspace(data, 2);
@@ -259,6 +283,7 @@ int mlhip_random_partition_means(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, c
                                  double* means, double* sizes)
 {
     return guarded([&] {
+        if (ctx && ctx->group) { grp::random_partition_means(ctx, data, K, order, offsets, means, sizes); return; }
         check_em_args(ctx, data, K);
         require(offsets && means && sizes && (order || data->n == 0), "null argument");
         require(offsets[0] == 0 && offsets[K] == data->n, "offsets must cover this rank's rows");

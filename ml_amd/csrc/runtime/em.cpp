@@ -625,7 +625,9 @@ void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* mean
     // ... and only where an iteration is short enough for the host's share to matter: the speculative iteration is thrown away
     // once per fit (and the log-responsibilities it overwrote are rebuilt on demand), which a long iteration never earns back
     // (N = 10M, d = 8, K = 32: 2.2 ms per iteration against ~10 us saved per iteration).
-    const double pair_work = (double)data->n * K * (diag ? d : d * d);
+    // (from the GLOBAL row count: every rank -- every shard of a device group -- must take the same loop, or a lagged rank's
+    // speculative all-reduce would meet another rank's end-of-fit exchange)
+    const double pair_work = (double)data->n_global / (double)std::max(1, ctx->world_size) * K * (diag ? d : d * d);
     // The matrix-core E-step (d >= 12) joins it in its EXACT form: the FOLD form is a per-iteration decision of the host (from the
     // closing kernel's bound on |W (mu - shift)|), which a loop that does not wait for the host cannot take; the records carry both
     // vectors, so no FOLD simply means a.fold = 0 (32 more subtractions per 64 samples and component at d = 32: a few per cent of
@@ -804,6 +806,7 @@ int mlhip_em_expectation(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const dou
                          const double* covariances, double* log_likelihood)
 {
     return guarded([&] {
+        if (ctx && ctx->group) { grp::em_expectation(ctx, data, K, mixing, means, covariances, log_likelihood); return; }
         check_em_args(ctx, data, K);
         require(mixing && means && covariances && log_likelihood, "null argument");
         run_estep(data, (int)K, mixing, means, covariances);
@@ -822,6 +825,7 @@ int mlhip_em_maximisation(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, double* 
                           double* covariances_out)
 {
     return guarded([&] {
+        if (ctx && ctx->group) { grp::em_maximisation(ctx, data, K, 0, nullptr, 0, nullptr, mixing_out, means_out, covariances_out); return; }
         check_em_args(ctx, data, K);
         require(mixing_out && means_out && covariances_out, "null argument");
         require(data->have_estep && data->em_K == (int)K, "no E-step results on the device for this K");
@@ -836,6 +840,10 @@ int mlhip_em_step(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* mi
                   double* covariances_out)
 {
     return guarded([&] {
+        if (ctx && ctx->group) {
+            grp::em_step(ctx, data, K, false, mixing, means, covariances, log_likelihood, mixing_out, means_out, covariances_out);
+            return;
+        }
         check_em_args(ctx, data, K);
         require(mixing && means && covariances && log_likelihood && mixing_out && means_out && covariances_out, "null argument");
         em_step_full(data, (int)K, mixing, means, covariances, log_likelihood, mixing_out, means_out, covariances_out);
@@ -847,6 +855,10 @@ int mlhip_em_step_diag(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const doubl
                        double* variances_out)
 {
     return guarded([&] {
+        if (ctx && ctx->group) {
+            grp::em_step(ctx, data, K, true, mixing, means, variances, log_likelihood, mixing_out, means_out, variances_out);
+            return;
+        }
         check_em_args(ctx, data, K);
         require(mixing && means && variances && log_likelihood && mixing_out && means_out && variances_out, "null argument");
         em_step_diag(data, (int)K, mixing, means, variances, log_likelihood, mixing_out, means_out, variances_out);
@@ -858,6 +870,13 @@ int mlhip_em_iterate(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, int covarianc
                      uint32_t* steps_done, int* converged, double* log_likelihood, double* log_likelihood_history)
 {
     return guarded([&] {
+        if (ctx && ctx->group) {
+            require(max_steps >= 1, "at least one step required");
+            if (absolute_tolerance < 0 || relative_tolerance < 0) throw DomainError("negative tolerance");
+            grp::em_iterate(ctx, data, K, covariance_type, mixing, means, covariances, max_steps, absolute_tolerance, relative_tolerance,
+                            steps_done, converged, log_likelihood, log_likelihood_history);
+            return;
+        }
         check_em_args(ctx, data, K);
         require(mixing && means && covariances && steps_done && converged && log_likelihood, "null argument");
         require(covariance_type == MLHIP_COVARIANCE_FULL || covariance_type == MLHIP_COVARIANCE_DIAGONAL, "bad covariance_type");
@@ -875,6 +894,7 @@ int mlhip_em_maximisation_from(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, con
                                double* mixing_out, double* means_out, double* covariances_out)
 {
     return guarded([&] {
+        if (ctx && ctx->group) { grp::em_maximisation(ctx, data, K, 1, resp, ldr, nullptr, mixing_out, means_out, covariances_out); return; }
         check_em_args(ctx, data, K);
         require((resp || data->n == 0) && mixing_out && means_out && covariances_out, "null argument");   // (an empty shard has no rows)
         require(ldr >= (int64_t)data->n, "ldr must be >= n_local");
@@ -893,6 +913,7 @@ int mlhip_em_maximisation_from_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t
                                       double* mixing_out, double* means_out, double* covariances_out)
 {
     return guarded([&] {
+        if (ctx && ctx->group) { grp::em_maximisation(ctx, data, K, 2, nullptr, 0, labels, mixing_out, means_out, covariances_out); return; }
         check_em_args(ctx, data, K);
         require((labels || data->n == 0) && mixing_out && means_out && covariances_out, "null argument");
         ensure_em_workspace(data, (int)K);
@@ -907,28 +928,41 @@ int mlhip_em_maximisation_from_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t
     });
 }
 
-int mlhip_em_responsibilities(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, double* resp, int64_t ldr)
+int mlhip_em_responsibilities_rows(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, uint64_t first_row, uint64_t n_rows, double* resp,
+                                   int64_t ldr)
 {
     return guarded([&] {
+        if (ctx && ctx->group) { grp::em_responsibilities(ctx, data, K, resp, ldr, first_row, n_rows); return; }
         check_em_args(ctx, data, K);
-        require(resp || data->n == 0, "null argument");
-        require(ldr >= (int64_t)data->n, "ldr must be >= n_local");
+        require(first_row <= data->n && n_rows <= data->n - first_row, "row range beyond this block");
+        require(resp || n_rows == 0, "null argument");
+        require(ldr >= (int64_t)n_rows, "ldr must be >= the number of rows");
         require(data->have_estep && data->em_K == (int)K, "no E-step results on the device for this K");
+        if (!n_rows) return;
         ensure_lw(data, (int)K);
-        data->resp_dev.reserve(sizeof(double) * data->ldr * K);
-        RespArgs a{data->lw.as<double>(), data->ldr, data->lse.as<double>(), data->n, (int)K,
-                   data->resp_dev.as<double>(), data->ldr, nullptr};
+        const size_t ldo = (size_t)padded_samples(n_rows);
+        data->resp_dev.reserve(sizeof(double) * ldo * K);
+        RespArgs a{data->lw.as<double>() + first_row, data->ldr, data->lse.as<double>() + first_row, (uint32_t)n_rows, (int)K,
+                   data->resp_dev.as<double>(), ldo, nullptr};
         launch_em_responsibilities(a, ctx->stream);
         HIP_CHECK(hipGetLastError());
         ctx->sync();
-        download_columns(ctx, reinterpret_cast<char*>(resp), sizeof(double) * ldr, data->resp_dev.as<char>(),
-                         sizeof(double) * data->ldr, sizeof(double) * data->n, K);
+        download_columns(ctx, reinterpret_cast<char*>(resp), sizeof(double) * ldr, data->resp_dev.as<char>(), sizeof(double) * ldo,
+                         sizeof(double) * n_rows, K);
     });
+}
+
+int mlhip_em_responsibilities(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, double* resp, int64_t ldr)
+{
+    if (!data) return mlhip_em_responsibilities_rows(ctx, data, K, 0, 0, resp, ldr);      // (reports the null argument)
+    const uint64_t n = data->parts.empty() ? (uint64_t)data->n : data->n_global;
+    return mlhip_em_responsibilities_rows(ctx, data, K, 0, n, resp, ldr);
 }
 
 int mlhip_em_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, uint32_t* labels)
 {
     return guarded([&] {
+        if (ctx && ctx->group) { grp::em_labels(ctx, data, K, labels); return; }
         check_em_args(ctx, data, K);
         require(labels || data->n == 0, "null argument");
         require(data->have_estep && data->em_K == (int)K, "no E-step results on the device for this K");
@@ -972,6 +1006,7 @@ int mlhip_em_plan(const mlhip_data* data, uint32_t K, uint32_t* flags)
 {
     return guarded([&] {
         require(data && flags && K >= 1, "null argument");
+        if (!data->parts.empty()) data = data->parts[0];        // (a group's block: every shard takes the same plan)
         uint32_t f = 0;
         const bool matrix = estep_mfma4_supported(data->D) && !(data->D <= kRegDim && std::getenv("MLHIP_ESTEP"));
         if (fused_step_applies(data, (int)K)) f |= MLHIP_PLAN_FUSED;

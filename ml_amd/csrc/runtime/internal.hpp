@@ -11,7 +11,12 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <exception>
+#include <functional>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -94,6 +99,7 @@ struct Rccl {
     void* handle = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;      // (only the device group needs it)
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
@@ -115,6 +121,7 @@ struct Rccl {
             auto sym = [&](const char* name) { return dlsym(x.handle, name); };
             x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(sym("ncclGetUniqueId"));
             x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(sym("ncclCommInitRank"));
+            x.CommInitAll = reinterpret_cast<decltype(x.CommInitAll)>(sym("ncclCommInitAll"));
             x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
             x.CommCount = reinterpret_cast<decltype(x.CommCount)>(sym("ncclCommCount"));
             x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(sym("ncclAllReduce"));
@@ -139,10 +146,18 @@ struct Rccl {
 }  // namespace mlhip_rt
 using namespace mlhip_rt;   // (internal header: the runtime's own translation units only)
 
+struct mlhip_group;   // group.cpp
+
 struct mlhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     int num_cus = 256;
+    // Device group (mlhip_ctx_create_group): `group` is set on the context the caller holds -- it owns no stream of its own, every
+    // entry point fans out to the group's shard contexts; `member_of` / `shard` are set on those.
+    mlhip_group* group = nullptr;
+    mlhip_group* member_of = nullptr;
+    int shard = 0;
+    size_t stage_bytes = size_t(128) << 20;   // upload staging chunk (two pinned + two device buffers of this size)
     // all-reduce hook
     mlhip_allreduce_fn reduce_fn = nullptr;
     void* reduce_user = nullptr;
@@ -247,6 +262,10 @@ struct mlhip_ctx {
 
 struct mlhip_data {
     mlhip_ctx* ctx = nullptr;
+    // A block uploaded through a device group: `parts[s]` is shard s's resident block (rows first_row[s] .. first_row[s+1] of the
+    // caller's sample); nothing else below is used then.
+    std::vector<mlhip_data*> parts;
+    std::vector<uint64_t> first_row;
     int d = 0, D = 0;
     uint32_t n = 0, n_pad = 0;
     uint64_t n_global = 0;
@@ -289,6 +308,7 @@ struct mlhip_data {
 
     ~mlhip_data()
     {
+        for (mlhip_data* p : parts) mlhip_data_free(p);
         for (DevBuf* b : {&xt, &shift_dev, &lw, &lse, &esum, &ll_partials, &params_dev, &partials, &stats_dev, &resp_dev,
                           &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_cent_next, &km_partials, &km_out, &km_mind, &km_probe, &km_scale, &km_cnorm, &km_xt_pad, &kpp_w, &kpp_scr,
                           &refine_shift, &refine_stats, &params_next, &params_prev, &it_pack[0], &it_pack[1], &it_pack[2]})
@@ -465,5 +485,55 @@ int rccl_allreduce_hook(void* user, double* buf, size_t count, int on_device, vo
 void drop_rccl(mlhip_ctx* ctx);
 
 void init_rccl(mlhip_ctx* ctx, const ncclUniqueId& id, int world_size, int rank);
+
+/// A failed C-ABI status (with the calling thread's message) as the exception `guarded` maps back to it: the device group calls
+/// the entry points of its shards on worker threads and hands their failures to the thread of the caller.
+[[noreturn]] void throw_status(int status, const std::string& message);
+inline void check_status(int status) { if (status != MLHIP_OK) throw_status(status, g_error); }
+
+/// mlhip_ctx_create for one device, without the environment defaults (context.cpp).
+mlhip_ctx* create_single_context(int device_id);
+void destroy_single_context(mlhip_ctx* ctx);
+
+// ---- device group (group.cpp): one caller-visible context over n shards. Every function is the group form of the entry point of
+// the same name: host arrays are the caller's WHOLE arrays (rows of all shards), results are what a single context would return.
+namespace grp {
+mlhip_ctx* create(int n_shards, const int* device_ids);
+void destroy(mlhip_ctx* ctx);
+void synchronize(mlhip_ctx* ctx);
+int shard_count(const mlhip_ctx* ctx);
+mlhip_ctx* shard_context(const mlhip_ctx* ctx, int shard);
+const char* reduce_kind(const mlhip_ctx* ctx);
+mlhip_data* upload(mlhip_ctx* ctx, const double* x, bool on_device, uint32_t d, uint64_t n, int64_t ld);
+void sample_covariance(mlhip_ctx* ctx, mlhip_data* data, double* mean, double* covariance);
+void xxt_xy(mlhip_ctx* ctx, mlhip_data* data, const double* y, double* xxt, double* xy);
+void random_partition_means(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const uint32_t* order, const uint32_t* offsets, double* means,
+                            double* sizes);
+void em_step(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, bool diag, const double* mixing, const double* means, const double* covs,
+             double* log_likelihood, double* mixing_out, double* means_out, double* covs_out);
+void em_iterate(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, int covariance_type, double* mixing, double* means, double* covs,
+                uint32_t max_steps, double atol, double rtol, uint32_t* steps_done, int* converged, double* log_likelihood,
+                double* history);
+void em_expectation(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* mixing, const double* means, const double* covs,
+                    double* log_likelihood);
+/// source: 0 = the last E-step (mlhip_em_maximisation), 1 = caller's responsibilities, 2 = caller's labels
+void em_maximisation(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, int source, const double* resp, int64_t ldr, const uint32_t* labels,
+                     double* mixing_out, double* means_out, double* covs_out);
+void em_responsibilities(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, double* resp, int64_t ldr, uint64_t first, uint64_t count);
+void em_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, uint32_t* labels);
+/// accumulate: the update's sums as well (mlhip_kmeans_step), else the assignment only
+void kmeans_step(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, bool accumulate, const double* centroids, double* inertia,
+                 uint64_t* n_changed, double* counts, double* centroids_out);
+void kmeans_iterate(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, double* centroids, double* old_centroids, uint32_t max_steps,
+                    double atol, uint32_t* steps_done, int* converged, double* inertia, double* counts);
+void kmeans_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t* labels);
+void kmeans_distances(mlhip_ctx* ctx, mlhip_data* data, double* dist2);
+void kpp_draw(mlhip_ctx* ctx, mlhip_data* data, const double* centroid, int first, double u, uint64_t first_row, uint64_t* index,
+              int* certain, double* weights_out);
+void min_squared_distances(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* centroids, double* dist2);
+void timing_enable(mlhip_ctx* ctx, int on);
+void timing_reset(mlhip_ctx* ctx);
+void timing_get(mlhip_ctx* ctx, const char* name, double* avg_ms, uint64_t* launches);
+}  // namespace grp
 
 }  // namespace mlhip_rt

@@ -234,6 +234,7 @@ int mlhip_kmeans_step(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double
                       uint64_t* n_changed, double* counts, double* centroids_out)
 {
     return guarded([&] {
+        if (ctx && ctx->group) { grp::kmeans_step(ctx, data, K, true, centroids, inertia, n_changed, counts, centroids_out); return; }
         check_em_args(ctx, data, K);
         require(centroids && inertia && n_changed && counts && centroids_out, "null argument");
         run_kmeans(data, (int)K, centroids, true);
@@ -249,6 +250,12 @@ int mlhip_kmeans_iterate(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, double* c
                          double* inertia, double* counts)
 {
     return guarded([&] {
+        if (ctx && ctx->group) {
+            require(max_steps >= 1, "at least one step");
+            require(absolute_tolerance >= 0, "negative tolerance");
+            grp::kmeans_iterate(ctx, data, K, centroids, old_centroids, max_steps, absolute_tolerance, steps_done, converged, inertia, counts);
+            return;
+        }
         check_em_args(ctx, data, K);
         require(centroids && steps_done && converged && inertia, "null argument");
         require(max_steps >= 1, "at least one step");
@@ -262,6 +269,7 @@ int mlhip_kmeans_assign(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const doub
                         uint64_t* n_changed)
 {
     return guarded([&] {
+        if (ctx && ctx->group) { grp::kmeans_step(ctx, data, K, false, centroids, inertia, n_changed, nullptr, nullptr); return; }
         check_em_args(ctx, data, K);
         require(centroids && inertia && n_changed, "null argument");
         run_kmeans(data, (int)K, centroids, false);
@@ -274,6 +282,7 @@ int mlhip_kmeans_assign(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const doub
 int mlhip_kmeans_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t* labels)
 {
     return guarded([&] {
+        if (ctx && ctx->group) { grp::kmeans_labels(ctx, data, labels); return; }
         check_em_args(ctx, data, 1);
         require(labels || data->n == 0, "null argument");
         require(data->km_have_old, "no K-means assignment on the device yet");
@@ -286,6 +295,7 @@ int mlhip_kmeans_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t* labels)
 int mlhip_kmeans_distances(mlhip_ctx* ctx, mlhip_data* data, double* dist2)
 {
     return guarded([&] {
+        if (ctx && ctx->group) { grp::kmeans_distances(ctx, data, dist2); return; }
         check_em_args(ctx, data, 1);
         require(dist2 || data->n == 0, "null argument");
         require(data->km_have_old, "no K-means assignment on the device yet");
@@ -298,6 +308,7 @@ int mlhip_kpp_draw(mlhip_ctx* ctx, mlhip_data* data, const double* centroid, int
                    int* certain, double* weights_out)
 {
     return guarded([&] {
+        if (ctx && ctx->group) { grp::kpp_draw(ctx, data, centroid, first, u, first_row, index, certain, weights_out); return; }
         check_em_args(ctx, data, 1);
         require(centroid && index && certain, "null argument");
         require(data->n_global >= 2, "at least two rows");
@@ -369,6 +380,7 @@ int mlhip_kpp_draw(mlhip_ctx* ctx, mlhip_data* data, const double* centroid, int
 int mlhip_min_squared_distances(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* centroids, double* dist2)
 {
     return guarded([&] {
+        if (ctx && ctx->group) { grp::min_squared_distances(ctx, data, K, centroids, dist2); return; }
         check_em_args(ctx, data, K);
         require(centroids && (dist2 || data->n == 0), "null argument");
         // Must disturb neither the label history used for n_changed nor the per-sample distances of the last assignment
