@@ -158,10 +158,21 @@ class Job:
         from ml_amd import _lib
         from ml_amd import dist as mldist
         self.args, self.rank, self.local_rank, self.world, self.dist, self.torch = args, rank, local_rank, world, dist, torch
-        self.ctx = _lib.Context(local_rank)
+        self.units = args.gpus                       # GPUs (ranks, or shards of a device group) the rows are spread over
         self.allreduce = "none"
         self.rccl_ranks = 1
         self.last_ranks = {}
+        if args.single_process and args.gpus > 1:
+            # ONE process, a device group (mlhip_ctx_create_group): shard s on GPU s mod the number of visible GPUs -- the shards
+            # share a GPU when there are fewer GPUs than shards (a one-GPU rehearsal of the multi-GPU configuration)
+            self.ctx = _lib.Context.group(args.gpus)
+            self.allreduce = {"group-rccl": "rccl-native (ncclCommInitAll communicators of the library's device group)",
+                              "group-direct": "in-process fixed-order sum over the shards' buffers (device group)"}[self.ctx.reduce_kind]
+            self.rccl_ranks = self.ctx.rccl_ranks
+            self.shard_devices = self.ctx.shard_devices
+            return
+        self.ctx = _lib.Context(local_rank)
+        self.shard_devices = None
         if world > 1 or args.force_hook:
             if args.allreduce == "native":
                 try:
@@ -237,6 +248,19 @@ class Job:
                            "allreduce_ms_per_rank": [r["allreduce_ms"] for r in per_rank]}
         return elapsed, kernel_ms
 
+    def rows_per_unit(self, data, own_rows):
+        """Rows on every GPU: the ranks' shard sizes, or the device group's."""
+        if self.shard_devices is not None:
+            return [data.shard_rows(s)[1] for s in range(self.units)]
+        return self.gather(own_rows)
+
+    def layout(self):
+        """Fields of the report that say how the GPUs were driven."""
+        if self.shard_devices is None:
+            return {"processes": self.world}
+        return {"processes": 1, "device_group": {"shards": self.units, "devices": self.shard_devices,
+                                                 "shards_share_a_gpu": len(set(self.shard_devices)) < self.units}}
+
     def close(self):
         self.ctx.close()
 
@@ -281,10 +305,10 @@ def kmeans_measure(job, n, d, K, steps, warmup, with_cpu, cpu_samples):
 
     elapsed, ms = job.timed(run, steps, warmup, ["kmeans_assign"])
     k_ms = ms["kmeans_assign"]
-    n_locals = job.gather(hi - lo)
+    n_locals = job.rows_per_unit(data, hi - lo)
     out = None
     if job.rank == 0:
-        n_local = hi - lo
+        n_local = n_locals[0]
         flops = float(n_local) * K * 3 * d                  # N*K*3d (direct-form distances)
         algorithmic = flops / (k_ms * 1e-3) / 1e12
         matrix = kmeans_uses_matrix_cores(d, K)
@@ -293,12 +317,12 @@ def kmeans_measure(job, n, d, K, steps, warmup, with_cpu, cpu_samples):
         achieved = algorithmic * (2.0 / 3.0 if matrix else 1.0)
         out = {
             "metric": f"K-means steps/sec at N={n} d={d} K={K} (fp64)",
-            "value": steps / elapsed, "unit": "steps/s", "n_gpus": job.world, "steps": steps, "warmup": warmup,
+            "value": steps / elapsed, "unit": "steps/s", "n_gpus": job.units, "steps": steps, "warmup": warmup,
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"K-means (Lloyd) N={n} d={d} K={K}, row-sharded over {job.world} GPU(s)", "N": n, "d": d,
-                       "K": K, "parallelism": f"dp{job.world}", "inertia": state["inertia"]},
-            "rccl_ranks": job.rccl_ranks, "allreduce": job.allreduce, "n_local": n_locals, **job.last_ranks,
+            "config": {"workload": f"K-means (Lloyd) N={n} d={d} K={K}, row-sharded over {job.units} GPU(s)", "N": n, "d": d,
+                       "K": K, "parallelism": f"dp{job.units}", "inertia": state["inertia"]},
+            "rccl_ranks": job.rccl_ranks, "allreduce": job.allreduce, "n_local": n_locals, **job.layout(), **job.last_ranks,
             "roofline": {"bound": "mfma", "kernel": "kmeans_assign", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
                          "flops_counted": "executed: 2d per (sample, cluster) on the matrix cores" if matrix else "3d per (sample, cluster)",
@@ -359,27 +383,30 @@ def em_measure(job, n, d, K, steps, warmup, with_cpu, cpu_samples, diagonal=Fals
         assert done == k
 
     names = ["em_diag", "em_close"] if diagonal else ["em_estep", "em_mstats", "em_fused", "em_close"]
-    elapsed, ms = job.timed(run, steps, warmup, names, live=(elapsed_hint_ms(n, d, K, diagonal, job.world) >= 1.0))
+    elapsed, ms = job.timed(run, steps, warmup, names, live=(elapsed_hint_ms(n, d, K, diagonal, job.units) >= 1.0))
     ms.setdefault("em_fused_wide", 0.0)
-    n_locals = job.gather(hi - lo)
+    n_locals = job.rows_per_unit(data, hi - lo)
     if job.rank != 0:
         data.close()
         return None
 
-    n_local = hi - lo
+    n_local = n_locals[0]
     headline = (n, d, K) == (N_TOTAL, DIM, COMPONENTS) and not diagonal
     it_tflops = (diag_flops if diagonal else algorithmic_flops)(n_local, d, K) / (elapsed / steps) / 1e12
     if diagonal:
         k_ms = ms["em_diag"]
-        gbs = n_local * d * 8.0 / (k_ms * 1e-3) / 1e9          # algorithmic bytes = X once (fused)
-        roof = {"bound": "hbm", "kernel": "em_diag", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": gbs / HBM_PEAK_GBS, "traffic": None, "kernel_ms": {"em_diag": k_ms},
-                "kernel_algorithmic_tflops": diag_flops(n_local, d, K) / (k_ms * 1e-3) / 1e12,
+        # N K (8d + 25) flops over N d 8 bytes (X once, fused) = 19 flop/B at d = K = 16, above the ridge (78.6 TFLOP/s /
+        # 8 TB/s = 9.8): the BINDING roof is fp64 issue, the HBM fraction is reported beside it
+        gbs = n_local * d * 8.0 / (k_ms * 1e-3) / 1e9
+        tfl = diag_flops(n_local, d, K) / (k_ms * 1e-3) / 1e12
+        roof = {"bound": "fp64", "kernel": "em_diag", "achieved": tfl, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tfl / FP64_PEAK_TFLOPS, "traffic": None, "kernel_ms": {"em_diag": k_ms},
+                "hbm_algorithmic_gbs": gbs, "hbm_peak_gbs": HBM_PEAK_GBS, "hbm_frac": gbs / HBM_PEAK_GBS,
                 "iteration_algorithmic_tflops": it_tflops}
     elif ms["em_fused_wide"] > 0:
         k_ms = ms["em_fused_wide"]                              # E-step + statistics in one kernel: the whole iteration's flops
         achieved = algorithmic_flops(n_local, d, K) / (k_ms * 1e-3) / 1e12
-        traffic, source = traffic_for("em_fused_wide", headline and job.world == 1)
+        traffic, source = traffic_for("em_fused_wide", headline and job.units == 1)
         roof = {"bound": "mfma", "kernel": "em_fused_wide", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": source,
                 "kernel_ms": {"em_fused_wide": k_ms}, "iteration_algorithmic_tflops": it_tflops}
@@ -396,7 +423,7 @@ def em_measure(job, n, d, K, steps, warmup, with_cpu, cpu_samples, diagonal=Fals
         dom_name, dom_ms, dom_flops = ("em_estep", e_ms, estep_flops(n_local, d, K, sn)) if e_ms >= m_ms else \
                                       ("em_mstats", m_ms, mstats_flops(n_local, d, K, sn))
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
-        traffic, source = traffic_for(dom_name, headline and job.world == 1)
+        traffic, source = traffic_for(dom_name, headline and job.units == 1)
         roof = {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": source,
                 "kernel_ms": {"em_estep": e_ms, "em_mstats": m_ms, "em_close": ms.get("em_close", 0.0)},
@@ -408,12 +435,12 @@ def em_measure(job, n, d, K, steps, warmup, with_cpu, cpu_samples, diagonal=Fals
     out = {
         "metric": f"GMM-EM iterations/sec at N={n} d={d} K={K} ({kind}, fp64)" if not headline
                   else "GMM-EM iterations/sec at N=10M d=32 K=64 (full covariance, fp64)",
-        "value": steps / elapsed, "unit": "iterations/s", "n_gpus": job.world, "steps": steps, "warmup": warmup,
+        "value": steps / elapsed, "unit": "iterations/s", "n_gpus": job.units, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"GMM-EM N={n} d={d} K={K} {kind}, row-sharded over {job.world} GPU(s)",
-                   "N": n, "d": d, "K": K, "parallelism": f"dp{job.world}", "final_mean_log_likelihood": state["ll"]},
-        "rccl_ranks": job.rccl_ranks, "allreduce": job.allreduce, "n_local": n_locals, **job.last_ranks,
+        "config": {"workload": f"GMM-EM N={n} d={d} K={K} {kind}, row-sharded over {job.units} GPU(s)",
+                   "N": n, "d": d, "K": K, "parallelism": f"dp{job.units}", "final_mean_log_likelihood": state["ll"]},
+        "rccl_ranks": job.rccl_ranks, "allreduce": job.allreduce, "n_local": n_locals, **job.layout(), **job.last_ranks,
         "roofline": roof,
     }
     data.close()
@@ -508,19 +535,26 @@ def main():
                          "mlhip_em_iterate / mlhip_kmeans_iterate (device-side closing)")
     ap.add_argument("--replay-events", action="store_true",
                     help="(A/B) no HIP events inside the timed region: the kernel times come from a replay of the same steps")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N from ONE process through the library's device group (mlhip_ctx_create_group: one host thread per "
+                         "shard, RCCL between distinct GPUs, an in-process sum when shards share a GPU) instead of one process per "
+                         "GPU: what ml::EM::fit / cppyml.clustering.EM.fit use when MLHIP_NUM_GPUS is set")
     ap.add_argument("--dry-launch", action="store_true",
                     help="(test) start the ranks, join a gloo group, report the launch environment; no GPU work")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.single_process:
         return launch_ranks(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
+    if args.single_process:
+        if world != 1:
+            raise SystemExit("--single-process is ONE process driving all GPUs: do not start it through a launcher")
+    elif world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if args.dry_launch:
         return dry_launch(rank, world)
@@ -555,7 +589,7 @@ def main():
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
 
-    with_cpu = world == 1 and not args.no_cpu_baseline
+    with_cpu = args.gpus == 1 and not args.no_cpu_baseline
     if args.workload == "kmeans":
         out = kmeans_measure(job, args.n or 100_000_000, args.dim or 8, args.components or 256, args.steps, args.warmup,
                              with_cpu, args.cpu_samples)
@@ -566,7 +600,7 @@ def main():
         out = em_measure(job, args.n or N_TOTAL, args.dim or DIM, args.components or COMPONENTS, args.steps, args.warmup,
                          with_cpu, args.cpu_samples)
         default_shape = (args.n, args.dim, args.components) == (None, None, None)
-        if world == 1 and default_shape and not args.no_secondary:
+        if args.gpus == 1 and default_shape and not args.no_secondary:
             # In the same driver-timed run (the EM block has been freed above), as a LIST:
             # [0] BASELINE.json configs[4] (K-means N=100M, d=8, K=256 on 8 GPUs) at ONE GPU's share of it;
             # [1] BASELINE.json configs[1] (N=1M, d=16, K=16 diagonal-covariance GMM on one GPU) -- an iteration is ~0.1 ms, so
@@ -577,10 +611,10 @@ def main():
                 sec["config"]["workload"] += " = one GPU's row shard of BASELINE.json configs[4] (N=100M on 8 GPUs)"
                 diag["config"]["workload"] += " = BASELINE.json configs[1]"
                 out["secondary"] = [sec, diag]
-        elif world > 1 and default_shape and not args.no_secondary:
+        elif args.gpus > 1 and default_shape and not args.no_secondary:
             # multi-GPU runs: BASELINE.json configs[4] at 12.5M rows per GPU in the same driver-timed run -- N = 100M at 8 GPUs is
             # the configuration itself (weak scaling over the driver's 1 / 2 / 4 / 8 series: per-GPU work is fixed)
-            sec = kmeans_measure(job, 12_500_000 * world, 8, 256, args.steps, args.warmup, False, args.cpu_samples)
+            sec = kmeans_measure(job, 12_500_000 * args.gpus, 8, 256, args.steps, args.warmup, False, args.cpu_samples)
             if out is not None and sec is not None:
                 sec["config"]["workload"] += f" = BASELINE.json configs[4] at 12.5M rows per GPU (N=100M on 8 GPUs)"
                 sec["scaling"] = "weak"

@@ -203,6 +203,18 @@ int direct_allreduce_hook(void* user, double* buf, size_t count, int on_device, 
         }
         launch_group_sum(slots, n, buf, count, stream);
         HIP_CHECK(hipGetLastError());
+        if (const char* e = std::getenv("MLHIP_GROUP_TEST_PERTURB")) {
+            // (tests only) shard e's copy of a statistics sum is made to differ in its last digits: the end-of-fit checksum
+            // exchange of the shards must catch it (short vectors -- that exchange itself -- are left alone)
+            if (std::atoi(e) == (int)r && count > 64) {
+                double v = 0;
+                HIP_CHECK(hipMemcpyAsync(&v, buf, sizeof v, hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+                v *= 1.0 + 1e-12;
+                HIP_CHECK(hipMemcpyAsync(buf, &v, sizeof v, hipMemcpyHostToDevice, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+            }
+        }
         HIP_CHECK(hipEventRecord(g->consumed[p][r], stream));
         ++g->sequence[r];
         return 0;

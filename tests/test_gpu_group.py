@@ -178,6 +178,55 @@ def test_a_failing_call_leaves_the_group_usable(group3):
     g.close()
 
 
+def test_group_fits_carry_the_allreduce_timer_and_the_shard_checksum_guard(group3, monkeypatch):
+    """What a first run on real multi-GPU hardware needs from the group path: the all-reduce is timed on every shard's stream,
+    the route is named, and shards whose sums differ fail the fit (the ranks' end-of-fit checksum exchange, through the group)."""
+    from ml_amd import _lib
+    X, pi, mu, S = _mixture(12, 6, 20000, 9)
+    g = _lib.Data(group3, X)
+    group3.timing_reset()
+    group3.timing_enable(True)
+    out = g.em_iterate(pi, mu, S, 6)
+    ms, launches = group3.timing_get("allreduce")
+    group3.timing_enable(False)
+    assert out[0] == 6 and launches >= 6 and ms > 0.0
+    assert group3.reduce_kind == "group-direct" and group3.rccl_ranks == 0      # (group-rccl reports ncclCommCount here)
+    assert group3.timing_get("em_estep")[1] >= 6
+    monkeypatch.setenv("MLHIP_GROUP_TEST_PERTURB", "1")      # shard 1's sums differ by 1e-12 relative in one entry
+    with pytest.raises(_lib.MlhipError, match="ranks disagree"):
+        g.em_iterate(pi, mu, S, 4)
+    C0 = X[:5].copy()
+    with pytest.raises(_lib.MlhipError, match="ranks disagree"):
+        g.kmeans_iterate(C0, 4)
+    monkeypatch.delenv("MLHIP_GROUP_TEST_PERTURB")
+    assert g.em_iterate(pi, mu, S, 4)[0] == 4                # ... and the group is usable afterwards
+    g.close()
+
+
+def test_group_on_distinct_gpus_when_there_are_two():
+    """Shards on distinct GPUs: RCCL communicators from ncclCommInitAll (or, MLHIP_GROUP_REDUCE=direct, peer access). Skipped on a
+    one-GPU box."""
+    from ml_amd import _lib
+    if _lib.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    n_dev = min(_lib.device_count(), 4)
+    single = _lib.Context(0)
+    grp = _lib.Context.group(n_dev)
+    try:
+        assert grp.shard_devices == list(range(n_dev))
+        assert grp.reduce_kind == "group-rccl" and grp.rccl_ranks == n_dev
+        X, pi, mu, S = _mixture(16, 8, 40001, 2)
+        g, s = _lib.Data(grp, X), _lib.Data(single, X)
+        a, b = g.em_iterate(pi, mu, S, 30, atol=1e-9), s.em_iterate(pi, mu, S, 30, atol=1e-9)
+        assert a[0] == b[0] and a[1] == b[1] and np.max(np.abs(a[6] - b[6]) / np.abs(b[6])) < 1e-12
+        assert np.array_equal(g.em_labels(8), s.em_labels(8))
+        ka, kb = g.kmeans_iterate(X[:8].copy(), 20), s.kmeans_iterate(X[:8].copy(), 20)
+        assert ka[0] == kb[0] and relerr(ka[4], kb[4]) < 1e-12 and np.array_equal(g.kmeans_labels(), s.kmeans_labels())
+        g.close(); s.close()
+    finally:
+        grp.close(); single.close()
+
+
 def test_facade_fit_through_a_group_matches_the_single_gpu_fit():
     """ml::EM::fit / KMeans::fit (through the Python mirror of cppyml.clustering) on a group context: the caller hands over ONE
     N x d array, exactly as with the reference, and gets the single-GPU results."""

@@ -15,12 +15,20 @@ def ctx():
     c.close()
 
 
-def test_em_full_size_properties(ctx):
+@pytest.fixture(scope="module")
+def headline():
+    """The N=10M, d=32, K=64 block of BASELINE.json configs[2] / [3] (2.56 GB on the host), generated once for the module."""
+    from ml_amd import synth
+    mix = synth.Mixture(32, 64)
+    X, comp = mix.sample(10_000_000)
+    return mix, X, comp
+
+
+def test_em_full_size_properties(ctx, headline):
     """N=10M, d=32, K=64 (BASELINE.json configs[2])."""
-    from ml_amd import _lib, synth
+    from ml_amd import _lib
     n, d, K = 10_000_000, 32, 64
-    mix = synth.Mixture(d, K)
-    X, comp = mix.sample(n)
+    mix, X, comp = headline
     dt = _lib.Data(ctx, X)
     mean, cov = dt.sample_covariance()
     assert np.max(np.abs(mean - X[:200000].mean(axis=0))) < 0.1          # sanity on a prefix
@@ -113,3 +121,89 @@ def test_kmeans_large_properties(ctx):
     i2, ch2 = dt.kmeans_assign(C)
     assert ch2 == 0 and abs(i2 - inertia) <= 1e-13 * inertia
     dt.close()
+
+
+def test_config_D_as_eight_shards_matches_the_one_shard_run(ctx, headline):
+    """BASELINE.json configs[3] -- N=10M, d=32, K=64 row-sharded over 8 GPUs, one statistics all-reduce per iteration -- at FULL
+    size through the library's device group: 8 shards of 1.25M rows, here all on the one GPU of the box (the in-process
+    fixed-order all-reduce stands in for RCCL; everything else -- sharding, per-shard kernels, closing arithmetic on every shard,
+    the end-of-fit checksum exchange that holds the shards to bit-identical parameters -- is the 8-GPU code path). Against the
+    one-shard run of the same block: the log-likelihood history of 6 iterations to 1e-12, a converge run with the same number
+    of steps and bit-exact labels on all 10M rows."""
+    from ml_amd import _lib
+    n, d, K = 10_000_000, 32, 64
+    mix, X, _ = headline
+    grp = _lib.Context.group(8, device_ids=[0] * 8)
+    try:
+        g, s = _lib.Data(grp, X), _lib.Data(ctx, X)
+        assert [g.shard_rows(i)[1] for i in range(8)] == [1_250_000] * 8
+        _, cov = s.sample_covariance()
+        _, cov_g = g.sample_covariance()
+        assert np.max(np.abs(cov_g - cov)) <= 1e-12 * np.max(np.abs(cov))
+        pi, mu, S = np.full(K, 1.0 / K), mix.initial_means(), np.stack([cov] * K)
+        a = g.em_iterate(pi, mu, S, 6)
+        b = s.em_iterate(pi, mu, S, 6)
+        assert a[0] == b[0] == 6
+        assert np.max(np.abs(a[6] - b[6]) / np.abs(b[6])) < 1e-12, (a[6], b[6])
+        assert np.max(np.abs(a[4] - b[4])) <= 1e-10 * np.max(np.abs(b[4]))
+        assert np.max(np.abs(a[5] - b[5])) <= 1e-9 * np.max(np.abs(b[5]))
+        # converge run from the same start (tolerance 1e-8 on the mean log-likelihood): same steps, bit-exact labels everywhere
+        a = g.em_iterate(pi, mu, S, 60, atol=1e-8)
+        b = s.em_iterate(pi, mu, S, 60, atol=1e-8)
+        assert a[1] and b[1] and a[0] == b[0], (a[0], b[0])
+        assert abs(a[2] - b[2]) <= 1e-12 * abs(b[2])
+        la, lb = g.em_labels(K), s.em_labels(K)
+        assert np.array_equal(la, lb)
+        g.close(); s.close()
+    finally:
+        grp.close()
+
+
+def test_config_E_full_size_on_one_gpu_and_as_eight_shards(ctx, oracle):
+    """BASELINE.json configs[4] -- K-means N=100M, d=8, K=256 on 8 GPUs -- at FULL size (6.4 GB block): 4 Lloyd steps on one
+    context with the per-step invariants, the labels of a 1M-row prefix against the oracle's assignment_step, and the same
+    steps as 8 shards of 12.5M rows through the device group (counts equal, inertia 1e-12, all 100M labels equal)."""
+    from ml_amd import _lib, synth
+    n, d, K = 100_000_000, 8, 256
+    mix = synth.Mixture(d, K, seed=77, diagonal=True)
+    X, _ = mix.sample(n)
+    C0 = mix.means + 0.3 * np.random.default_rng(1).standard_normal((K, d))
+    dt = _lib.Data(ctx, X)
+    C, inertias, per_step = C0, [], []
+    for step in range(4):
+        inertia, changed, counts, C_new = dt.kmeans_step(C)
+        assert counts.sum() == n and (changed == n if step == 0 else changed < n)
+        inertias.append(inertia)
+        per_step.append((inertia, changed, counts))
+        C_prev, C = C, C_new
+    assert all(b <= a * (1 + 1e-12) for a, b in zip(inertias, inertias[1:])), inertias   # Lloyd never increases inertia
+    labels = dt.kmeans_labels()
+    dist2 = dt.kmeans_distances()
+    # the last assignment (against C_prev) on the first 1M rows: labels AND distances as the reference's assignment_step gives them
+    m = 1_000_000
+    km = oracle.KMeans(K)
+    km.set_centroids(C_prev, m)
+    km.assignment_step(np.ascontiguousarray(X[:m]))
+    assert np.array_equal(labels[:m], km.labels)
+    want = ((X[:m] - C_prev[km.labels]) ** 2).sum(axis=1)
+    assert np.max(np.abs(dist2[:m] - want)) <= 1e-12 * np.max(want)
+    for k in (0, 255):                                   # the returned means are the means of the assigned rows
+        sel = X[labels == k]
+        assert sel.shape[0] == per_step[-1][2][k]
+        assert np.max(np.abs(sel.mean(axis=0) - C[k])) <= 1e-11 * max(1.0, np.max(np.abs(C[k])))
+    dt.close()
+    grp = _lib.Context.group(8, device_ids=[0] * 8)
+    try:
+        g = _lib.Data(grp, X)
+        assert [g.shard_rows(i)[1] for i in range(8)] == [12_500_000] * 8
+        Cg = C0
+        for step in range(4):
+            inertia, changed, counts, Cg = g.kmeans_step(Cg)
+            ref = per_step[step]
+            assert changed == ref[1] and np.array_equal(counts, ref[2])
+            assert abs(inertia - ref[0]) <= 1e-12 * ref[0]
+        assert np.max(np.abs(Cg - C)) <= 1e-13 * np.max(np.abs(C))
+        assert np.array_equal(g.kmeans_labels(), labels)
+        g.close()
+    finally:
+        grp.close()
