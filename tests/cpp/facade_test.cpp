@@ -319,13 +319,91 @@ static void gpu_checks()
     unlink(id_file.c_str());
 }
 
+// The reference's API is ONE process handing ONE d x N block to fit (ML/EM.cpp:91, ML/KMeans.cpp:25). Through a device group the same
+// call drives several GPUs (here: several shards on GPU 0 -- the in-process all-reduce): `explicit_group` builds the group through
+// the C ABI and installs it, otherwise the facade's own default context must already be one (MLHIP_NUM_GPUS / MLHIP_DEVICES in the
+// environment: mode "env-group").
+static void group_checks(bool explicit_group)
+{
+    std::default_random_engine rng(11);
+    std::normal_distribution<double> standard_normal;
+    const unsigned K = 3, d = 5, n = 30001;
+    MatrixXd data(d, n);
+    for (unsigned i = 0; i < n; ++i)
+        for (unsigned l = 0; l < d; ++l) data(l, i) = standard_normal(rng) + 5.0 * (i % K) * ((l & 1) ? 1.0 : -0.5);   // three well separated clusters
+    auto fit_em = [&](ml::EM& em) {
+        em.set_absolute_tolerance(1e-9);
+        em.set_relative_tolerance(0);
+        em.set_maximum_steps(200);
+        em.set_means_initialiser(std::make_shared<ml::Clustering::KPP>());
+        em.set_seed(4242);
+        return em.fit(data);
+    };
+    ml::EM one(K);
+    ml::Clustering::KMeans km_one(K);
+    km_one.set_seed(99);
+    km_one.set_centroids_initialiser(std::make_shared<ml::Clustering::RandomPartition>());
+    mlhip_ctx* single = nullptr;
+    CHECK(mlhip_ctx_create(0, &single) == MLHIP_OK);
+    ml::device::set_context(single);
+    CHECK(fit_em(one));
+    CHECK(km_one.fit(data));
+    one.release_device_data();
+    ml::device::set_context(nullptr);
+
+    mlhip_ctx* group = nullptr;
+    if (explicit_group) {
+        const int devices[4] = {0, 0, 0, 0};
+        CHECK(mlhip_ctx_create_group(4, devices, &group) == MLHIP_OK);
+        ml::device::set_context(group);
+    }
+    int shards = 0, world = 0, rank = -1;
+    const char* kind = "";
+    CHECK(mlhip_ctx_shards(ml::device::context(), &shards) == MLHIP_OK && shards == 4);
+    CHECK(mlhip_ctx_world(ml::device::context(), &world, &rank) == MLHIP_OK && world == 1 && rank == 0);
+    CHECK(mlhip_ctx_reduce_kind(ml::device::context(), &kind) == MLHIP_OK && std::strncmp(kind, "group-", 6) == 0);
+    ml::EM many(K);
+    CHECK(fit_em(many));
+    CHECK(many.steps_done() == one.steps_done());
+    CHECK(std::abs(many.log_likelihood() - one.log_likelihood()) <= 1e-12 * std::abs(one.log_likelihood()));
+    CHECK(many.labels() == one.labels());
+    for (unsigned k = 0; k < K; ++k) {
+        CHECK(std::abs(many.mixing_probabilities()[k] - one.mixing_probabilities()[k]) <= 1e-11);
+        for (unsigned l = 0; l < d; ++l) CHECK(std::abs(many.means()(l, k) - one.means()(l, k)) <= 1e-10);
+    }
+    CHECK(many.responsibilities().rows() == n);
+    double worst = 0;
+    for (unsigned i = 0; i < n; i += 97)
+        for (unsigned k = 0; k < K; ++k) worst = std::max(worst, std::abs(many.responsibilities()(i, k) - one.responsibilities()(i, k)));
+    CHECK(worst <= 1e-11);
+    ml::Clustering::KMeans km_many(K);
+    km_many.set_seed(99);
+    km_many.set_centroids_initialiser(std::make_shared<ml::Clustering::RandomPartition>());
+    CHECK(km_many.fit(data));
+    CHECK(km_many.labels() == km_one.labels());
+    CHECK(std::abs(km_many.inertia() - km_one.inertia()) <= 1e-12 * km_one.inertia());
+    many.release_device_data();
+    if (explicit_group) {
+        ml::device::set_context(nullptr);
+        CHECK(mlhip_ctx_destroy(group) == MLHIP_OK);
+    }
+    CHECK(mlhip_ctx_destroy(single) == MLHIP_OK);
+}
+
 int main(int argc, char** argv)
 {
     const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
+    const bool env_group = argc > 1 && std::strcmp(argv[1], "env-group") == 0;
     try {
+        if (env_group) {
+            group_checks(false);
+            std::printf(failures ? "%d FAILURES\n" : "OK (%d failures)\n", failures);
+            return failures ? 1 : 0;
+        }
         host_checks();
         ldlt_checks();
         if (gpu) gpu_checks();
+        if (gpu) group_checks(true);
     } catch (const std::exception& e) {
         std::printf("FAIL unexpected exception: %s\n", e.what());
         ++failures;

@@ -58,3 +58,15 @@ def test_cpp_facade_full_fits():
     _build()
     out = subprocess.run([EXE, "gpu"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_facade_picks_up_a_device_group_from_the_environment():
+    """MLHIP_NUM_GPUS=4 and nothing else: ml::device::context() is a device group (shard s on GPU s mod the number of GPUs), and
+    ml::EM::fit / KMeans::fit on ONE data block return the single-GPU results -- from plain C++, no launcher, no hook."""
+    _build()
+    env = dict(os.environ, MLHIP_NUM_GPUS="4")
+    env.pop("LOCAL_RANK", None)
+    env.pop("MLHIP_DEVICES", None)
+    out = subprocess.run([EXE, "env-group"], capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
