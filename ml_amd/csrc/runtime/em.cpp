@@ -1,5 +1,5 @@
-// EM family of the C ABI: E-step / statistics / closing orchestration of the gfx950 kernels, per step (closing on the host) and
-// as the whole loop of EM::fit (mlhip_em_iterate: closing on the device, synchronous or lagged), full and diagonal covariances.
+// EM family of the C ABI: E-step / statistics / closing orchestration of the gfx950 kernels per step (closing on the host), full
+// and diagonal covariances; the whole loop of EM::fit (mlhip_em_iterate: closing on the device) lives in em_loop.cpp.
 #include "internal.hpp"
 
 namespace mlhip_rt {
@@ -83,15 +83,15 @@ void prepare_estep(mlhip_data* dt, int K, const double* mixing, const double* me
 
 /// E-step kernel on the records in params_dev: fills lw and -- unless the statistics kernel is going to normalise the
 /// log-responsibilities itself (`with_lse` false, matrix-core kernel only) -- lse and the log-likelihood partials.
-void launch_estep(mlhip_data* dt, int K, bool with_lse)
+void launch_estep(mlhip_data* dt, int K, bool with_lse, const DevBuf* records, int fold)
 {
     mlhip_ctx* ctx = dt->ctx;
     EstepArgs a{};
     a.xt = dt->xt.as<double>(); a.ldx = dt->ldx; a.n = dt->n; a.D = dt->D;
-    a.params = dt->params_dev.as<double>(); a.K = K;
+    a.params = (records ? records : &dt->params_dev)->as<double>(); a.K = K;
     a.lw = dt->lw.as<double>(); a.ldr = dt->ldr; a.lse = dt->lse.as<double>();
     a.ll_partials = dt->ll_partials.as<double>(); a.n_ll_partials = kMaxLlPartials;
-    a.shift = dt->shift_dev.as<double>(); a.fold = dt->estep_fold ? 1 : 0;
+    a.shift = dt->shift_dev.as<double>(); a.fold = (fold < 0 ? dt->estep_fold : fold != 0) ? 1 : 0;
     a.with_lse = (with_lse || dt->estep_variant != 2) ? 1 : 0;
     int grid = 0;
     ctx->timed("em_estep", [&] {
@@ -172,12 +172,12 @@ bool fused_step_applies(const mlhip_data* dt, int K)
 
 /// The fused kernel + reduction on the records already in params_dev; statistics end in stats_dev (and, with `collect`, all-
 /// reduced in stats_host).
-void launch_fused_step(mlhip_data* dt, int K, bool collect)
+void launch_fused_step(mlhip_data* dt, int K, bool collect, const DevBuf* records)
 {
     mlhip_ctx* ctx = dt->ctx;
     FusedArgs a{};
     a.xt = dt->xt.as<double>(); a.ldx = dt->ldx; a.n = dt->n; a.d = dt->d;
-    a.shift = dt->shift_dev.as<double>(); a.params = dt->params_dev.as<double>(); a.K = K;
+    a.shift = dt->shift_dev.as<double>(); a.params = (records ? records : &dt->params_dev)->as<double>(); a.K = K;
     a.lse = dt->lse.as<double>();
     a.partials = dt->partials.as<double>(); a.partials_capacity = dt->partials.bytes / sizeof(double);
     a.ll_partials = dt->ll_partials.as<double>(); a.n_ll_partials = kMaxLlPartials;
@@ -357,12 +357,12 @@ void finalize_out(mlhip_data* dt, int K, double* mixing_out, double* means_out, 
 
 /// One diagonal-covariance EM iteration's device work (em_diag.hip) with the statistics shift at `shift_dev`; leaves the
 /// all-reduced [K * (2d+1) statistics, ll_sum] in stats_host. The records must already be in params_dev.
-void run_diag_kernel(mlhip_data* dt, int K, const double* shift_dev, bool collect)
+void run_diag_kernel(mlhip_data* dt, int K, const double* shift_dev, bool collect, const DevBuf* records)
 {
     mlhip_ctx* ctx = dt->ctx;
     DiagArgs a{};
     a.xt = dt->xt.as<double>(); a.ldx = dt->ldx; a.n = dt->n; a.d = dt->d;
-    a.shift = shift_dev; a.params = dt->params_dev.as<double>(); a.K = K;
+    a.shift = shift_dev; a.params = (records ? records : &dt->params_dev)->as<double>(); a.K = K;
     a.lse = dt->lse.as<double>();
     a.partials = dt->partials.as<double>(); a.partials_capacity = dt->partials.bytes / sizeof(double);
     a.ll_partials = dt->ll_partials.as<double>(); a.n_ll_partials = kMaxLlPartials;
@@ -508,294 +508,6 @@ void em_step_diag(mlhip_data* data, int K, const double* mixing, const double* m
     refine_diag(data, K, mixing_out, means_out, variances_out);
 }
 
-
-/// The loop of EM::fit (ML/EM.cpp:143-170) with everything between two convergence tests on the device: E-step, statistics,
-/// all-reduce, closing arithmetic + next records (em_close.hip); per iteration the host reads back 1 + 2K doubles (log-
-/// likelihood sum, refinement flags, FOLD criterion) and decides. A flagged component (far, tight cluster) sends that one
-/// iteration through the host closing with its refinement pass, exactly as mlhip_em_step would. MLHIP_DEVICE_CLOSE=0, or
-/// d > 64, runs the whole loop through the per-step functions.
-void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* means, double* covs, uint32_t max_steps, double atol,
-                double rtol, uint32_t* steps_done, int* converged, double* log_likelihood, double* history)
-{
-    mlhip_ctx* ctx = data->ctx;
-    const int d = data->d;
-    *steps_done = 0;
-    *converged = 0;
-    double old_ll = -HUGE_VAL;
-    auto test = [&](uint32_t step, double ll) {       // ML/EM.cpp:161-168
-        if (history) history[step] = ll;
-        *log_likelihood = ll;
-        *steps_done = step + 1;
-        if (step > 0) {
-            const double change = std::fabs(ll - old_ll);
-            if (change < atol + rtol * std::max(std::fabs(old_ll), std::fabs(ll))) { *converged = 1; return true; }
-        }
-        old_ll = ll;
-        return false;
-    };
-    static const bool device_close_allowed = [] { const char* e = std::getenv("MLHIP_DEVICE_CLOSE"); return !(e && e[0] == '0'); }();
-    ensure_em_workspace(data, K);
-    bool device_close = device_close_allowed && em_close_supported(d) && !(diag && !mstats::em_diag_supported(d, K));
-    if (device_close && !diag) {
-        prepare_estep(data, K, mixing, means, covs);           // records of the caller's parameters -> params_dev
-        if (data->estep_variant == 1) device_close = false;    // (experimental record layout: host closing only)
-    }
-    if (!device_close) {
-        for (uint32_t step = 0; step < max_steps; ++step) {
-            double ll = 0;
-            if (diag) em_step_diag(data, K, mixing, means, covs, &ll, mixing, means, covs);
-            else em_step_full(data, K, mixing, means, covs, &ll, mixing, means, covs);
-            if (test(step, ll)) break;
-        }
-        return;
-    }
-
-    const size_t n_cov = diag ? (size_t)K * d : (size_t)K * d * d;
-    const size_t F = diag ? diag_stats_count(d) : stats_count(d);
-    const size_t n_info = em_close_info_doubles(K);
-    const size_t n_pack = n_info + K + (size_t)K * d + n_cov;
-    for (int b = 0; b < 3; ++b) data->it_pack[b].reserve(sizeof(double) * n_pack);
-    data->it_info_host.reserve(sizeof(double) * n_pack);          // info, then (diagonal mode) a shadow of the newest parameters
-    // Full covariances: the closing kernel writes its 1 + 2K info doubles (log-likelihood sum, refinement flags, FOLD bounds) straight
-    // into pinned host memory -- no hipMemcpyAsync in the loop (one API call and one copy-engine round trip less per iteration).
-    // Diagonal mode: its whole pack (info + the K (2d + 1) parameters the host shadows every iteration, a few KB) lives in pinned
-    // memory. MLHIP_INFO_PINNED=0: device packs and the copy.
-    static const bool info_pinned_allowed = [] { const char* e = std::getenv("MLHIP_INFO_PINNED"); return !(e && e[0] == '0'); }();
-    const bool info_pinned = info_pinned_allowed && !diag;
-    const bool pack_pinned = info_pinned_allowed && diag;
-    if (pack_pinned)
-        for (int b = 0; b < 3; ++b) data->it_info_slot[b].reserve(sizeof(double) * n_pack);
-    auto pack_base = [&](int b) { return pack_pinned ? data->it_info_slot[b].as<double>() : data->it_pack[b].as<double>(); };
-    auto pack_mixing = [&](int b) { return pack_base(b) + n_info; };
-    auto pack_means = [&](int b) { return pack_mixing(b) + K; };
-    auto pack_covs = [&](int b) { return pack_means(b) + (size_t)K * d; };
-    if (diag) {
-        upload_diag_records(data, K, mixing, means, covs, data->params_dev);
-        upload_diag_records(data, K, mixing, means, covs, data->params_next);          // (the neutral padding records live in both)
-        data->diag_mixing.assign(mixing, mixing + K);
-        data->diag_means.assign(means, means + (size_t)K * d);
-        data->diag_vars.assign(covs, covs + (size_t)K * d);
-    } else {
-        data->params_next.reserve(data->params_dev.bytes);
-    }
-    data->diag_step = diag;
-    const bool fused = !diag && data->estep_variant == 0 && fused_step_applies(data, K);
-    const bool self_norm = !diag && !fused && data->estep_variant == 2 && self_norm_applies(data, K);
-    static const bool fold_allowed = [] { const char* e = std::getenv("MLHIP_ESTEP_FOLD"); return !(e && e[0] == '0'); }();
-    const double limit = refine_ratio();
-    std::vector<double> prev_mixing, prev_means, prev_vars;     // diag: the inputs of the E-step before the newest parameters
-    int cur = 0;
-    bool latest_on_host = true;
-    double* info = data->it_info_host.as<double>();
-    double* shadow = info + n_info;
-
-    // One iteration's device work: E-step + statistics from the records in params_dev, all-reduce, closing arithmetic into
-    // it_pack[out] and the next records into params_next. Nothing here waits for the device.
-    auto launch_iteration = [&](int out, double* info_host) {
-        if (diag) {
-            run_diag_kernel(data, K, data->shift_dev.as<double>(), false);
-        } else if (fused) {
-            launch_fused_step(data, K, false);
-        } else {
-            launch_estep(data, K, !self_norm);
-            run_mstats(data, K, self_norm ? kFromLogRespSelfNorm : kFromLogResp, nullptr, 0, true, false);
-        }
-        data->have_estep = true;
-        data->lw_valid = !(diag || fused);
-        allreduce_stats_dev(data, (size_t)K * F + 1);
-        CloseArgs ca{};
-        ca.stats = data->stats_dev.as<double>(); ca.K = K; ca.d = d; ca.D = data->D;
-        ca.shift = data->shift_dev.as<double>(); ca.n_global = (double)data->n_global;
-        ca.layout = data->estep_variant; ca.refine_limit = limit;
-        ca.mixing = pack_mixing(out); ca.means = pack_means(out);
-        ca.covs = pack_covs(out); ca.records = data->params_next.as<double>();
-        ca.info = info_pinned ? info_host : pack_base(out);
-        ctx->timed("em_close", [&] { if (diag) launch_em_close_diag(ca, ctx->stream); else launch_em_close(ca, ctx->stream); });
-        HIP_CHECK(hipGetLastError());
-    };
-
-    // ---- lagged loop (small shapes: an iteration is tens of microseconds, of which the host's launches and its wait for the
-    // read-back are most). Iteration i + 1 is launched BEFORE the host looks at iteration i's log-likelihood: the convergence
-    // test of ML/EM.cpp:161-168 then fires one iteration late, and the speculative iteration is simply dropped -- three record
-    // buffers and three packs keep the inputs and outputs of iteration i intact while i + 1 runs, so the results are
-    // bit-identical to the synchronous loop. Not taken when the host has to decide something per iteration (FOLD form of the
-    // matrix-core E-step) or carries the all-reduce itself (host hooks); a refinement flag (far, tight component) rolls the
-    // loop back to the flagged iteration and hands over to the synchronous loop below. MLHIP_LAGGED=0: off.
-    static const bool lagged_allowed = [] { const char* e = std::getenv("MLHIP_LAGGED"); return !(e && e[0] == '0'); }();
-    // ... and only where an iteration is short enough for the host's share to matter: the speculative iteration is thrown away
-    // once per fit (and the log-responsibilities it overwrote are rebuilt on demand), which a long iteration never earns back
-    // (N = 10M, d = 8, K = 32: 2.2 ms per iteration against ~10 us saved per iteration).
-    // (from the GLOBAL row count: every rank -- every shard of a device group -- must take the same loop, or a lagged rank's
-    // speculative all-reduce would meet another rank's end-of-fit exchange)
-    const double pair_work = (double)data->n_global / (double)std::max(1, ctx->world_size) * K * (diag ? d : d * d);
-    // The matrix-core E-step (d >= 12) joins it in its EXACT form: the FOLD form is a per-iteration decision of the host (from the
-    // closing kernel's bound on |W (mu - shift)|), which a loop that does not wait for the host cannot take; the records carry both
-    // vectors, so no FOLD simply means a.fold = 0 (32 more subtractions per 64 samples and component at d = 32: a few per cent of
-    // an E-step that is short here by construction). MLHIP_LAGGED_WORK overrides the bound on N K d^2.
-    static const double work_limit = [] { const char* e = std::getenv("MLHIP_LAGGED_WORK"); return e ? std::atof(e) : 2.0e9; }();
-    const bool lagged = lagged_allowed && (!ctx->reduce_fn || ctx->reduce_on_device) && max_steps >= 2 &&
-                        pair_work <= (diag ? 1.0e9 : work_limit);
-    if (lagged && !diag && data->estep_variant == 2) data->estep_fold = false;
-    uint32_t first_sync_step = 0;
-    if (lagged) {
-        const size_t copy_doubles = diag ? n_pack : n_info;
-        for (int b = 0; b < 3; ++b) {
-            data->it_info_slot[b].reserve(sizeof(double) * n_pack);
-            if (!data->it_event[b]) HIP_CHECK(hipEventCreateWithFlags(&data->it_event[b], hipEventDisableTiming));
-        }
-        data->params_prev.reserve(data->params_dev.bytes);
-        data->params_next.reserve(data->params_dev.bytes);
-        std::vector<double> shadow_of[3];                        // diag: host copy of pack b's parameters (inputs of an E-step)
-        if (diag) {
-            // the neutral padding records must live in all three record buffers (params_next may just have been re-allocated)
-            upload_diag_records(data, K, mixing, means, covs, data->params_next);
-            upload_diag_records(data, K, mixing, means, covs, data->params_prev);
-            shadow_of[0].assign(mixing, mixing + K);
-            shadow_of[0].insert(shadow_of[0].end(), means, means + (size_t)K * d);
-            shadow_of[0].insert(shadow_of[0].end(), covs, covs + n_cov);
-        }
-        auto launch = [&](uint32_t i) {                          // iteration i: records R_i (params_dev) -> R_(i+1), pack (i+1) % 3
-            const int out = (int)((i + 1) % 3);
-            launch_iteration(out, data->it_info_slot[out].as<double>());
-            if (!info_pinned && !pack_pinned)
-                HIP_CHECK(hipMemcpyAsync(data->it_info_slot[out].p, data->it_pack[out].p, sizeof(double) * copy_doubles, hipMemcpyDeviceToHost,
-                                         ctx->stream));
-            HIP_CHECK(hipEventRecord(data->it_event[out], ctx->stream));
-            // rotate: params_dev <- R_(i+1), params_prev <- R_i, params_next <- the buffer of R_(i-1) (evaluated, free)
-            std::swap(data->params_prev, data->params_dev);      // prev = R_i, dev = old prev
-            std::swap(data->params_dev, data->params_next);      // dev = R_(i+1), next = old prev
-        };
-        launch(0);
-        uint32_t launched = 1;
-        bool handed_over = false, stopped = false;
-        uint32_t last = 0;
-        for (uint32_t i = 0; i < max_steps; ++i) {
-            if (i + 1 < max_steps) { launch(i + 1); launched = i + 2; }
-            const int slot = (int)((i + 1) % 3);
-            HIP_CHECK(hipEventSynchronize(data->it_event[slot]));
-            const double* inf = data->it_info_slot[slot].as<double>();
-            const double ll = inf[0] / (double)data->n_global - (double)d * log_two_pi() / 2;   // ML/EM.cpp:197-198, 211
-            bool flagged = false;
-            for (int k = 0; k < K; ++k) flagged = flagged || inf[1 + k] != 0.0;
-            if (diag) shadow_of[slot].assign(inf + n_info, inf + n_info + K + (size_t)K * d + n_cov);
-            last = i;
-            if (flagged) {
-                // roll back to the start of iteration i: records R_i into params_dev, parameters P_i into the caller's arrays
-                ctx->sync();
-                if (launched == i + 2) std::swap(data->params_dev, data->params_next);     // (next holds R_i after two rotations)
-                else std::swap(data->params_dev, data->params_prev);
-                if (i > 0) {
-                    const int in = (int)(i % 3);
-                    HIP_CHECK(hipMemcpyAsync(mixing, pack_mixing(in), sizeof(double) * K, hipMemcpyDefault, ctx->stream));
-                    HIP_CHECK(hipMemcpyAsync(means, pack_means(in), sizeof(double) * K * d, hipMemcpyDefault, ctx->stream));
-                    HIP_CHECK(hipMemcpyAsync(covs, pack_covs(in), sizeof(double) * n_cov, hipMemcpyDefault, ctx->stream));
-                    ctx->sync();
-                }
-                if (diag) {
-                    const std::vector<double>& sh = shadow_of[i % 3];
-                    data->diag_mixing.assign(sh.begin(), sh.begin() + K);
-                    data->diag_means.assign(sh.begin() + K, sh.begin() + K + (size_t)K * d);
-                    data->diag_vars.assign(sh.begin() + K + (size_t)K * d, sh.end());
-                    upload_diag_records(data, K, mixing, means, covs, data->params_next);   // (its neutral padding records)
-                }
-                first_sync_step = i;
-                handed_over = true;
-                break;
-            }
-            if (test(i, ll) || i + 1 == max_steps) { stopped = true; break; }
-        }
-        if (!handed_over) {
-            (void)stopped;
-            ctx->sync();                                         // a speculative iteration may still be running: let it finish
-            // device state as the synchronous loop leaves it: the records of the LAST evaluated E-step in params_dev; what the
-            // speculative iteration overwrote (log-responsibilities, lse) is rebuilt from them on demand
-            const bool speculated = launched == last + 2;
-            if (speculated) { std::swap(data->params_dev, data->params_next); data->lw_valid = false; }
-            else std::swap(data->params_dev, data->params_prev);
-            const int res = (int)((last + 1) % 3);               // P_(last+1): the newest parameters
-            HIP_CHECK(hipMemcpyAsync(mixing, pack_mixing(res), sizeof(double) * K, hipMemcpyDefault, ctx->stream));
-            HIP_CHECK(hipMemcpyAsync(means, pack_means(res), sizeof(double) * K * d, hipMemcpyDefault, ctx->stream));
-            HIP_CHECK(hipMemcpyAsync(covs, pack_covs(res), sizeof(double) * n_cov, hipMemcpyDefault, ctx->stream));
-            ctx->sync();
-            if (diag) {                                          // ensure_lw rebuilds the block from the inputs of the last E-step
-                const std::vector<double>& sh = shadow_of[last % 3];
-                data->diag_mixing.assign(sh.begin(), sh.begin() + K);
-                data->diag_means.assign(sh.begin() + K, sh.begin() + K + (size_t)K * d);
-                data->diag_vars.assign(sh.begin() + K + (size_t)K * d, sh.end());
-            }
-            return;
-        }
-    }
-
-    for (uint32_t step = first_sync_step; step < max_steps; ++step) {
-        PhaseTrace tr;
-        const int nxt = cur ^ 1;
-        launch_iteration(nxt, info);
-        // one read-back: the info block and, in diagonal mode (small), a host shadow of the newest parameters right behind it
-        // (ensure_lw needs the inputs of the last E-step)
-        if (pack_pinned) { info = pack_base(nxt); shadow = info + n_info; }        // (read in place)
-        else if (!info_pinned)
-            HIP_CHECK(hipMemcpyAsync(info, data->it_pack[nxt].p, sizeof(double) * (diag ? n_pack : n_info), hipMemcpyDeviceToHost, ctx->stream));
-        ctx->sync();
-        tr.mark("iteration (device close)");
-        const double ll = info[0] / (double)data->n_global - (double)d * log_two_pi() / 2;   // ML/EM.cpp:197-198, 211
-        bool flagged = false;
-        double cmax = 0.0;
-        for (int k = 0; k < K; ++k) {
-            flagged = flagged || info[1 + k] != 0.0;
-            cmax = std::max(cmax, info[1 + K + k]);
-        }
-        bool fold_next = false;
-        if (flagged) {
-            // a far, tight component: this iteration is closed on the host, refinement pass included (the per-step arithmetic)
-            HIP_CHECK(hipMemcpyAsync(data->stats_host.p, data->stats_dev.p, sizeof(double) * ((size_t)K * F + 1),
-                                     hipMemcpyDeviceToHost, ctx->stream));
-            ctx->sync();
-            if (diag) {
-                host::finalize_mstep_diag(d, K, data->stats_host.as<double>(), data->shift.data(), (double)data->n_global, mixing, means, covs);
-                refine_diag(data, K, mixing, means, covs);
-                upload_diag_records(data, K, mixing, means, covs, data->params_next);
-                prev_mixing = data->diag_mixing; prev_means = data->diag_means; prev_vars = data->diag_vars;
-                data->diag_mixing.assign(mixing, mixing + K);
-                data->diag_means.assign(means, means + (size_t)K * d);
-                data->diag_vars.assign(covs, covs + (size_t)K * d);
-            } else {
-                finalize_out(data, K, mixing, means, covs);
-                const int variant = data->estep_variant;
-                const bool fold_now = data->estep_fold;
-                prepare_estep(data, K, mixing, means, covs, &data->params_next);
-                fold_next = data->estep_fold;
-                data->estep_fold = fold_now;                     // (still describes the records in params_dev)
-                if (data->estep_variant != variant) throw std::runtime_error("E-step record layout changed inside a fit");
-            }
-            latest_on_host = true;
-        } else {
-            latest_on_host = false;
-            cur = nxt;
-            fold_next = fold_allowed && data->estep_variant == 2 && data->D <= kRegDim && cmax <= kEstepFoldLimit;
-            if (diag) {
-                prev_mixing = data->diag_mixing; prev_means = data->diag_means; prev_vars = data->diag_vars;
-                data->diag_mixing.assign(shadow, shadow + K);
-                data->diag_means.assign(shadow + K, shadow + K + (size_t)K * d);
-                data->diag_vars.assign(shadow + K + (size_t)K * d, shadow + K + (size_t)K * d + n_cov);
-            }
-        }
-        const bool stop = test(step, ll);
-        if (stop || step + 1 == max_steps) break;
-        std::swap(data->params_dev, data->params_next);          // the new records become the next E-step's
-        data->estep_fold = fold_next;
-    }
-    // the caller's arrays receive the newest parameters; the device keeps the records of the LAST E-step in params_dev
-    if (!latest_on_host) {
-        HIP_CHECK(hipMemcpyAsync(mixing, pack_mixing(cur), sizeof(double) * K, hipMemcpyDefault, ctx->stream));
-        HIP_CHECK(hipMemcpyAsync(means, pack_means(cur), sizeof(double) * K * d, hipMemcpyDefault, ctx->stream));
-        HIP_CHECK(hipMemcpyAsync(covs, pack_covs(cur), sizeof(double) * n_cov, hipMemcpyDefault, ctx->stream));
-        ctx->sync();
-    }
-    if (diag && !prev_mixing.empty()) {   // ensure_lw rebuilds the block from the inputs of the last E-step
-        data->diag_mixing = prev_mixing; data->diag_means = prev_means; data->diag_vars = prev_vars;
-    }
-}
 
 }  // namespace mlhip_rt
 

@@ -286,11 +286,10 @@ struct mlhip_data {
     // diagonal-covariance extension: parameters of the last mlhip_em_step_diag (the N x K block is rebuilt from them on demand)
     bool diag_step = false;
     std::vector<double> diag_mixing, diag_means, diag_vars;
-    // mlhip_em_iterate: parameters and the next E-step's records stay on the device between iterations
-    DevBuf params_next, it_pack[3];      // it_pack: [info (1 + 2K) | mixing (K) | means (K d) | covariances], one D2H covers it
-    PinnedBuf it_info_host;
-    // ... and, for the lagged (speculative) loop of small shapes: a third record buffer, one read-back slot and event per pack
-    DevBuf params_prev;
+    // mlhip_em_iterate (em_loop.cpp): parameters and the E-steps' records stay on the device between iterations, in a ring of three --
+    // iteration i reads the records of slot i % 3 (params_dev / params_next / params_prev take turns) and writes pack and records
+    // (i + 1) % 3; it_pack: [info (1 + 2K) | mixing (K) | means (K d) | covariances]; one pinned read-back slot and event per pack
+    DevBuf params_next, params_prev, it_pack[3];
     PinnedBuf it_info_slot[3];
     hipEvent_t it_event[3] = {nullptr, nullptr, nullptr};
     // source of the last statistics pass (for the per-component refinement pass)
@@ -313,7 +312,6 @@ struct mlhip_data {
                           &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_cent_next, &km_partials, &km_out, &km_mind, &km_probe, &km_scale, &km_cnorm, &km_xt_pad, &kpp_w, &kpp_scr,
                           &refine_shift, &refine_stats, &params_next, &params_prev, &it_pack[0], &it_pack[1], &it_pack[2]})
             b->release();
-        it_info_host.release();
         for (auto& sl : it_info_slot) sl.release();
         for (auto& e : it_event) if (e) (void)hipEventDestroy(e);
         params_host.release(); stats_host.release(); km_host.release();
@@ -372,7 +370,9 @@ void prepare_estep(mlhip_data* dt, int K, const double* mixing, const double* me
 
 /// E-step kernel on the records in params_dev: fills lw and -- unless the statistics kernel is going to normalise the
 /// log-responsibilities itself (`with_lse` false, matrix-core kernel only) -- lse and the log-likelihood partials.
-void launch_estep(mlhip_data* dt, int K, bool with_lse = true);
+/// `records` / `fold`: another record buffer than params_dev and its form (mlhip_em_iterate keeps a ring of them); default: params_dev
+/// and dt->estep_fold.
+void launch_estep(mlhip_data* dt, int K, bool with_lse = true, const DevBuf* records = nullptr, int fold = -1);
 
 void run_estep(mlhip_data* dt, int K, const double* mixing, const double* means, const double* covs, bool with_lse = true);
 
@@ -389,7 +389,7 @@ bool fused_step_applies(const mlhip_data* dt, int K);
 
 /// The fused kernel + reduction on the records already in params_dev; statistics end in stats_dev (and, with `collect`, all-
 /// reduced in stats_host).
-void launch_fused_step(mlhip_data* dt, int K, bool collect);
+void launch_fused_step(mlhip_data* dt, int K, bool collect, const DevBuf* records = nullptr);
 
 bool run_fused_step(mlhip_data* dt, int K, const double* mixing, const double* means, const double* covs);
 
@@ -418,7 +418,7 @@ void finalize_out(mlhip_data* dt, int K, double* mixing_out, double* means_out, 
 
 /// One diagonal-covariance EM iteration's device work (em_diag.hip) with the statistics shift at `shift_dev`; leaves the
 /// all-reduced [K * (2d+1) statistics, ll_sum] in stats_host. The records must already be in params_dev.
-void run_diag_kernel(mlhip_data* dt, int K, const double* shift_dev, bool collect = true);
+void run_diag_kernel(mlhip_data* dt, int K, const double* shift_dev, bool collect = true, const DevBuf* records = nullptr);
 
 void ensure_km_workspace(mlhip_data* dt, int K);
 
@@ -470,8 +470,8 @@ void refine_diag(mlhip_data* data, int K, const double* mixing_out, double* mean
 void em_step_diag(mlhip_data* data, int K, const double* mixing, const double* means, const double* variances,
                   double* log_likelihood, double* mixing_out, double* means_out, double* variances_out);
 
-/// The loop of EM::fit (ML/EM.cpp:143-170) with everything between two convergence tests on the device: E-step, statistics,
-/// all-reduce, closing arithmetic + next records (em_close.hip); per iteration the host reads back 1 + 2K doubles (log-
+/// The loop of EM::fit (ML/EM.cpp:143-170) with everything between two convergence tests on the device (em_loop.cpp): E-step,
+/// statistics, all-reduce, closing arithmetic + next records (em_close.hip); per iteration the host reads back 1 + 2K doubles (log-
 /// likelihood sum, refinement flags, FOLD criterion) and decides. A flagged component (far, tight cluster) sends that one
 /// iteration through the host closing with its refinement pass, exactly as mlhip_em_step would. MLHIP_DEVICE_CLOSE=0, or
 /// d > 64, runs the whole loop through the per-step functions.
