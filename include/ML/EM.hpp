@@ -39,7 +39,8 @@ public:
     /** EXTENSION -- not part of the reference API, whose EM is full-covariance only (reference ML/EM.hpp:175). With
     `Diagonal` every covariance is restricted to its diagonal (the E-/M-step loops of ML/EM.cpp:190-263 on the diagonal
     entries only; covariances() returns diagonal matrices). Default `Full` == the reference's behaviour.
-    Diagonal mode is built for number_dimensions <= 32 and number_components <= 64 (std::runtime_error otherwise). */
+    One fused kernel serves number_dimensions <= 32 and number_components <= 64; other shapes run the full-covariance kernels on
+    diagonal matrices (slower, never refused). */
     enum class CovarianceType { Full, Diagonal };
     void set_covariance_type(CovarianceType covariance_type) { covariance_type_ = covariance_type; }
     CovarianceType covariance_type() const { return covariance_type_; }

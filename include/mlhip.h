@@ -92,7 +92,8 @@ int mlhip_ctx_set_allreduce(mlhip_ctx* ctx, mlhip_allreduce_fn fn, void* user, i
  * the others wait for it up to MLHIP_RCCL_TIMEOUT_S seconds, default 120); use a fresh path per job.
  * librccl.so.1 is loaded on first use (override: MLHIP_RCCL_LIBRARY). RCCL refuses two ranks on the same GPU.
  * Rank 0 removes the rendezvous file once the communicator exists; files older than MLHIP_RCCL_STALE_S seconds (default 600:
- * the left-over of a job that died before that) are ignored by the waiting ranks.
+ * the left-over of a job that died before that) are ignored by the waiting ranks, and so is a file whose job nonce differs (a hash
+ * of MLHIP_RCCL_NONCE, TORCHELASTIC_RUN_ID, MASTER_ADDR, MASTER_PORT as the ranks see them -- the same within a launch).
  * mlhip_rccl_available() says whether librccl can be loaded in THIS process without touching a GPU: ranks of a job can agree on
  * it (over whatever channel they have) BEFORE anyone enters the collective mlhip_ctx_init_rccl*, where a rank that cannot load
  * the library would leave the others waiting. */
@@ -248,6 +249,9 @@ int mlhip_kmeans_distances(mlhip_ctx* ctx, mlhip_data* data, double* dist2);
  * sequential evaluation. At least two rows in the whole sample. */
 int mlhip_kpp_draw(mlhip_ctx* ctx, mlhip_data* data, const double* centroid, int first, double u, uint64_t first_row, uint64_t* index,
                    int* certain, double* weights_out);
+/* The running-minimum weights the draws of mlhip_kpp_draw have left on the device (n_local doubles): fetched by the caller only when
+ * a draw was not certain -- a certified draw never moves them (ML/Clustering.cpp:44-51 keeps them in a host vector). */
+int mlhip_kpp_weights(mlhip_ctx* ctx, mlhip_data* data, double* weights_out);
 /* min_k |x_i - c_k|^2 per sample of this rank's shard (the weights of KPP::init, ML/Clustering.cpp:44-51). */
 int mlhip_min_squared_distances(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* centroids, double* dist2);
 

@@ -70,7 +70,9 @@ __global__ __launch_bounds__(256) void em_estep_kernel(const double* __restrict_
             const double lw = __builtin_fma(-0.5, q, p[PS - 1]);
             lw_out[(size_t)k * ldr + i] = lw;
             // online log-sum-exp with a single exp per component
-            const double e = exp_nonpos(-fabs(lw - m));
+            // (a component of mixing weight 0 has lw = -inf: it adds exp(-inf) = 0 like the reference's `column *= 0`, ML/EM.cpp:209 --
+            // -inf - -inf would be a NaN while the running maximum is still -inf; a genuinely NaN lw stays a NaN)
+            const double e = exp_nonpos(lw == -HUGE_VAL ? -HUGE_VAL : -fabs(lw - m));
             const bool up = lw > m;
             s = up ? __builtin_fma(s, e, 1.0) : s + e;
             m = up ? lw : m;

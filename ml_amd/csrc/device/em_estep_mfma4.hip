@@ -1,7 +1,7 @@
 // E-step of Gaussian-mixture EM on the gfx950 fp64 matrix cores with ELEMENT-BLOCK triangular work (dimensions 12..128)
 // -- replaces EM::expectation_step (reference ML/EM.cpp:190-219) and its xAx_symmetric calls (ML/LinearAlgebra.cpp:8-31).
 //
-// Same arithmetic as em_estep_mfma.hip (z = x - mu_k, y = W_k z with W_k = L_k^-1 lower triangular, q = |y|^2,
+// Same arithmetic as the 16x16x4 variant it superseded (experiments/em_estep_mfma16.hip) (z = x - mu_k, y = W_k z with W_k = L_k^-1 lower triangular, q = |y|^2,
 // lw = log pi_k - sum log L_jj - q/2, online log-sum-exp), but on v_mfma_f64_4x4x4_4b_f64: one instruction multiplies
 // FOUR independent 4x4 blocks, D_b[4 rows][4 samples] += A_b[4 x 4] * B_b[4 x 4 samples]. With the same 4x4 block of W in
 // all four A blocks and four different sample quads in B, one instruction advances 4 rows of y for 16 samples, and only
@@ -52,7 +52,7 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-/// See em_estep_mfma.hip: group g = lane>>4 ends with the sum over groups of v[g] (v_permlane16/32_swap reduce-scatter).
+/// (As in experiments/em_estep_mfma16.hip:) group g = lane>>4 ends with the sum over groups of v[g] (v_permlane16/32_swap reduce-scatter).
 __device__ __forceinline__ double reduce_scatter_groups(double v0, double v1, double v2, double v3)
 {
     auto swap16 = [](double& a, double& b) {
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64 * NW, D <= 32 ? 8 / SB : 2) void em_estep_mfma4_
 #pragma unroll
                     for (int sb = 0; sb < SB; ++sb)
                         acc[sb][R] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, z[sb], C == 0 ? init : acc[sb][R], 0, 0, 0);
-                    // Pin the block order (column-quad major, the sample blocks back to back); see em_estep_mfma.hip.
+                    // Pin the block order (column-quad major, the sample blocks back to back); the same pinning as in experiments/em_estep_mfma16.hip.
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -209,7 +209,9 @@ __global__ __launch_bounds__(64 * NW, D <= 32 ? 8 / SB : 2) void em_estep_mfma4_
                 // exp(t) is exactly 0 in fp64 for t < -745.2: when that holds for the whole wave the update would add 0 to
                 // every ssum and leave every m unchanged, so it is skipped (bit-identical result, one exp saved).
                 if (!__all(lw - m < -746.0)) {
-                    const double e = exp_nonpos(-fabs(lw - m));
+                    // (mixing weight 0: lw = -inf adds exp(-inf) = 0 as the reference's `column *= 0` does, ML/EM.cpp:209; -inf - -inf
+                    // would poison the sum while the running maximum is still -inf; a genuinely NaN lw stays a NaN)
+                    const double e = exp_nonpos(lw == -HUGE_VAL ? -HUGE_VAL : -fabs(lw - m));
                     const bool up = lw > m;
                     ssum = up ? __builtin_fma(ssum, e, 1.0) : ssum + e;
                     m = up ? lw : m;

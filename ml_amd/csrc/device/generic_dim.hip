@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void em_estep_generic_kernel(const double* __r
             }
             const double lw = __builtin_fma(-0.5, q, p[PS - 1]);
             lw_out[(size_t)k * ldr + i] = lw;
-            const double e = exp_nonpos(-fabs(lw - m));                    // online log-sum-exp, one exp per component
+            const double e = exp_nonpos(lw == -HUGE_VAL ? -HUGE_VAL : -fabs(lw - m));   // online log-sum-exp, one exp per component (lw = -inf: adds 0)
             const bool up = lw > m;
             s = up ? __builtin_fma(s, e, 1.0) : s + e;
             m = up ? lw : m;

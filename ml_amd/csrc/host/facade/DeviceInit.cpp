@@ -142,7 +142,11 @@ void kpp_sharded(const Shard& sh, ConstMatrixRef data, std::default_random_engin
 {
     const Index d = data.rows();
     const std::size_t count = static_cast<std::size_t>(data.cols());
-    std::vector<double> weights(count, 1.0), latest;
+    // Large samples: the draws on the devices (mlhip_kpp_draw: certified index, see the single-rank route below); the ranks'
+    // weights stay on their devices -- the host copy is only allocated and fetched when a draw has to be settled by the sequential
+    // evaluation (mlhip_kpp_weights; ADVICE r3: no 8 N byte host pass per fit otherwise).
+    const bool device_draw = sh.n_global >= 32768;
+    std::vector<double> weights(device_draw ? 0 : count, 1.0), latest;
     std::vector<double> pick(static_cast<std::size_t>(d));
     // The sequential evaluation over the rank-ordered rows: sum = ((0 + w_0) + w_1) + ..., then the cumulative probabilities up to
     // the drawn one, the ranks taking turns.
@@ -175,9 +179,6 @@ void kpp_sharded(const Shard& sh, ConstMatrixRef data, std::default_random_engin
             broadcast_from(ctx, r, sh.rank, carry, 2);
         }
     };
-    // Large samples: the draws on the devices (mlhip_kpp_draw: certified index, see the single-rank route below); the ranks'
-    // weights stay on their devices unless a draw has to be settled by the sequential evaluation.
-    const bool device_draw = sh.n_global >= 32768;
     for (unsigned int chosen = 0; chosen < K; ++chosen) {
         if (device_draw) {
             std::fill(pick.begin(), pick.end(), 0.0);
@@ -195,11 +196,16 @@ void kpp_sharded(const Shard& sh, ConstMatrixRef data, std::default_random_engin
             } else {
                 uint64_t index = 0;
                 int certain = 0;
-                weights.resize(count);
                 device::check(mlhip_kpp_draw(ctx, device_data, centroids.col(chosen - 1), chosen == 1 ? 1 : 0, p,
-                                             static_cast<uint64_t>(sh.lo), &index, &certain, weights.data()));
-                if (certain) global = static_cast<Index>(index);
-                else { sequential_pick(p); settled = false; }          // (every rank got the same verdict)
+                                             static_cast<uint64_t>(sh.lo), &index, &certain, nullptr));
+                if (certain) {
+                    global = static_cast<Index>(index);
+                } else {                                                // (every rank got the same verdict)
+                    weights.resize(count);
+                    device::check(mlhip_kpp_weights(ctx, device_data, weights.data()));
+                    sequential_pick(p);
+                    settled = false;
+                }
             }
             if (settled && global >= sh.lo && global < sh.hi) std::copy_n(data.col(global - sh.lo), d, pick.data());
             device::check(mlhip_ctx_allreduce(ctx, pick.data(), pick.size()));   // only the owner's copy is non-zero
@@ -297,12 +303,13 @@ void init_centroids(const CentroidsInitialiser& initialiser, ConstMatrixRef data
             } else {
                 uint64_t index = 0;
                 int certain = 0;
-                weights.resize(count);
                 device::check(mlhip_kpp_draw(ctx, device_data, centroids.col(chosen - 1), chosen == 1 ? 1 : 0, p, 0, &index, &certain,
-                                             weights.data()));
+                                             nullptr));
                 if (certain) {
                     pick = static_cast<std::size_t>(index);
                 } else {
+                    weights.resize(count);                             // (only now: the weights stay on the device otherwise)
+                    device::check(mlhip_kpp_weights(ctx, device_data, weights.data()));
                     double sum = 0.0;
                     for (std::size_t i = 0; i < count; ++i) sum += weights[i];
                     double cumulative = 0.0;

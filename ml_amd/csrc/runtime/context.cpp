@@ -279,26 +279,39 @@ int mlhip_ctx_init_rccl_file(mlhip_ctx* ctx, const char* path, int world_size, i
         require(ctx && path && *path, "null argument");
         refuse_group(ctx);
         require(world_size >= 1 && rank >= 0 && rank < world_size, "bad world_size / rank");
+        // The file carries [job nonce | unique id]. The nonce is a hash of what tells this job's launch from another's
+        // (MLHIP_RCCL_NONCE, else the launcher's TORCHELASTIC_RUN_ID / MASTER_ADDR / MASTER_PORT): a waiting rank rejects the
+        // left-over file of a job that died before its rank 0 removed it, even inside the staleness window.
+        uint64_t nonce = 1469598103934665603ull;
+        for (const char* name : {"MLHIP_RCCL_NONCE", "TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT"}) {
+            const char* v = std::getenv(name);
+            for (const char* c = v ? v : ""; *c; ++c) { nonce ^= (unsigned char)*c; nonce *= 1099511628211ull; }
+            nonce ^= 0xff; nonce *= 1099511628211ull;
+        }
+        struct Record { uint64_t nonce; ncclUniqueId id; } rec;
         ncclUniqueId id;
         if (rank == 0) {
             const Rccl& r = Rccl::get();
             r.check(r.GetUniqueId(&id), "ncclGetUniqueId");
+            rec.nonce = nonce;
+            rec.id = id;
+            std::remove(path);                                      // (an earlier job's left-over)
             const std::string tmp = std::string(path) + ".tmp";     // written whole, then renamed: readers never see a part
             FILE* f = std::fopen(tmp.c_str(), "wb");
-            if (!f || std::fwrite(&id, 1, sizeof id, f) != sizeof id || std::fclose(f) != 0 || std::rename(tmp.c_str(), path) != 0)
+            if (!f || std::fwrite(&rec, 1, sizeof rec, f) != sizeof rec || std::fclose(f) != 0 || std::rename(tmp.c_str(), path) != 0)
                 throw std::runtime_error(std::string("cannot write the RCCL rendezvous file ") + path);
         } else {
             const int limit_s = std::max(1, env_int("MLHIP_RCCL_TIMEOUT_S", 120));
             const int stale_s = std::max(1, env_int("MLHIP_RCCL_STALE_S", 600));
             const auto t0 = std::chrono::steady_clock::now();
             for (;;) {
-                // the left-over file of an earlier job (one that died before rank 0 removed it) must not be taken for this job's
+                // neither the left-over of an old job (age) nor the file of another launch (nonce) is taken for this job's
                 struct stat st;
                 const bool fresh = ::stat(path, &st) == 0 && std::time(nullptr) - st.st_mtime <= stale_s;
                 if (FILE* f = fresh ? std::fopen(path, "rb") : nullptr) {
-                    const size_t got = std::fread(&id, 1, sizeof id, f);
+                    const size_t got = std::fread(&rec, 1, sizeof rec, f);
                     std::fclose(f);
-                    if (got == sizeof id) break;
+                    if (got == sizeof rec && rec.nonce == nonce) { id = rec.id; break; }
                 }
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(limit_s))
                     throw std::runtime_error(std::string("timed out waiting for the RCCL rendezvous file ") + path);

@@ -725,6 +725,15 @@ void kpp_draw(mlhip_ctx* ctx, mlhip_data* data, const double* centroid, int firs
     *certain = sure[0];
 }
 
+void kpp_weights(mlhip_ctx* ctx, mlhip_data* data, double* weights_out)
+{
+    check_group_data(ctx, data);
+    require(weights_out || data->n_global == 0, "null argument");
+    each_shard(ctx, [&](int s, mlhip_ctx* c) {
+        check_status(mlhip_kpp_weights(c, data->parts[(size_t)s], weights_out ? weights_out + data->first_row[(size_t)s] : nullptr));
+    });
+}
+
 void min_squared_distances(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* centroids, double* dist2)
 {
     check_group_data(ctx, data);

@@ -530,6 +530,7 @@ void kmeans_labels(mlhip_ctx* ctx, mlhip_data* data, uint32_t* labels);
 void kmeans_distances(mlhip_ctx* ctx, mlhip_data* data, double* dist2);
 void kpp_draw(mlhip_ctx* ctx, mlhip_data* data, const double* centroid, int first, double u, uint64_t first_row, uint64_t* index,
               int* certain, double* weights_out);
+void kpp_weights(mlhip_ctx* ctx, mlhip_data* data, double* weights_out);
 void min_squared_distances(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* centroids, double* dist2);
 void timing_enable(mlhip_ctx* ctx, int on);
 void timing_reset(mlhip_ctx* ctx);

@@ -377,6 +377,18 @@ int mlhip_kpp_draw(mlhip_ctx* ctx, mlhip_data* data, const double* centroid, int
     });
 }
 
+int mlhip_kpp_weights(mlhip_ctx* ctx, mlhip_data* data, double* weights_out)
+{
+    return guarded([&] {
+        if (ctx && ctx->group) { grp::kpp_weights(ctx, data, weights_out); return; }
+        check_em_args(ctx, data, 1);
+        require(weights_out || data->n == 0, "null argument");
+        require(data->kpp_w.p != nullptr, "no K-means++ draw on the device yet");
+        ctx->sync();
+        download_columns(ctx, reinterpret_cast<char*>(weights_out), 0, data->kpp_w.as<char>(), 0, sizeof(double) * data->n, 1);
+    });
+}
+
 int mlhip_min_squared_distances(mlhip_ctx* ctx, mlhip_data* data, uint32_t K, const double* centroids, double* dist2)
 {
     return guarded([&] {

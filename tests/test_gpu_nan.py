@@ -60,3 +60,37 @@ def test_nan_parameters_poison_the_log_likelihood(ctx, oracle, d, K, n, diagonal
     steps, conv, ll_it, *_ = dt.em_iterate(pi0, mu0, S0, 4, 1e-6, 1e-6, diagonal)
     assert not conv and steps == 4 and np.isnan(ll_it)
     dt.close()
+
+
+@pytest.mark.parametrize("d,K,n", [
+    (16, 40, 6000),      # matrix-core E-step with its own log-sum-exp
+    (32, 64, 6000),      # ... without (the statistics kernel normalises)
+    (8, 5, 5000),        # scalar-fed E-step
+    (4, 3, 5000),        # fused small-shape kernel
+    (150, 3, 1500),      # plain tier (d > 128)
+])
+@pytest.mark.parametrize("zeros", [(0,), (0, 1), (2,)])
+def test_zero_mixing_weight_stays_finite_like_the_reference(ctx, oracle, d, K, n, zeros):
+    """pi_k = 0 multiplies column k by 0 in the reference (ML/EM.cpp:209): the log-likelihood and the other components'
+    responsibilities stay finite. In the log domain that component is lw = -inf, which must not turn the online log-sum-exp into
+    -inf - -inf = NaN when it comes FIRST."""
+    from ml_amd import _lib
+    X, mu0 = _problem(d, K, n, 3 * d + K)
+    dt = _lib.Data(ctx, X)
+    S0 = np.stack([np.diag(np.var(X, axis=0))] * K)
+    pi0 = np.full(K, 1.0)
+    pi0[list(zeros)] = 0.0
+    pi0 /= pi0.sum()
+    ll = dt.em_expectation(pi0, mu0, S0)
+    em = oracle.EM(K)
+    em.set_parameters(mu0, S0, pi0)
+    em.expectation_step(X)
+    assert np.isfinite(ll) and abs(ll - em.log_likelihood) <= 1e-12 * abs(em.log_likelihood)
+    R = dt.em_responsibilities(K)
+    assert np.all(R[:, list(zeros)] == 0.0)
+    assert np.max(np.abs(R - em.responsibilities)) < 1e-12
+    em.calculate_labels()
+    assert np.array_equal(dt.em_labels(K), em.labels)
+    ll_step = dt.em_step(pi0, mu0, S0)[0]                     # the route mlhip_em_iterate takes (fused / self-normalising kernels)
+    assert abs(ll_step - em.log_likelihood) <= 1e-12 * abs(em.log_likelihood)
+    dt.close()
