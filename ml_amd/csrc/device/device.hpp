@@ -113,6 +113,9 @@ struct DiagArgs {
     double* lse;                                             // out: per-sample log-sum-exp
     double* partials; size_t partials_capacity;              // scratch: [grid][KP][FP]
     double* ll_partials; int n_ll_partials;                  // out: per-workgroup log-likelihood sums
+    int two_op;                                              // the records' (a, b) operands were built for THIS shift (the data's): the
+                                                             // mixed-feed kernel may take its two-operation density form; 0 for a
+                                                             // refinement pass about another shift (exact form)
 };
 namespace mstats {
 bool em_diag_supported(int d, int K);                        // d <= 32, K <= 64

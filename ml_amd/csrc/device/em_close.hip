@@ -199,7 +199,7 @@ __global__ __launch_bounds__(NT) void em_close_kernel(const double* __restrict__
 
 /// Diagonal covariances: elementwise (host/em_math.cpp finalize_mstep_diag + build_diag_params). One workgroup per
 /// component (d <= 32 threads busy); records of the padding rows k >= K are written once by the host and left alone.
-__global__ __launch_bounds__(64) void em_close_diag_kernel(const double* __restrict__ stats, int K, int d, int D,
+__global__ __launch_bounds__(64) void em_close_diag_kernel(const double* __restrict__ stats, int K, int KP, int d, int D,
                                                             const double* __restrict__ shift, double n_global, double refine_limit,
                                                             double* __restrict__ mixing, double* __restrict__ means,
                                                             double* __restrict__ vars, double* __restrict__ records,
@@ -208,11 +208,13 @@ __global__ __launch_bounds__(64) void em_close_diag_kernel(const double* __restr
     __shared__ double logs[64];
     __shared__ int codes[64];
     const int k = blockIdx.x, tid = threadIdx.x;
-    const int F = 2 * d + 1, PS = 2 * D + 2;
+    const int F = 2 * d + 1, PS = diag_param_stride_c(D);
     const double* s = stats + (size_t)k * F;
     const double s0 = s[2 * d];
     const double mix = s0 / n_global;
     double* rec = records + (size_t)k * PS;
+    double* aT = records + (size_t)KP * PS;                   // the trailer behind the KP records (layout.hpp)
+    double* bT = aT + (size_t)D * KP;
     if (tid < d) {
         const double mm = s[tid] / s0;
         const double mean = shift[tid] + mm;
@@ -225,6 +227,12 @@ __global__ __launch_bounds__(64) void em_close_diag_kernel(const double* __restr
         rec[tid] = mean;
         rec[D + tid] = (1.0 / l) / l;
         logs[tid] = log(l);
+        // operands of the two-operation density form (layout.hpp diag_param_stride; host: build_diag_params)
+        const double a = 1.0 / l;
+        const double b = -(off * a);
+        aT[(size_t)tid * KP + k] = a;
+        bT[(size_t)tid * KP + k] = b;
+        logs[32 + tid] = isfinite(a) ? b : __builtin_inf();
     }
     __syncthreads();
     if (tid == 0) {
@@ -232,6 +240,9 @@ __global__ __launch_bounds__(64) void em_close_diag_kernel(const double* __restr
         double ldh = 0.0;
         for (int j = 0; j < d; ++j) ldh += logs[j];
         rec[2 * D] = log(mix) - ldh;
+        double b2 = 0.0;                                       // B2 = sum_j b_j^2 (layout.hpp), ascending j like the host
+        for (int a = 0; a < d; ++a) b2 = __builtin_fma(logs[32 + a], logs[32 + a], b2);
+        rec[2 * D + 1] = b2;
         int flag = 0;
         if (mix > 0 && isfinite(mix))
             for (int a = 0; a < d; ++a) {
@@ -284,7 +295,7 @@ void launch_em_close(const CloseArgs& a, hipStream_t stream)
 
 void launch_em_close_diag(const CloseArgs& a, hipStream_t stream)
 {
-    hipLaunchKernelGGL(em_close_diag_kernel, dim3(a.K), dim3(64), 0, stream, a.stats, a.K, a.d, a.D, a.shift, a.n_global,
+    hipLaunchKernelGGL(em_close_diag_kernel, dim3(a.K), dim3(64), 0, stream, a.stats, a.K, mstats::em_diag_partial_rows(a.K), a.d, a.D, a.shift, a.n_global,
                        a.refine_limit, a.mixing, a.means, a.covs, a.records, a.info);
 }
 

@@ -312,6 +312,41 @@ __global__ __launch_bounds__(256, (D <= 16 && RBT <= 2) ? 2 : 1) void em_diag_ke
     }
 }
 
+/// Lanes l, l ^ 16, l ^ 32, l ^ 48 (the four lanes that hold one sample's components in the matrix cores' output layout) combine
+/// their values without the LDS pipe: v_permlane16_swap / v_permlane32_swap hand every lane its partner's value.
+template <bool BIT5> __device__ __forceinline__ void lane_partners(double v, double& a, double& b)
+{
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    if constexpr (BIT5) {
+        const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        a = __hiloint2double((int)h[0], (int)l[0]);
+        b = __hiloint2double((int)h[1], (int)l[1]);
+    } else {
+        const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        a = __hiloint2double((int)h[0], (int)l[0]);
+        b = __hiloint2double((int)h[1], (int)l[1]);
+    }
+}
+__device__ __forceinline__ double quad_max(double v)
+{
+    double a, b;
+    lane_partners<false>(v, a, b);
+    asm("v_max_f64 %0, %1, %2" : "=v"(v) : "v"(a), "v"(b));   // (a NaN operand is dropped, as in the scalar-fed loop)
+    lane_partners<true>(v, a, b);
+    asm("v_max_f64 %0, %1, %2" : "=v"(v) : "v"(a), "v"(b));
+    return v;
+}
+__device__ __forceinline__ double quad_sum(double v)
+{
+    double a, b;
+    lane_partners<false>(v, a, b);
+    v = a + b;
+    lane_partners<true>(v, a, b);
+    return a + b;
+}
+
 /// The same iteration for K <= 16 with the component records fed from SCALAR registers instead of LDS: the
 /// records are wave-uniform, so the compiler fetches them with s_load and every v_add / v_mul / v_fma of the density loop
 /// takes its record operand from an SGPR pair -- one scalar source per instruction, which is what the constant bus of gfx950
@@ -319,11 +354,25 @@ __global__ __launch_bounds__(256, (D <= 16 && RBT <= 2) ? 2 : 1) void em_diag_ke
 /// fma(a, x~, b)^2 would need two). No operand goes through the LDS pipe, so ONE sample per lane costs nothing extra: half
 /// the registers, FOUR waves per SIMD instead of two (the kernel is latency-bound: 3.8 tiles per wave, each starting with
 /// an HBM round trip), and the statistics tiles pass through LDS in two 32-sample halves (9.2 KB per wave: 16 waves per CU).
-template <int D, int CB>
+///
+/// GEMM = the log-densities on the MATRIX CORES (round 4): with a = 1 / sigma, b = -(mu - shift) / sigma the log-density is linear in
+/// the features the statistics GEMM already uses, Phi = [x~^2 ; x~]:
+///     lw_k = (coef_k - B2_k / 2) + sum_j (-a_kj^2 / 2) x~_j^2 + (-a_kj b_kj) x~_j  ,
+/// one 16 x 2D by 2D x 16 product per 16 samples on v_mfma_f64_16x16x4 with the parameter matrix as the A operand -- (2D + 3) / 4
+/// doubles per lane, loaded ONCE per kernel -- the constant as the accumulator initialiser, and the B operand read (and squared)
+/// from the very sample tile the statistics phase stages in LDS. The 3 d (or 2 d) vector instructions per (sample, component) of
+/// the vector forms, and with them every per-component operand feed (scalar loads, LDS broadcasts), are gone; what the vector unit
+/// still does per (sample, component) is the one exponential. The output sits in the matrix cores' layout -- lane (g, c) holds
+/// components g, g + 4, g + 8, g + 12 of sample c -- so maximum and sum over the components are three in-lane operations and two
+/// lane exchanges (v_permlane16/32_swap), and the responsibilities go to the statistics tile from there. No coordinates stay in
+/// registers across the component loop. The price is the expanded form's cancellation, ~eps 4 B2 in a log-responsibility:
+/// taken only while every B2_k <= kDiagExpandLimit (layout.hpp; 4.5e-13) and the shift is the data's; the exact scalar-fed form
+/// otherwise (same kernel, decided from the records, the same on every workgroup and rank).
+template <int D, int CB, bool GEMM>
 __global__ __launch_bounds__(256, D <= 8 ? 4 : 3) void em_diag_sgpr_kernel(
     const double* __restrict__ xt, size_t ldx, uint32_t n, int d, const double* __restrict__ shift,
     const double* __restrict__ params, int K, double* __restrict__ lse_out, double* __restrict__ partials, int KP, int FP,
-    double* __restrict__ ll_partials)
+    double* __restrict__ ll_partials, double expand_limit)
 {
     constexpr int PS = 2 * D + 2;                             // diag_param_stride(D)
     constexpr int KMAX = 16;
@@ -364,6 +413,107 @@ __global__ __launch_bounds__(256, D <= 8 ? 4 : 3) void em_diag_sgpr_kernel(
     lds_cdouble* rbase = (lds_cdouble*)(Rw + 8 * (lane >> 4) * RSS + (lane & 15));
     double ll_acc = 0.0;
 
+    bool expanded = false;
+    if constexpr (GEMM) {
+        expanded = true;                                      // every record must allow the form (wave-uniform: scalar loads; a NaN fails)
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) expanded = expanded && params[(size_t)k * PS + 2 * D + 1] <= expand_limit;
+    }
+    if (GEMM && expanded) {
+        constexpr int NQ = (2 * D + 3) / 4;                   // feature quads of Phi = [x~^2 (D) ; x~ (D)]
+        const int g = lane >> 4, c = lane & 15;
+        double* MS = smem + 4 * (HT * XSS + HT * RSS) + (size_t)wave * 2 * TS;     // per sample: max and exp-sum, for the tile's lse
+        // A operand, lane (g, c): Theta[component c][feature 4 q + g]; accumulator initialiser, element e: component g + 4 e
+        const double* __restrict__ aT = params + (size_t)KMAX * PS;
+        const double* __restrict__ bT = aT + (size_t)D * KMAX;
+        double th[NQ];
+        int col[NQ];                                          // LDS column of the lane's feature; squared for f < D
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int f = 4 * q + g;
+            const int j = f < D ? f : f - D;
+            const double a = f < 2 * D ? aT[(size_t)j * KMAX + c] : 0.0, b = f < 2 * D ? bT[(size_t)j * KMAX + c] : 0.0;
+            th[q] = f < D ? -0.5 * (a * a) : -(a * b);
+            col[q] = f < 2 * D ? j : ZERO;
+        }
+        d4 cst;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const double* __restrict__ p = params + (size_t)(g + 4 * e) * PS;
+            cst[e] = p[2 * D] - 0.5 * p[2 * D + 1];
+        }
+        lds_cdouble* xrow = (lds_cdouble*)(Xw + c * XSS);     // the lane's sample row in 16-sample group 0 of the half tile
+        for (uint32_t tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += stride) {
+            const uint32_t i = tile * TS + lane;              // < n_pad (a multiple of 256)
+            double x[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) x[j] = xt[(size_t)j * ldx + i];
+#pragma unroll
+            for (int j = 0; j < D; ++j) x[j] -= shift[j];     // shift is zero-padded to D entries
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                __builtin_amdgcn_wave_barrier();
+                if ((lane >> 5) == h) {
+                    double* xw = Xw + (lane & 31) * XSS;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) xw[j] = x[j];
+                    xw[ONE] = 1.0;
+                    xw[ZERO] = 0.0;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // ---- log-densities of the half's two 16-sample groups on the matrix cores, normalised in the output layout
+#pragma unroll
+                for (int gh = 0; gh < 2; ++gh) {
+                    d4 lw = cst;
+                    __builtin_amdgcn_s_setprio(kMatrixPhasePriority);
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        double v = xrow[gh * 16 * XSS + col[q]];
+                        if constexpr (D % 4 == 0) { if (4 * q < D) v *= v; }
+                        else v = (4 * q + g < D) ? v * v : v;
+                        lw = __builtin_amdgcn_mfma_f64_16x16x4f64(th[q], v, lw, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_s_setprio(0);
+                    double m = lw[0];
+                    asm("v_max_f64 %0, %0, %1" : "+v"(m) : "v"(lw[1]));
+                    asm("v_max_f64 %0, %0, %1" : "+v"(m) : "v"(lw[2]));
+                    asm("v_max_f64 %0, %0, %1" : "+v"(m) : "v"(lw[3]));
+                    m = quad_max(m);
+                    double e[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) e[u] = lw[u] - m;
+                    exp_nonpos_n<4>(e);                       // exp(-inf) = 0 for the neutral components
+                    const double sum = quad_sum(((e[0] + e[1]) + e[2]) + e[3]);
+                    const uint32_t sample = tile * TS + h * HT + gh * 16 + c;
+                    const double inv = sample < n ? 1.0 / sum : 0.0;               // padding samples contribute nothing
+                    if (g == 0) { MS[h * HT + gh * 16 + c] = m; MS[TS + h * HT + gh * 16 + c] = sum; }
+                    double* rw = Rw + (gh * 16 + c) * RSS + g;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) rw[4 * u] = e[u] * inv;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // ---- statistics of the half on the matrix cores (as below)
+                __builtin_amdgcn_s_setprio(kMatrixPhasePriority);
+#pragma unroll
+                for (int sg = 0; sg < HT / 4; ++sg) {
+                    const double av = rbase[sg * RSS];
+                    s0 += av;
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) {
+                        const double bv = pa[cb][sg * XSS] * pb[cb][sg * XSS];
+                        acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[cb], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+            }
+            // the tile's log-sum-exp, one sample per lane (the maxima / sums were left in LDS by the lanes g == 0)
+            const double lse = MS[lane] + log(MS[TS + lane]);
+            lse_out[i] = lse;
+            if (i < n) ll_acc += lse;
+        }
+    } else
     for (uint32_t tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += stride) {
         const uint32_t i = tile * TS + lane;                  // < n_pad (a multiple of 256)
         double x[D];
@@ -485,6 +635,265 @@ __global__ __launch_bounds__(256, D <= 8 ? 4 : 3) void em_diag_sgpr_kernel(
     if (tid == 0) ll_partials[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
+/// K <= 16, d <= 16 (BASELINE.json configs[1]): the two-operation density form
+///     t = fma(a, x~, b) ;  q = fma(t, t, q)        a = 1 / sigma, b = -(mu - shift) / sigma
+/// -- 2 vector instructions per (sample, component, dimension) instead of the 3 of the exact form -- run DIMENSION-outer: for one j the
+/// operand pairs of all 16 components are contiguous (the records' trailer, layout.hpp: aT / bT, interleaved in LDS) and feed 16
+/// INDEPENDENT accumulation chains per sample (q_k, which then become lw_k, e_k, r_k in place); S = 2 samples per lane share every
+/// operand read. Both operands come from LDS: feeding `a` from scalar registers (one scalar source per instruction is what the
+/// constant bus allows) was built in three forms and measured SLOWER than the exact kernel in spite of 20 - 24 % fewer
+/// vector instructions -- scalar loads and LDS reads share one counter, so every wait in the loop becomes a wait for everything
+/// (profiles/r04_diag_feed.txt). Taken while every record's flag allows it (every |b| <= kDiagAbLimit:
+/// decided where the records are built, host/em_math.cpp build_diag_params and em_close_diag_kernel) and the shift is the data's;
+/// otherwise the exact three-operation form runs from scalar registers. Statistics phase: that of em_diag_kernel, one row block.
+template <int D, int CB, int S>
+__global__ __launch_bounds__(256, 2) void em_diag_mixed_kernel(
+    const double* __restrict__ xt, size_t ldx, uint32_t n, int d, const double* __restrict__ shift,
+    const double* __restrict__ params, int K, double* __restrict__ lse_out, double* __restrict__ partials, int KP, int FP,
+    double* __restrict__ ll_partials, int allow_two_op)
+{
+    constexpr int PS = diag_param_stride_c(D);
+    constexpr int KMAX = 16;
+    constexpr int XSS = xsd<D>();
+    constexpr int TW = TS * S;                                // samples per wave tile
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double red[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double* Xw = smem + (size_t)wave * (TS * XSS + TS * RSS);
+    double* Rw = Xw + TS * XSS;
+    double* bl = smem + 4 * (TS * XSS + TS * RSS);            // [D][KMAX] pairs (a, b): the records' trailer, interleaved
+    constexpr int ONE = D, ZERO = D + 1;                      // LDS row: [x~_0 .. x~_(D-1) | 1 | 0]
+    const double* __restrict__ aT = params + (size_t)KMAX * PS;
+    for (int e = tid; e < KMAX * D; e += 256) { bl[2 * e] = aT[e]; bl[2 * e + 1] = aT[KMAX * D + e]; }
+    // every record must allow the two-operation form (wave-uniform: scalar loads and compares)
+    bool ab = allow_two_op != 0;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) ab = ab && params[(size_t)k * PS + 2 * D + 1] <= kDiagAbLimit * kDiagAbLimit;   // (B2: layout.hpp; a NaN fails)
+    __syncthreads();
+
+    int offa[CB], offb[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+        const int f = c * 16 + (lane & 15);
+        offa[c] = f < d ? f : (f < 2 * d ? f - d : ZERO);
+        offb[c] = f < d ? ONE : (f < 2 * d ? f - d : ZERO);
+    }
+    d4 acc[CB];
+    double s0 = 0.0;                                          // lane (g, c): partial S0 of component c
+#pragma unroll
+    for (int c = 0; c < CB; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
+
+    const uint32_t n_tiles = (n + TW - 1) / TW;
+    const uint32_t stride = gridDim.x * 4;
+    const double* xbase = Xw + 16 * (lane >> 4) * XSS;
+    lds_cdouble* pa[CB];
+    lds_cdouble* pb[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+        pa[c] = (lds_cdouble*)(xbase + offa[c]);
+        pb[c] = (lds_cdouble*)(xbase + offb[c]);
+    }
+    lds_cdouble* rbase = (lds_cdouble*)(Rw + 16 * (lane >> 4) * RSS + (lane & 15));
+    double ll_acc = 0.0;
+
+    for (uint32_t tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += stride) {
+        asm volatile("" ::: "memory");
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(3))) const d2 lds_cd2;
+        lds_cd2* blv = (lds_cd2*)bl;                          // ONE base register: every b read is `ds_read_b128 base offset:imm`
+        asm volatile("" : "+v"(blv));
+        const uint32_t i0 = tile * TW + lane;                 // sample of slot s: i0 + 64 s (< n_pad: a multiple of 256)
+        double x[S][D];
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int j = 0; j < D; ++j) x[s][j] = xt[(size_t)j * ldx + i0 + TS * s];
+
+        // ---- 1. log-densities of all 16 component slots (records k >= K are neutral: a = b = 0, coef = -inf)
+        double lwv[S][KMAX];
+        double m[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) m[s] = -__builtin_inf();
+        if (ab) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) {                     // the two-operation form works on x~ = x - shift throughout
+                const double sh = shift[j];
+#pragma unroll
+                for (int s = 0; s < S; ++s) x[s][j] -= sh;
+            }
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) lwv[s][k] = 0.0;
+            // Software pipeline over the dimensions, in HALVES of 8 components: the operand pairs (a, b) of a half -- eight 16-byte LDS
+            // broadcast reads -- are re-loaded for dimension j + 1 as soon as dimension j's arithmetic on that half has been ISSUED,
+            // and land while the other half's 16 S instructions run (no second operand buffer; the waits are the compiler's own
+            // counted lgkmcnt). Within a half the first operation of four components is issued before their second: a dependent
+            // v_fma_f64 right behind its producer stalls.
+            constexpr int KH = KMAX / 2;
+                d2 pv[2][KH];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int c = 0; c < KH; ++c) pv[h][c] = blv[h * KH + c];
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                        for (int g = 0; g < KH; g += 4) {
+                            double t[4][S];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                                for (int s = 0; s < S; ++s) t[u][s] = __builtin_fma(pv[h][g + u][0], x[s][j], pv[h][g + u][1]);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                                for (int s = 0; s < S; ++s) lwv[s][h * KH + g + u] = __builtin_fma(t[u][s], t[u][s], lwv[s][h * KH + g + u]);
+                        }
+                        if (j + 1 < D) {
+#pragma unroll
+                            for (int c = 0; c < KH; ++c) pv[h][c] = blv[(j + 1) * KMAX + h * KH + c];
+                        }
+                    }
+                }
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const double coef = params[(size_t)k * PS + 2 * D];
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const double lw = __builtin_fma(-0.5, lwv[s][k], coef);
+                    lwv[s][k] = lw;
+                    asm("v_max_f64 %0, %0, %1" : "+v"(m[s]) : "v"(lw));             // (a NaN lw leaves m, as `lw > m ? lw : m` does)
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                if (k < K) {
+                    const double* __restrict__ p = params + (size_t)k * PS;
+                    double q[S];
+#pragma unroll
+                    for (int s = 0; s < S; ++s) q[s] = 0.0;
+#pragma unroll
+                    for (int j = 0; j < D; ++j)
+#pragma unroll
+                        for (int s = 0; s < S; ++s) {
+                            const double z = x[s][j] - p[j];
+                            q[s] = __builtin_fma(z * p[D + j], z, q[s]);
+                        }
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const double lw = __builtin_fma(-0.5, q[s], p[2 * D]);
+                        lwv[s][k] = lw;
+                        asm("v_max_f64 %0, %0, %1" : "+v"(m[s]) : "v"(lw));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);        // one record in scalar registers at a time
+                } else {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) lwv[s][k] = -__builtin_inf();
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double sh = shift[j];                   // shift is zero-padded to D entries
+#pragma unroll
+                for (int s = 0; s < S; ++s) x[s][j] -= sh;
+            }
+        }
+        // ---- 2. normalisation: one exp per (sample, component)
+        double inv[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            double sum = 0.0;
+#pragma unroll
+            for (int k8 = 0; k8 < KMAX; k8 += 8) {                                // eight chains side by side (exp_nonpos.hpp)
+                double e[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) e[u] = lwv[s][k8 + u] - m[s];
+                exp_nonpos_n<8>(e);                                              // exp(-inf) = 0 for the neutral tail
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    lwv[s][k8 + u] = e[u];
+                    sum += e[u];
+                }
+            }
+            const double lse = m[s] + log(sum);
+            const bool live = i0 + TS * s < n;
+            lse_out[i0 + TS * s] = lse;
+            if (live) ll_acc += lse;
+            inv[s] = live ? 1.0 / sum : 0.0;                     // padding samples contribute nothing
+        }
+
+        // ---- 3. per 64-sample slot: tiles -> LDS, statistics on the matrix cores
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < D; ++j) Xw[lane * XSS + j] = x[s][j];
+            Xw[lane * XSS + ONE] = 1.0;
+            Xw[lane * XSS + ZERO] = 0.0;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) Rw[lane * RSS + it] = lwv[s][it] * inv[s];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_setprio(kMatrixPhasePriority);
+#pragma unroll 4
+            for (int sg = 0; sg < TS / 4; ++sg) {
+                const double av = rbase[sg * RSS];               // r of (sample 16 g + sg, component lane & 15)
+                s0 += av;
+#pragma unroll
+                for (int c = 0; c < CB; ++c) {
+                    const double bv = pa[c][sg * XSS] * pb[c][sg * XSS];
+                    acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[c], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+
+    // ---- epilogue: fold the 4 waves' accumulators, S0 sums and log-likelihood sums in fixed order
+    s0 += __shfl_xor(s0, 16, 64);
+    s0 += __shfl_xor(s0, 32, 64);
+    double* out = partials + (size_t)blockIdx.x * KP * FP;
+    for (int w = 0; w < 4; ++w) {
+        if (w == wave) {
+#pragma unroll
+            for (int c = 0; c < CB; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int k = (lane >> 4) + 4 * g;
+                    const int f = c * 16 + (lane & 15);
+                    if (f < 2 * d) {
+                        double* p = out + (size_t)k * FP + f;
+                        *p = (w == 0 ? 0.0 : *p) + acc[c][g];
+                    }
+                }
+            if (lane < 16) {
+                double* p = out + (size_t)lane * FP + 2 * d;
+                *p = (w == 0 ? 0.0 : *p) + s0;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ll_acc += __shfl_down(ll_acc, off, 64);
+    if (lane == 0) red[wave] = ll_acc;
+    __syncthreads();
+    if (tid == 0) ll_partials[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+/// MLHIP_DIAG_MIXED=0: em_diag_sgpr_kernel (the exact scalar-fed form; with MLHIP_DIAG_GEMM=1 its matrix-core density path) instead of
+/// this kernel (A/B runs).
+inline bool diag_mixed_applies(int d, int K)
+{
+    const char* e = std::getenv("MLHIP_DIAG_MIXED");
+    const char* g = std::getenv("MLHIP_DIAG_GEMM");
+    return !(e && e[0] == '0') && !(g && g[0] == '1') && K <= 16 && padded_dim(d) <= 16;
+}
+
 /// Shapes the scalar-fed kernel serves: one row block of components, coordinates + densities within 128 registers.
 /// MLHIP_DIAG_SGPR=0: off (A/B runs).
 inline bool diag_sgpr_applies(int d, int K)
@@ -502,6 +911,14 @@ inline double diag_ab_limit()
     return e && e[0] == '0' ? -1.0 : kDiagAbLimit;
 }
 
+/// Largest B2 = sum_j ((mu_j - shift_j) / sigma_j)^2 of a component for which the expanded form runs on the matrix cores
+/// (layout.hpp kDiagExpandLimit; MLHIP_DIAG_EXPAND_LIMIT overrides it -- tests, error measurements).
+inline double diag_expand_limit()
+{
+    const char* e = std::getenv("MLHIP_DIAG_EXPAND_LIMIT");   // (read per launch: tests switch it inside one process)
+    return e && *e ? std::atof(e) : kDiagExpandLimit;
+}
+
 /// Samples per lane: 2 while coordinates + densities of both fit the registers of 2 waves per SIMD, else 1.
 constexpr int samples_per_lane(int D, int RBT) { return (D <= 16 && RBT == 1) || (D <= 8 && RBT == 2) ? 2 : 1; }
 
@@ -510,10 +927,24 @@ int launch_t(const DiagArgs& a, int grid, hipStream_t stream)
 {
     constexpr int CB = (2 * D + 15) / 16, RBW = rbw_of(RBT), PS = 2 * D + 2, XSS = xsd<D>(), S = samples_per_lane(D, RBT);
     if constexpr (RBT == 1 && D <= 16) {
+        if (diag_sgpr_applies(a.d, a.K) && diag_mixed_applies(a.d, a.K)) {
+            const size_t smem = sizeof(double) * (4 * ((size_t)TS * XSS + (size_t)TS * RSS) + (size_t)32 * D);
+            hipLaunchKernelGGL((em_diag_mixed_kernel<D, CB, 2>), dim3(grid), dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d, a.shift,
+                               a.params, a.K, a.lse, a.partials, em_diag_partial_rows(a.K), em_diag_partial_cols(a.d), a.ll_partials,
+                               (a.two_op && diag_ab_limit() > 0) ? 1 : 0);
+            return grid;
+        }
         if (diag_sgpr_applies(a.d, a.K)) {
-            const size_t smem = sizeof(double) * 4 * ((size_t)(TS / 2) * XSS + (size_t)(TS / 2) * RSS);
-            hipLaunchKernelGGL((em_diag_sgpr_kernel<D, CB>), dim3(grid), dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d, a.shift, a.params,
-                               a.K, a.lse, a.partials, em_diag_partial_rows(a.K), em_diag_partial_cols(a.d), a.ll_partials);
+            const char* e = std::getenv("MLHIP_DIAG_GEMM");        // 1: log-densities on the matrix cores while the guard allows (A/B runs)
+            const bool gemm = e && e[0] == '1';
+            const size_t smem = sizeof(double) * (4 * ((size_t)(TS / 2) * XSS + (size_t)(TS / 2) * RSS) + (gemm ? 4 * 2 * (size_t)TS : 0));
+            if (gemm)
+                hipLaunchKernelGGL((em_diag_sgpr_kernel<D, CB, true>), dim3(grid), dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d, a.shift,
+                                   a.params, a.K, a.lse, a.partials, em_diag_partial_rows(a.K), em_diag_partial_cols(a.d), a.ll_partials,
+                                   (a.two_op && diag_ab_limit() > 0) ? diag_expand_limit() : -1.0);
+            else
+                hipLaunchKernelGGL((em_diag_sgpr_kernel<D, CB, false>), dim3(grid), dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d, a.shift,
+                                   a.params, a.K, a.lse, a.partials, em_diag_partial_rows(a.K), em_diag_partial_cols(a.d), a.ll_partials, -1.0);
             return grid;
         }
     }
@@ -545,8 +976,9 @@ int em_diag_grid(int d, int K, uint32_t n, int num_cus)
 {
     const int RB = (K + 15) / 16;
     const int D = padded_dim(d), RBT = RB == 1 ? 1 : (RB == 2 ? 2 : 4);
-    const bool sgpr = diag_sgpr_applies(d, K);
-    const uint32_t tw = (uint32_t)TS * (sgpr ? 1 : samples_per_lane(D, RBT));
+    const bool mixed = diag_sgpr_applies(d, K) && diag_mixed_applies(d, K);
+    const bool sgpr = diag_sgpr_applies(d, K) && !mixed;
+    const uint32_t tw = (uint32_t)TS * (sgpr ? 1 : (mixed ? 2 : samples_per_lane(D, RBT)));
     const uint32_t n_tiles = (n + tw - 1) / tw;
     const int groups = RB >= 4 ? 2 : 1;                          // row-block groups in grid.y
     int per_cu = sgpr ? (D <= 8 ? 4 : 3) : ((D <= 16 && RB <= 2) ? 2 : 1);   // workgroups the registers / LDS admit per CU

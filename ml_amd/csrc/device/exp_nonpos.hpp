@@ -40,4 +40,33 @@ MLHIP_EXP_FN double exp_nonpos(double x)
     return __builtin_ldexp(p, (int)n);
 }
 
+/// N exponentials side by side: the same operations as exp_nonpos on each element (bit-identical results), issued step by step
+/// across the N arguments -- the degree-13 Horner chain of ONE argument is 15 dependent fp64 instructions, each waiting out the
+/// pipeline latency of its predecessor; interleaved, the N chains fill each other's latency slots (em_diag.hip: the compiler
+/// otherwise evaluates the 16 exponentials of a sample one after the other).
+template <int N> MLHIP_EXP_FN void exp_nonpos_n(double (&x)[N])
+{
+    double n[N], r[N], p[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = x[i] < -800.0 ? -800.0 : x[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) n[i] = __builtin_rint(x[i] * 1.4426950408889634074);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = __builtin_fma(n[i], -6.93147180369123816490e-01, x[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = __builtin_fma(n[i], -1.90821492927058770002e-10, r[i]);
+    constexpr double c[13] = {2.0876756987868098979e-09, 2.5052108385441718775e-08, 2.7557319223985890653e-07,
+                              2.7557319223985892511e-06, 2.4801587301587301566e-05, 1.9841269841269841253e-04,
+                              1.3888888888888889419e-03, 8.3333333333333332177e-03, 4.1666666666666664354e-02,
+                              1.6666666666666665741e-01, 0.5, 1.0, 1.0};
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = 1.6059043836821614599e-10;
+#pragma unroll
+    for (int t = 0; t < 13; ++t)
+#pragma unroll
+        for (int i = 0; i < N; ++i) p[i] = __builtin_fma(p[i], r[i], c[t]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = __builtin_ldexp(p[i], (int)n[i]);
+}
+
 }  // namespace mlhip

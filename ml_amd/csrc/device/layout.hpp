@@ -72,9 +72,20 @@ inline int estep_mfma4_param_stride(int D) { return estep_mfma4_block_count(D) *
 ///   S0 = (d,d), S1'_b = (d,b), M2'_ab = (a,b).
 inline int stats_count(int d) { return (d + 1) * (d + 2) / 2; }
 /// Diagonal-covariance extension (device/em_diag.hip). Parameter record of one component, diag_param_stride(D) doubles:
-///   [ mean(D) | iv(D) = 1 / sigma_j^2 | coef = log(pi) - sum_j log sigma_j | pad ]   (even stride: 16-byte aligned LDS reads).
-/// Statistics of one component, diag_stats_count(d) doubles: [ S1'(d) = sum r xt_j | S2'(d) = sum r xt_j^2 | S0 = sum r ].
-inline int diag_param_stride(int D) { return 2 * D + 2; }
+///   [ mean(D) | iv(D) = 1 / sigma_j^2 | coef = log(pi) - sum_j log sigma_j | B2 = sum_j b_j^2 ]       (even stride: 16-byte aligned reads)
+/// -- what the exact density form reads (z = x - mean; q += (z iv) z). Behind the KP records of a parameter set sits a TRAILER with
+/// the operands of the shift-centred forms, a = 1 / sigma, b = -(mean - shift) / sigma, dimension-major so that one dimension's
+/// operands of all components are contiguous:
+///   [ aT: D rows of KP doubles, aT[j KP + k] = a_kj | bT: D rows of KP, bT[j KP + k] = b_kj ]
+/// B2 (NaN / inf when a parameter is not finite) is what the kernels' guards read, the same on every workgroup and rank:
+///   * two-operation form  q += fma(a, x~, b)^2  (error ~ eps |b| per term): while every B2 <= kDiagAbLimit^2;
+///   * expanded form on the matrix cores  lw = coef - B2/2 + sum_j (-a^2/2) x~^2 + (-a b) x~  (error ~ eps 4 B2 in q, i.e. in a
+///     log-responsibility): while every B2 <= kDiagExpandLimit -- 4.5e-13, inside the 1e-12 parity tolerances.
+/// Padding records k >= K: a = b = 0, coef = -inf, B2 = 0.
+constexpr double kDiagExpandLimit = 1024.0;
+constexpr int diag_param_stride_c(int D) { return 2 * D + 2; }
+inline int diag_param_stride(int D) { return diag_param_stride_c(D); }
+inline size_t diag_param_doubles(int D, int KP) { return (size_t)KP * diag_param_stride_c(D) + 2 * (size_t)D * KP; }
 inline int diag_stats_count(int d) { return 2 * d + 1; }
 inline int stats_index(int a, int b) { return a * (a + 1) / 2 + b; }
 

@@ -221,25 +221,38 @@ void finalize_mstep(int d, int K, const double* stats, const double* shift, doub
 }
 
 void build_diag_params(int d, int D, int K, int K_padded, const double* mixing, const double* means, const double* variances,
-                       double* records)
+                       const double* shift, double* records)
 {
-    const int PS = diag_param_stride(D);
+    const int PS = diag_param_stride(D), KP = K_padded;
+    double* aT = records + (size_t)KP * PS;                    // trailer (layout.hpp): operands of the two-operation density form
+    double* bT = aT + (size_t)D * KP;
+    for (size_t i = 0; i < 2 * (size_t)D * KP; ++i) aT[i] = 0.0;
     for (int k = K; k < K_padded; ++k) {
         double* rec = records + (size_t)k * PS;
         for (int i = 0; i < PS; ++i) rec[i] = 0.0;
-        rec[2 * D] = -HUGE_VAL;
+        rec[2 * D] = -HUGE_VAL;                                // (a = b = 0, B2 = 0: every density form gives lw = -inf)
     }
     for (int k = 0; k < K; ++k) {
         double* rec = records + (size_t)k * PS;
         for (int i = 0; i < PS; ++i) rec[i] = 0.0;            // padded coordinates: mean 0, weight 0 -> contribute exactly 0
         double log_det_half = 0.0;
+        double b2 = 0.0;
         for (int j = 0; j < d; ++j) {
             const double l = std::sqrt(variances[(size_t)k * d + j]);
-            rec[j] = means[(size_t)k * d + j];
+            const double mean = means[(size_t)k * d + j];
+            rec[j] = mean;
             rec[D + j] = (1.0 / l) / l;
             log_det_half += std::log(l);
+            // (the device closing kernel writes the same: em_close.hip)
+            const double a = 1.0 / l;
+            const double b = -((mean - shift[j]) * a);
+            aT[(size_t)j * KP + k] = a;
+            bT[(size_t)j * KP + k] = b;
+            b2 = std::fma(b, b, b2);                          // (em_close.hip sums in the same order with the same fma)
+            if (!std::isfinite(a)) b2 = HUGE_VAL;
         }
         rec[2 * D] = std::log(mixing[k]) - log_det_half;
+        rec[2 * D + 1] = b2;
     }
 }
 

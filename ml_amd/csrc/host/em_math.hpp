@@ -37,12 +37,13 @@ bool build_estep_params_mfma4(int d, int D, int K, const double* mixing, const d
 void finalize_mstep(int d, int K, const double* stats, const double* shift, double n_global, double* mixing,
                     double* means, double* covariances);
 
-/// Diagonal-covariance extension: records [mean(D) | 1/sigma^2 (D) | log(pi) - sum log sigma] (layout.hpp diag_param_stride)
+/// Diagonal-covariance extension: K_padded records [mean(D) | 1/sigma^2 (D) | log(pi) - sum log sigma | two-op flag] and the
+/// dimension-major trailer [1/sigma | -(mean - shift)/sigma] behind them (layout.hpp diag_param_stride / diag_param_doubles)
 /// from variances[K*d]; sigma_j = sqrt(var_j) is the diagonal Cholesky factor, 1/sigma^2 = (1/sigma)/sigma what
 /// llt.solve(I) yields for it (ML/EM.cpp:279-285 restricted to a diagonal matrix).
 /// `records` receives K_padded >= K records; those beyond K are neutral (coef = -inf: log-density -inf, responsibility 0).
 void build_diag_params(int d, int D, int K, int K_padded, const double* mixing, const double* means, const double* variances,
-                       double* records);
+                       const double* shift, double* records);
 
 /// Diagonal closing arithmetic from the all-reduced statistics [S1'(d) | S2'(d) | S0] per component:
 ///   mean_k = shift + S1'/S0 ; var_kj = (S2'_j - S1'_j (S1'_j/S0)) / S0 + 1e-15 ; pi_k = S0 / N   (ML/EM.cpp:242-257, diagonal).

@@ -366,6 +366,7 @@ void run_diag_kernel(mlhip_data* dt, int K, const double* shift_dev, bool collec
     a.lse = dt->lse.as<double>();
     a.partials = dt->partials.as<double>(); a.partials_capacity = dt->partials.bytes / sizeof(double);
     a.ll_partials = dt->ll_partials.as<double>(); a.n_ll_partials = kMaxLlPartials;
+    a.two_op = shift_dev == dt->shift_dev.as<double>() ? 1 : 0;     // (the records' a, b are relative to the data's shift)
     int grid = 0;
     ctx->timed("em_diag", [&] { grid = mstats::launch_em_diag(a, ctx->num_cus, ctx->stream); });
     if (grid <= 0) throw std::runtime_error("diagonal EM kernel launch failed");
@@ -431,10 +432,10 @@ void upload_diag_records(mlhip_data* data, int K, const double* mixing, const do
 {
     mlhip_ctx* ctx = data->ctx;
     const int KP = mstats::em_diag_partial_rows(K);
-    const size_t rec_bytes = sizeof(double) * diag_param_stride(data->D) * (size_t)KP;
+    const size_t rec_bytes = sizeof(double) * diag_param_doubles(data->D, KP);
     target.reserve(rec_bytes);
     data->params_host.reserve(rec_bytes);
-    host::build_diag_params(data->d, data->D, K, KP, mixing, means, variances, data->params_host.as<double>());
+    host::build_diag_params(data->d, data->D, K, KP, mixing, means, variances, data->shift.data(), data->params_host.as<double>());
     HIP_CHECK(hipMemcpyAsync(target.p, data->params_host.p, rec_bytes, hipMemcpyHostToDevice, ctx->stream));
     ctx->sync();                                     // params_host may be rewritten right away by the caller's next upload
 }

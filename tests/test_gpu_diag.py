@@ -253,3 +253,50 @@ def test_two_operation_density_form_and_its_guard(ctx, oracle, d, K, n, monkeypa
     mu2[0], var2[0] = far, 1e-6
     c, e = step(X2, mu2, var2, False), step(X2, mu2, var2, True)
     assert c[0] == e[0] and np.array_equal(c[1], e[1]) and np.array_equal(c[2], e[2]) and np.array_equal(c[3], e[3])
+
+
+@pytest.mark.parametrize("d,K,n", [(16, 16, 20000), (12, 7, 9000), (6, 16, 9000), (3, 4, 5000)])
+def test_matrix_core_density_form_and_its_guard(ctx, oracle, d, K, n, monkeypatch):
+    """MLHIP_DIAG_GEMM=1 (an A/B variant, off by default): the log-densities as ONE product [K x 2d] . [x~^2 ; x~] on the matrix
+    cores -- the expanded form, whose cancellation costs about 4 eps B2 in a log-responsibility, B2_k = |(mu_k - shift) / sigma_k|^2.
+    Overlapping components whose PAIRS sit far from the global mean (B2 of several hundred, responsibilities strictly between 0
+    and 1): within the usual tolerances of the oracle while every B2 is below the limit; beyond it the kernel takes the exact
+    scalar-fed form by itself -- bit-identical to the run without the variant."""
+    rng = np.random.default_rng(7 * d + K)
+    centres = 16.0 * rng.standard_normal((K // 2 + 1, d)) / np.sqrt(d)          # |centre| ~ 16 sigma: B2 of a few hundred
+    means = centres[np.arange(K) // 2] + 0.6 * rng.standard_normal((K, d)) / np.sqrt(d)   # the two of a pair overlap
+    sig = rng.uniform(0.8, 1.25, (K, d))
+    comp = rng.integers(0, K, n)
+    X = np.ascontiguousarray(means[comp] + sig[comp] * rng.standard_normal((n, d)))
+    pi0 = np.full(K, 1.0 / K)
+    mu0 = means + 0.05 * rng.standard_normal((K, d))
+    var0 = sig ** 2
+    b2 = np.max(np.sum((mu0 - X.mean(axis=0)) ** 2 / var0, axis=1))
+    assert 50.0 < b2 < 1000.0, b2
+
+    def step(gemm, limit=None):
+        monkeypatch.setenv("MLHIP_DIAG_GEMM", "1" if gemm else "0")
+        monkeypatch.setenv("MLHIP_DIAG_MIXED", "0")                               # (the scalar-fed kernel hosts the variant)
+        if limit is not None:
+            monkeypatch.setenv("MLHIP_DIAG_EXPAND_LIMIT", str(limit))
+        dt = _data(ctx, X)
+        out = dt.em_step_diag(pi0, mu0, var0)
+        R, labels = dt.em_responsibilities(K), dt.em_labels(K)
+        dt.close()
+        for name in ("MLHIP_DIAG_GEMM", "MLHIP_DIAG_MIXED", "MLHIP_DIAG_EXPAND_LIMIT"):
+            monkeypatch.delenv(name, raising=False)
+        return out, R, labels
+
+    ll0, R0, labels0, pi_o, mu_o, var_o = _oracle_step(oracle, X, pi0, mu0, var0)
+    assert np.mean((R0.max(axis=1) < 0.99)) > 0.2                                  # genuinely overlapping
+    (ll, pi1, mu1, var1), R, labels = step(True)
+    assert abs(ll - ll0) <= 1e-12 * abs(ll0)
+    assert relerr(pi1, pi_o) < 1e-11 and relerr(mu1, mu_o) < 1e-11 and relerr(var1, var_o) < 1e-10
+    assert np.max(np.abs(R - R0)) < 1e-12                                          # (the block is rebuilt by the exact E-step kernel)
+    exact = step(False)
+    assert relerr(pi1, exact[0][1]) < 1e-12 and relerr(var1, exact[0][3]) < 1e-11  # ... so the statistics are what shows the form
+    assert ll != exact[0][0] or not np.array_equal(mu1, exact[0][2])               # the variant did run
+    guarded = step(True, limit=0.5 * b2)                                            # some B2 above the limit: exact form
+    assert guarded[0][0] == exact[0][0]
+    for a, b in zip(guarded[0][1:], exact[0][1:]):
+        assert np.array_equal(a, b)
