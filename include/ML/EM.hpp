@@ -63,6 +63,10 @@ public:
     /** `sample_size` x number_components(): the responsibilities of the last E-step. They stay on the device after
     fit() and are copied to the host on the first call (N x K doubles), unlike the reference which always holds them. */
     DLL_DECLSPEC const MatrixXd& responsibilities() const;
+    /** Extension: rows [first_row, first_row + number_rows) of responsibilities() as a number_rows x number_components() matrix,
+    WITHOUT materialising the whole block on the host when it still lives on the device (what a slice of a 5 GB block costs).
+    @throw std::invalid_argument If the range exceeds the sample. */
+    DLL_DECLSPEC MatrixXd responsibilities_rows(Index first_row, Index number_rows) const;
     double log_likelihood() const { return log_likelihood_; }
     std::shared_ptr<const Clustering::CentroidsInitialiser> means_initialiser() const { return means_initialiser_; }
     /** Posterior component probabilities of one point under the fitted parameters (host-side).

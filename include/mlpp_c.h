@@ -59,6 +59,8 @@ int mlpp_em_means(const mlpp_em* h, double* out /* d x K column-major, like EM::
 int mlpp_em_covariance(const mlpp_em* h, uint32_t k, double* out /* d x d */);
 int mlpp_em_mixing_probabilities(const mlpp_em* h, double* out);
 int mlpp_em_responsibilities(const mlpp_em* h, double* out /* N x K column-major */);
+/* Extension: rows [first_row, first_row + n_rows) only (n_rows x K column-major) -- no N x K host copy while the block is on the device. */
+int mlpp_em_responsibilities_rows(const mlpp_em* h, uint64_t first_row, uint64_t n_rows, double* out);
 int mlpp_em_log_likelihood(const mlpp_em* h, double* out);
 int mlpp_em_labels(const mlpp_em* h, uint32_t* out);
 int mlpp_em_converged(const mlpp_em* h, int* out);

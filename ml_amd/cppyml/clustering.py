@@ -7,7 +7,7 @@ Conventions kept from the reference:
   * `EM.means` is `d x K` (NOT transposed, clustering.cpp:126), `KMeans.centroids` is `K x d` (clustering.cpp:66-69,172);
   * `KMeans.labels` is a Python list (pybind11/stl.h conversion, clustering.cpp:173);
   * std::invalid_argument / std::domain_error surface as ValueError.
-Extensions (not in the reference surface): `EM.labels`, `EM.converged`, `EM.steps_done`, `KMeans.converged`,
+Extensions (not in the reference surface): `EM.labels`, `EM.converged`, `EM.steps_done`, `EM.responsibilities_rows`, `KMeans.converged`,
 `KMeans.steps_done`, `KMeans.labels_array`, `FixedCentroids`.
 """
 import ctypes as C
@@ -222,6 +222,13 @@ class EM:
         _, n = self._dims()
         out = np.empty((n, self.number_components), order="F")
         _check(_l.mlpp_em_responsibilities(self._h, _dp(out)))
+        return out
+
+    def responsibilities_rows(self, first_row, number_rows):
+        """Extension: rows [first_row, first_row + number_rows) of `responsibilities` without fetching the whole N x K block
+        from the device (5 GB at N=10M, K=64)."""
+        out = np.empty((int(number_rows), self.number_components), order="F")
+        _check(_l.mlpp_em_responsibilities_rows(self._h, C.c_uint64(int(first_row)), C.c_uint64(int(number_rows)), _dp(out)))
         return out
 
     @property

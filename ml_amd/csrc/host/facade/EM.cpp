@@ -120,6 +120,22 @@ const MatrixXd& EM::responsibilities() const
     return responsibilities_;
 }
 
+MatrixXd EM::responsibilities_rows(Index first_row, Index number_rows) const
+{
+    const Index n = static_cast<Index>(labels_.size());
+    if (first_row < 0 || number_rows < 0 || first_row > n || number_rows > n - first_row)
+        throw std::invalid_argument("EM: Row range beyond the sample");
+    MatrixXd out(number_rows, number_components_);
+    if (responsibilities_on_device_ && device_data_) {
+        check(mlhip_em_responsibilities_rows(device::context(), device_data_, number_components_, static_cast<uint64_t>(first_row),
+                                             static_cast<uint64_t>(number_rows), out.data(), std::max<Index>(number_rows, 1)));
+    } else {
+        for (unsigned int k = 0; k < number_components_; ++k)
+            std::copy_n(responsibilities_.col(k) + first_row, number_rows, out.col(k));
+    }
+    return out;
+}
+
 bool EM::fit(ConstMatrixRef data)
 {
     converged_ = false;

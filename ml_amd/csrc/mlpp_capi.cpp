@@ -129,6 +129,14 @@ int mlpp_em_means(const mlpp_em* h, double* out) { return guarded([&] { need(h);
 int mlpp_em_covariance(const mlpp_em* h, uint32_t k, double* out) { return guarded([&] { need(h); need(out); const MatrixXd& c = h->em.covariance(k); std::copy_n(c.data(), c.size(), out); }); }
 int mlpp_em_mixing_probabilities(const mlpp_em* h, double* out) { return guarded([&] { need(h); need(out); std::copy_n(h->em.mixing_probabilities().data(), h->em.mixing_probabilities().size(), out); }); }
 int mlpp_em_responsibilities(const mlpp_em* h, double* out) { return guarded([&] { need(h); need(out); const MatrixXd& r = h->em.responsibilities(); std::copy_n(r.data(), r.size(), out); }); }
+int mlpp_em_responsibilities_rows(const mlpp_em* h, uint64_t first_row, uint64_t n_rows, double* out)
+{
+    return guarded([&] {
+        need(h); need(out);
+        const MatrixXd r = h->em.responsibilities_rows(static_cast<Index>(first_row), static_cast<Index>(n_rows));
+        std::copy_n(r.data(), r.size(), out);
+    });
+}
 int mlpp_em_log_likelihood(const mlpp_em* h, double* out) { return guarded([&] { need(h); need(out); *out = h->em.log_likelihood(); }); }
 int mlpp_em_labels(const mlpp_em* h, uint32_t* out) { return guarded([&] { need(h); need(out); std::copy(h->em.labels().begin(), h->em.labels().end(), out); }); }
 int mlpp_em_converged(const mlpp_em* h, int* out) { return guarded([&] { need(h); need(out); *out = h->em.converged() ? 1 : 0; }); }

@@ -565,3 +565,40 @@ def test_kpp_draw_on_the_device_picks_the_reference_rows(oracle, tmp_path):
         assert p.returncode == 0, p.stderr[-2000:]
         got = np.load(out)
         assert np.max(np.abs(got - okm.centroids)) <= 1e-13 * np.max(np.abs(okm.centroids)), name
+
+
+def test_verbose_fit_prints_ten_rows_and_row_ranges_match_the_block(capfd):
+    """A verbose fit prints `responsibilities_.topRows(10)` after every step (reference ML/EM.cpp:149-159): only those rows are
+    fetched (mlhip_em_responsibilities_rows), and they are the first rows of the block the property returns. The same entry
+    serves row ranges of the lazy block (EM.responsibilities_rows, an extension)."""
+    from ml_amd.cppyml import clustering as cl
+    rng = np.random.default_rng(8)
+    n, d, K = 30000, 5, 3
+    X = np.ascontiguousarray(rng.standard_normal((n, d)) + 2.5 * rng.integers(0, K, (n, 1)))
+    em = cl.EM(K)
+    em.set_seed(5)
+    em.set_means_initialiser(cl.KPP())
+    em.set_maximum_steps(4)
+    em.set_absolute_tolerance(0.0)
+    em.set_relative_tolerance(0.0)
+    em.set_verbose(True)
+    em.fit(X)
+    out = capfd.readouterr().out
+    blocks = out.split("Responsibilities (first 10 rows):\n")
+    assert len(blocks) == 5                                   # four steps
+    printed = np.array([[float(v) for v in line.split()] for line in blocks[-1].strip().split("\n")[:10]])
+    assert printed.shape == (10, K)
+    rows = em.responsibilities_rows(0, 10)                    # (before the block is materialised on the host)
+    assert np.max(np.abs(printed - rows)) < 1e-5              # (std::cout prints 6 significant digits)
+    mid = em.responsibilities_rows(n // 2 - 3, 7)
+    R = em.responsibilities
+    assert np.array_equal(rows, R[:10]) and np.array_equal(mid, R[n // 2 - 3:n // 2 + 4])
+    assert np.array_equal(em.responsibilities_rows(n - 2, 2), R[n - 2:])     # ... and from the host copy afterwards
+    with pytest.raises(ValueError):
+        em.responsibilities_rows(n - 1, 2)
+    # the quiet fit of the same model takes the same steps
+    quiet = cl.EM(K)
+    quiet.set_seed(5); quiet.set_means_initialiser(cl.KPP()); quiet.set_maximum_steps(4)
+    quiet.set_absolute_tolerance(0.0); quiet.set_relative_tolerance(0.0)
+    quiet.fit(X)
+    assert abs(quiet.log_likelihood - em.log_likelihood) <= 1e-12 * abs(em.log_likelihood)
