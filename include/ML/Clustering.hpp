@@ -1,4 +1,8 @@
 #pragma once
+#ifdef MLHIP_ML_EIGEN_API_HPP
+#error "ML/Clustering.hpp and ML/EigenApi.hpp share their class names: include one family per translation unit"
+#endif
+#define MLHIP_ML_CLUSTERING_HPP
 /* Interfaces and initialisers of the clustering models: same class names, virtual signatures and semantics as
  * the reference's ML/Clustering.hpp:17-127 (Eigen argument types replaced by the views of Dense.hpp).
  * Initialisers run on the host on the caller's data, exactly like the reference (same libstdc++ <random> calls,

@@ -1,4 +1,8 @@
 #pragma once
+#ifdef MLHIP_ML_EIGEN_API_HPP
+#error "ML/EM.hpp and ML/EigenApi.hpp share their class names: include one family per translation unit"
+#endif
+#define MLHIP_ML_EM_HPP
 /* ml::EM -- Gaussian-mixture Expectation-Maximisation with the public interface of the reference's
  * ML/EM.hpp:18-198 (same method names, defaults, exceptions and result semantics), executed on an MI355X:
  * the E-step / M-step loops of ML/EM.cpp:190-263 run as HIP kernels through the C ABI in mlhip.h; this class keeps

@@ -1,4 +1,8 @@
 #pragma once
+#ifdef MLHIP_ML_EIGEN_API_HPP
+#error "ML/KMeans.hpp and ML/EigenApi.hpp share their class names: include one family per translation unit"
+#endif
+#define MLHIP_ML_KMEANS_HPP
 /* ml::Clustering::KMeans -- Lloyd K-means with the public interface of the reference's ML/KMeans.hpp:18-125,
  * executed on an MI355X: assignment_step/update_step (ML/KMeans.cpp:153-192) run as one HIP kernel per step through
  * the C ABI in mlhip.h; this class keeps fit/fit_once (ML/KMeans.cpp:25-114) and the host-side point query. */

@@ -70,3 +70,33 @@ def test_cpp_facade_picks_up_a_device_group_from_the_environment():
     env.pop("MLHIP_DEVICES", None)
     out = subprocess.run([EXE, "env-group"], capture_output=True, text=True, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+API = os.path.join(ROOT, "tests", "cpp", "eigen_api_test")
+
+
+def _build_api():
+    """include/ML/EigenApi.hpp (accessors that ARE Eigen objects, header-only over the C handles) reached as the reference's own
+    `#include "ML/EM.hpp"` through include/eigen_api, against tests/cpp/eigen_shim (a stand-in: INTEGRATION.md)."""
+    src = os.path.join(ROOT, "tests", "cpp", "eigen_api_test.cpp")
+    lib = os.path.join(ROOT, "ml_amd", "libmlhip.so")
+    deps = [src, lib, os.path.join(ROOT, "include", "ML", "EigenApi.hpp"), os.path.join(ROOT, "tests", "cpp", "eigen_shim", "Eigen", "Core")]
+    if os.path.exists(API) and os.path.getmtime(API) > max(os.path.getmtime(d) for d in deps):
+        return
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "tests", "cpp", "eigen_shim"),
+                           "-I", os.path.join(ROOT, "include", "eigen_api"), "-I", os.path.join(ROOT, "include"), src, "-o", API,
+                           "-L", os.path.join(ROOT, "ml_amd"), "-lmlhip", "-Wl,-rpath," + os.path.join(ROOT, "ml_amd"),
+                           "-Wl,-rpath,/opt/rocm/lib"])
+
+
+def test_eigen_typed_api_compiles_the_reference_tests_accessor_expressions():
+    _build_api()
+    out = subprocess.run([API, "host"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_eigen_typed_api_full_fits():
+    _build_api()
+    out = subprocess.run([API, "gpu"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
