@@ -98,11 +98,25 @@ struct FusedArgs {
     double* partials; size_t partials_capacity;              // scratch: [grid][KP][FP]
     double* ll_partials; int n_ll_partials;                  // out: per-workgroup log-likelihood sums (grid of them)
 };
+/// The tail of the ONE-kernel iteration of tiny fits (em_fused_small.hip): the last workgroup to finish combines the partial blocks
+/// in the order of the reduction kernel (-> stats, K*F + 1 doubles) and closes the iteration (em_close_body.hpp) -- new parameters,
+/// the next E-step's records, the info block -- so that an iteration is one launch instead of three. Single rank only (the
+/// statistics all-reduce would sit between the reduction and the closing).
+struct FusedTail {
+    unsigned* counter;                                       // device, zero before the first launch (the kernel leaves it zero)
+    double* stats;                                           // out: [K*F statistics | log-likelihood sum]
+    double n_global; double refine_limit;
+    double* mixing; double* means; double* covs;             // out (CloseArgs)
+    double* records; double* info;                           // out: the next records (estep_param_stride layout), the info block
+};
 namespace mstats {
 bool em_fused_supported(int d, int K);
 int em_fused_partial_rows(int K);
 int em_fused_partial_cols(int d);
 int launch_em_fused_small(const FusedArgs& a, int num_cus, hipStream_t stream);
+/// Components a tail closes at most (four waves take turns).
+constexpr int kFusedTailMaxK = 8;
+int launch_em_fused_small_tail(const FusedArgs& a, const FusedTail& t, int num_cus, hipStream_t stream);
 }
 /// Diagonal-covariance EM iteration in one kernel (em_diag.hip): params are em_diag_partial_rows(K) records of
 /// diag_param_stride(padded_dim(d)) -- K real ones, then neutral padding (coef = -inf) -- and shift holds padded_dim(d)

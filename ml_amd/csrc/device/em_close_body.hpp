@@ -1,0 +1,207 @@
+// The per-component closing arithmetic of the M-step as a device function, shared by em_close.hip (one wave per component, K
+// workgroups side by side) and em_fused_small.hip (the tail of the one-kernel iteration of tiny fits: the last workgroup to finish
+// closes the iteration). See em_close.hip for what it computes and why it mirrors the host's arithmetic statement by statement.
+#pragma once
+#include "device.hpp"
+
+namespace mlhip {
+namespace closing {
+
+__device__ __forceinline__ int sidx(int a, int b) { return a * (a + 1) / 2 + b; }   // stats_index
+
+constexpr int NT = 64;    // ONE wave per component: the factorization is a chain of short dependent steps, and a wave-wide
+                          // barrier costs next to nothing where a 4-wave workgroup barrier per step cost 40 of 63 us (d = 32)
+
+/// LAYOUT: 0 = estep_param_stride records (VALU E-step / fused small kernel), 2 = estep_mfma4_param_stride records.
+/// DT: the padded dimension when d <= 32 (the thread's column of W = L^-1 then lives in registers, loops fully unrolled),
+/// 0 = any d <= 64 (that column goes through LDS).
+/// LDS doubles one component's closing needs (statistics, covariance / factor, W, four d-vectors, three scalars, d flags).
+__host__ __device__ constexpr size_t scratch_doubles(int d) { return (size_t)(d + 1) * (d + 2) / 2 + 2 * (size_t)d * d + 4 * (size_t)d + 4 + (size_t)(d + 1) / 2 + 1; }
+
+/// All NT threads of the ONE wave that closes a component meet here: LDS writes of the lanes before it are visible to the lanes
+/// after it (a wave executes in lockstep; the fences keep the compiler and the LDS counter in line).
+#define MLHIP_CLOSE_SYNC()                                          \
+    do {                                                            \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      \
+        __builtin_amdgcn_wave_barrier();                            \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      \
+    } while (0)
+
+/// Component k, by the NT threads tid = 0 .. NT - 1 of one wave, with `sm` = scratch_doubles(d) doubles of LDS of their own.
+template <int LAYOUT, int DT>
+__device__ __forceinline__ void close_component(const double* __restrict__ stats, int K, int d, int D, const double* __restrict__ shift,
+                                                double n_global, double refine_limit, double* __restrict__ mixing,
+                                                double* __restrict__ means, double* __restrict__ covs, double* __restrict__ records,
+                                                int PS, double* __restrict__ info, const int k, const int tid, double* sm)
+{
+#pragma clang fp contract(off)     // the host's closing arithmetic, statement by statement (em_close.hip)
+    const int F = (d + 1) * (d + 2) / 2;
+    double* s = sm;                    // F statistics of this component
+    double* A = s + F;                 // d x d column-major: covariance, overwritten by its Cholesky factor (lower)
+    double* W = A + d * d;             // d x d column-major: L^-1 (lower)
+    double* m = W + d * d;             // d: S1'/S0
+    double* mean = m + d;              // d
+    double* c = mean + d;              // d: W (mean - shift)
+    double* tcol = c + d;              // d: column scratch of the factorization
+    double& s_ljj = tcol[d];
+    double& s_ldh = tcol[d + 1];
+    double& s_mix = tcol[d + 2];
+    int* codes = reinterpret_cast<int*>(tcol + d + 4);     // d ints
+
+    for (int e = tid; e < F; e += NT) s[e] = stats[(size_t)k * F + e];
+    MLHIP_CLOSE_SYNC();
+    const double s0 = s[sidx(d, d)];
+    if (tid < d) {
+        m[tid] = s[sidx(d, tid)] / s0;
+        mean[tid] = shift[tid] + m[tid];
+        means[(size_t)k * d + tid] = mean[tid];
+    }
+    if (tid == 0) { s_mix = s0 / n_global; mixing[k] = s_mix; }                      // ML/EM.cpp:257
+    MLHIP_CLOSE_SYNC();
+    for (int e = tid; e < d * d; e += NT) {
+        const int a = e % d, b = e / d;                                              // element (a, b), column-major
+        const int hi = a > b ? a : b, lo = a > b ? b : a;
+        double v = (s[sidx(hi, lo)] - s[sidx(d, hi)] * m[lo]) / s0;
+        if (a == b) v += 1e-15;                                                      // ML/EM.cpp:252
+        A[e] = v;
+        covs[(size_t)k * d * d + e] = v;
+    }
+    MLHIP_CLOSE_SYNC();
+    // refinement criterion of the host path (mlhip_abi.cpp finalize_out): scanned in order, a non-finite entry ends the scan
+    if (tid < d) {
+        const double off = mean[tid] - shift[tid], var = A[tid * d + tid];
+        codes[tid] = (!isfinite(off) || !isfinite(var)) ? 2 : ((refine_limit > 0 && off * off > refine_limit * var) ? 1 : 0);
+    }
+    MLHIP_CLOSE_SYNC();
+    if (tid == 0) {
+        int flag = 0;
+        if (s_mix > 0 && isfinite(s_mix))
+            for (int a = 0; a < d; ++a) {
+                if (codes[a] == 2) break;
+                if (codes[a] == 1) { flag = 1; break; }
+            }
+        info[1 + k] = flag;
+    }
+
+    // ---- Cholesky (host/em_math.cpp cholesky_lower) and W = L^-1 (whitening_matrix).
+    if constexpr (DT > 0) {
+        // d <= 32: thread i keeps ROW i of the factor in registers; what another thread's row contributes arrives through
+        // v_readlane (wave-uniform lane index -> an SGPR pair, used directly as the multiplier). No LDS round trips and no
+        // barriers inside the factorization: the chain of dependent steps is the arithmetic itself. Every thread forms the
+        // very dot products of the host loops, term by term in their order.
+        auto lane_value = [](double v, int lane) {
+            return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+        };
+        double Li[DT];
+#pragma unroll
+        for (int c0 = 0; c0 < DT; ++c0) Li[c0] = (tid < d && c0 < d) ? A[c0 * d + tid] : 0.0;   // A(tid, c0)
+#pragma unroll
+        for (int jj = 0; jj < DT; ++jj) {
+            if (jj < d) {                                                                // (uniform)
+                double t = Li[jj];
+#pragma unroll
+                for (int l = 0; l < jj; ++l) t -= Li[l] * lane_value(Li[l], jj);         // L(i,l) * L(j,l)
+                const double ljj = sqrt(lane_value(t, jj));
+                Li[jj] = tid == jj ? ljj : t / ljj;                                      // rows above the diagonal: unused
+            }
+        }
+        // W, one thread per column `col`: w[i] = ((i == col) - sum_{l<i} L(i,l) w[l]) / L(i,i). Entries above the diagonal are
+        // exact zeros, so the host's sum over l = col .. i-1 may as well start at l = 0 (t - L * 0 == t): same bits.
+        double w[DT];
+        const int col = tid;
+#pragma unroll
+        for (int ii = 0; ii < DT; ++ii) {
+            double t = (ii == col) ? 1.0 : 0.0;
+#pragma unroll
+            for (int l = 0; l < ii; ++l) t -= lane_value(Li[l], ii < d ? ii : 0) * w[l];
+            w[ii] = (ii < col || ii >= d) ? 0.0 : t / lane_value(Li[ii], ii < d ? ii : 0);
+        }
+        if (tid < d) {
+#pragma unroll
+            for (int c0 = 0; c0 < DT; ++c0)
+                if (c0 < d) {
+                    A[c0 * d + tid] = Li[c0];                                            // L back to LDS (log det, generic readers)
+                    W[col * d + c0] = w[c0];
+                }
+        }
+        MLHIP_CLOSE_SYNC();
+    } else {
+        for (int jj = 0; jj < d; ++jj) {
+            if (tid >= jj && tid < d) {
+                double t = A[jj * d + tid];
+                for (int l = 0; l < jj; ++l) t -= A[l * d + tid] * A[l * d + jj];
+                tcol[tid] = t;
+            }
+            MLHIP_CLOSE_SYNC();
+            if (tid == 0) s_ljj = sqrt(tcol[jj]);
+            MLHIP_CLOSE_SYNC();
+            if (tid >= jj && tid < d) A[jj * d + tid] = tid == jj ? s_ljj : tcol[tid] / s_ljj;
+            MLHIP_CLOSE_SYNC();
+        }
+        if (tid < d) {
+            const int col = tid;
+            for (int ii = 0; ii < d; ++ii) {
+                if (ii < col) { W[col * d + ii] = 0.0; continue; }
+                double t = (ii == col) ? 1.0 : 0.0;
+                for (int l = col; l < ii; ++l) t -= A[l * d + ii] * W[col * d + l];
+                W[col * d + ii] = t / A[ii * d + ii];
+            }
+        }
+    }
+    if (tid == 0) {
+        double ldh = 0.0;
+        for (int j = 0; j < d; ++j) ldh += log(A[j * d + j]);
+        s_ldh = ldh;
+    }
+    MLHIP_CLOSE_SYNC();
+    if (tid < d) {
+        double acc = 0.0;
+        for (int col = 0; col <= tid; ++col) acc += W[col * d + tid] * (mean[col] - shift[col]);
+        c[tid] = acc;
+    }
+    MLHIP_CLOSE_SYNC();
+    if (tid == 0) {
+        double biggest = 0.0;
+        bool finite = true;
+        for (int j = 0; j < d; ++j) {
+            const double a = fabs(c[j]);
+            if (a > biggest) biggest = a;
+            finite = finite && isfinite(c[j]);
+        }
+        info[1 + K + k] = finite ? biggest : __builtin_inf();
+        if (k == 0) info[0] = stats[(size_t)K * F];                                  // the log-likelihood sum rides along
+    }
+    // ---- the next E-step's record
+    double* rec = records + (size_t)k * PS;
+    const double coef = log(s_mix) - s_ldh;
+    if constexpr (LAYOUT == 2) {
+        const int Q = D / 4, NB = Q * (Q + 1) / 2;
+        for (int e = tid; e < NB * 16; e += NT) {
+            const int t = e / 16, kk = (e % 16) / 4, i = e % 4;
+            int C = 0;
+            while (C + 1 < Q && (C + 1) * Q - (C + 1) * C / 2 <= t) ++C;             // column-quad-major block order
+            const int R = C + (t - (C * Q - C * (C - 1) / 2));
+            const int row = 4 * R + i, col = 4 * C + kk;
+            rec[e] = (row < d && col <= row) ? W[col * d + row] : 0.0;
+        }
+        for (int j = tid; j < D; j += NT) {
+            rec[NB * 16 + j] = j < d ? mean[j] : 0.0;
+            rec[NB * 16 + D + j] = j < d ? -c[j] : 0.0;
+        }
+        if (tid == 0) rec[NB * 16 + 2 * D] = coef;
+    } else {
+        for (int j = tid; j < D; j += NT) rec[j] = j < d ? mean[j] : 0.0;
+        for (int e = tid; e < D * (D + 1) / 2; e += NT) {
+            int j = 0;
+            while ((j + 1) * (j + 2) / 2 <= e) ++j;                                  // packed lower triangle, row by row
+            const int l = e - j * (j + 1) / 2;
+            rec[D + e] = (j < d) ? W[l * d + j] : 0.0;
+        }
+        if (tid == 0) rec[PS - 1] = coef;
+    }
+}
+
+#undef MLHIP_CLOSE_SYNC
+
+}  // namespace closing
+}  // namespace mlhip

@@ -14,6 +14,7 @@
 //      on the matrix cores exactly as in em_mstats_small.hip.
 // HBM traffic per iteration: X once, LSE once. The log-responsibility block is produced on demand (labels /
 // responsibilities after the fit) by the ordinary E-step kernel from the same parameter records.
+#include "em_close_body.hpp"
 #include "em_mstats_common.hpp"
 #include "exp_nonpos.hpp"
 
@@ -25,11 +26,13 @@ typedef __attribute__((address_space(3))) const double lds_cdouble;
 template <int D> constexpr int xss() { return D <= 4 ? 7 : 11; }   // LDS row stride of the sample tile (d + 2 doubles used), odd
 constexpr int RSS = 17;   // LDS row stride of one 16-component responsibility block, odd
 
-template <int D, int RBW, int CB>
+/// TAIL: the workgroup that finishes LAST (a ticket per workgroup) also reduces the partial blocks and closes the iteration
+/// (FusedTail, device.hpp) -- tiny fits, where the three dependent launches of an iteration cost more than their kernels.
+template <int D, int RBW, int CB, bool TAIL>
 __global__ __launch_bounds__(256, (D <= 4 && RBW <= 2) ? 3 : 2) void em_fused_small_kernel(
     const double* __restrict__ xt, size_t ldx, uint32_t n, int d, const double* __restrict__ shift,
     const double* __restrict__ params, int K, int F, double* __restrict__ lse_out, double* __restrict__ partials, int KP,
-    int FP, double* __restrict__ ll_partials)
+    int FP, double* __restrict__ ll_partials, FusedTail tail)
 {
     constexpr int PS = D + D * (D + 1) / 2 + 1;    // estep_param_stride(D)
     constexpr int KMAX = 16 * RBW;
@@ -185,26 +188,80 @@ __global__ __launch_bounds__(256, (D <= 4 && RBW <= 2) ? 3 : 2) void em_fused_sm
     if (lane == 0) red[wave] = ll_acc;
     __syncthreads();
     if (tid == 0) ll_partials[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+
+    if constexpr (TAIL) {
+        __shared__ unsigned s_ticket;
+        __threadfence();                                    // this thread's partial-block / log-likelihood writes: device-wide
+        __syncthreads();
+        if (tid == 0) s_ticket = atomicAdd(tail.counter, 1u);
+        __syncthreads();
+        if (s_ticket != gridDim.x - 1) return;              // (workgroup-uniform)
+        __threadfence();                                    // the other workgroups' partial blocks
+        // ---- reduction, in the order of em_reduce_kernel (em_mstats.hip): 8 outputs per pass, each summed by 32 threads over
+        // the block slices b = s, s + 32, ... (ascending), the 32 slice sums added in ascending s -- the same bits
+        const int total = K * F, nb = (int)gridDim.x;
+        double* buf = smem;                                 // (the tiles are done with)
+        for (int e0 = 0; e0 < total; e0 += 8) {
+            const int o = tid & 7, sl = tid >> 3, e = e0 + o;
+            double s = 0.0;
+            if (e < total) {
+                const int k = e / F, f = e - k * F;
+                const double* p = partials + (size_t)k * FP + f;
+                for (int b = sl; b < nb; b += 32) s += p[(size_t)b * KP * FP];
+            }
+            buf[tid] = s;
+            __syncthreads();
+            if (sl == 0 && e < total) {
+                double t = buf[o];
+#pragma unroll
+                for (int q = 1; q < 32; ++q) t += buf[q * 8 + o];
+                tail.stats[e] = t;
+            }
+            __syncthreads();
+        }
+        {   // log-likelihood partials: the fixed-order tree of em_reduce_kernel's extra block
+            double s = 0.0;
+            for (int b = tid; b < nb; b += 256) s += ll_partials[b];
+            buf[tid] = s;
+            __syncthreads();
+            for (int off = 128; off > 0; off >>= 1) {
+                if (tid < off) buf[tid] += buf[tid + off];
+                __syncthreads();
+            }
+            if (tid == 0) { tail.stats[total] = buf[0]; *tail.counter = 0u; }   // (the counter is ready for the next launch)
+        }
+        __threadfence();                                    // the statistics are read back from memory by the closing waves
+        __syncthreads();
+        // ---- closing arithmetic, one wave per component, the four waves taking turns (em_close_body.hpp)
+        double* sm = smem + (size_t)wave * closing::scratch_doubles(d);
+        for (int k = wave; k < K; k += 4)
+            closing::close_component<0, D>(tail.stats, K, d, D, shift, tail.n_global, tail.refine_limit, tail.mixing, tail.means,
+                                           tail.covs, tail.records, PS, tail.info, k, lane, sm);
+    }
 }
 
-template <int D, int RBW, int CB>
-int launch_t(const FusedArgs& a, int grid, hipStream_t stream)
+template <int D, int RBW, int CB, bool TAIL>
+int launch_t(const FusedArgs& a, const FusedTail& t, int grid, hipStream_t stream)
 {
     constexpr int PS = D + D * (D + 1) / 2 + 1;
     constexpr int XSS = xss<D>();
     const size_t smem = sizeof(double) * (4 * ((size_t)TS * XSS + (size_t)TS * RSS) + (size_t)16 * RBW * PS);
-    hipLaunchKernelGGL((em_fused_small_kernel<D, RBW, CB>), dim3(grid), dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d, a.shift,
-                       a.params, a.K, stats_count(a.d), a.lse, a.partials, RBW * 16, CB * 16, a.ll_partials);
+    static_assert(4 * ((size_t)TS * XSS + (size_t)TS * RSS) >= 256 && 4 * ((size_t)TS * XSS + (size_t)TS * RSS) >= 4 * closing::scratch_doubles(D),
+                  "the tail reuses the tiles' LDS");
+    hipLaunchKernelGGL((em_fused_small_kernel<D, RBW, CB, TAIL>), dim3(grid), dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d, a.shift,
+                       a.params, a.K, stats_count(a.d), a.lse, a.partials, RBW * 16, CB * 16, a.ll_partials, t);
     return grid;
 }
 
-template <int D, int CB>
-int launch_d(const FusedArgs& a, int grid, hipStream_t stream)
+template <int D, int CB, bool TAIL>
+int launch_d(const FusedArgs& a, const FusedTail& t, int grid, hipStream_t stream)
 {
     const int RB = (a.K + 15) / 16;
-    if (RB == 1) return launch_t<D, 1, CB>(a, grid, stream);
-    if (RB == 2) return launch_t<D, 2, CB>(a, grid, stream);
-    if constexpr (CB == 1) { if (RB <= 4) return launch_t<D, 4, CB>(a, grid, stream); }
+    if (RB == 1) return launch_t<D, 1, CB, TAIL>(a, t, grid, stream);
+    if constexpr (!TAIL) {
+        if (RB == 2) return launch_t<D, 2, CB, false>(a, t, grid, stream);
+        if constexpr (CB == 1) { if (RB <= 4) return launch_t<D, 4, CB, false>(a, t, grid, stream); }
+    }
     return -1;
 }
 
@@ -222,8 +279,21 @@ bool em_fused_supported(int d, int K)
 int em_fused_partial_rows(int K) { const int RB = (K + 15) / 16; return (RB == 1 ? 1 : RB == 2 ? 2 : 4) * 16; }
 int em_fused_partial_cols(int d) { return ((stats_count(d) + 15) / 16) * 16; }
 
+namespace {
+template <bool TAIL> int launch_fused(const FusedArgs& a, const FusedTail& t, int num_cus, hipStream_t stream);
+}
+
 /// Returns the number of per-workgroup partial blocks written (stats and log-likelihood alike), or < 0.
-int launch_em_fused_small(const FusedArgs& a, int num_cus, hipStream_t stream)
+int launch_em_fused_small(const FusedArgs& a, int num_cus, hipStream_t stream) { return launch_fused<false>(a, FusedTail{}, num_cus, stream); }
+
+int launch_em_fused_small_tail(const FusedArgs& a, const FusedTail& t, int num_cus, hipStream_t stream)
+{
+    if (a.K > kFusedTailMaxK || !t.counter || !t.stats) return -1;
+    return launch_fused<true>(a, t, num_cus, stream);
+}
+
+namespace {
+template <bool TAIL> int launch_fused(const FusedArgs& a, const FusedTail& t, int num_cus, hipStream_t stream)
 {
     if (!em_fused_supported(a.d, a.K)) return -1;
     const uint32_t n_tiles = (a.n + TS - 1) / TS;
@@ -236,15 +306,16 @@ int launch_em_fused_small(const FusedArgs& a, int num_cus, hipStream_t stream)
     if ((size_t)grid * block > a.partials_capacity) grid = (int)(a.partials_capacity / block);
     if (grid < 1) return -2;
     switch (padded_dim(a.d)) {
-    case 1: return launch_d<1, 1>(a, grid, stream);
-    case 2: return launch_d<2, 1>(a, grid, stream);
-    case 3: return launch_d<3, 1>(a, grid, stream);
-    case 4: return launch_d<4, 1>(a, grid, stream);
-    case 6: return launch_d<6, 2>(a, grid, stream);
-    case 8: return launch_d<8, 3>(a, grid, stream);
+    case 1: return launch_d<1, 1, TAIL>(a, t, grid, stream);
+    case 2: return launch_d<2, 1, TAIL>(a, t, grid, stream);
+    case 3: return launch_d<3, 1, TAIL>(a, t, grid, stream);
+    case 4: return launch_d<4, 1, TAIL>(a, t, grid, stream);
+    case 6: return launch_d<6, 2, TAIL>(a, t, grid, stream);
+    case 8: return launch_d<8, 3, TAIL>(a, t, grid, stream);
     default: return -1;
     }
 }
+}  // namespace
 
 }  // namespace mstats
 }  // namespace mlhip

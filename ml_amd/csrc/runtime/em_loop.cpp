@@ -51,6 +51,7 @@ struct EmLoop {
     double *mixing, *means, *covs;              // the caller's arrays (start -> result)
     // ---- plan of an iteration
     bool fused = false, self_norm = false;
+    bool one_launch = false;                    // tiny fits: the fused kernel's last workgroup also reduces and closes (FusedTail)
     bool info_pinned = false;                   // full covariances: the closing kernel writes its info block into pinned host memory
     bool pack_pinned = false;                   // diagonal mode: its whole (small) pack lives there
     size_t n_cov = 0, F = 0, n_info = 0, n_pack = 0;
@@ -106,6 +107,15 @@ struct EmLoop {
         data->diag_step = diag;
         fused = !diag && data->estep_variant == 0 && fused_step_applies(data, K);
         self_norm = !diag && !fused && data->estep_variant == 2 && self_norm_applies(data, K);
+        // MLHIP_ONE_LAUNCH=1 (single rank, few components): the whole iteration in ONE launch -- measured SLOWER than the three
+        // launches (N=10k, d=4, K=3: 2.28 - 2.35 ms against 1.95 ms per 50-iteration fit on the same box: the last workgroup's
+        // serial reduction + closing cost more than the two dispatch gaps they save), so it is opt-in.
+        const char* one = std::getenv("MLHIP_ONE_LAUNCH");
+        one_launch = fused && !ctx->reduce_fn && K <= mstats::kFusedTailMaxK && one && one[0] == '1';
+        if (one_launch && !data->it_counter.p) {
+            data->it_counter.reserve(256);
+            HIP_CHECK(hipMemsetAsync(data->it_counter.p, 0, 256, ctx->stream));
+        }
         fold_allowed = env_allows("MLHIP_ESTEP_FOLD");
         refine_limit = refine_ratio();
         fold[0] = data->estep_fold;
@@ -117,6 +127,12 @@ struct EmLoop {
     void launch(uint32_t i)
     {
         const int in = (int)(i % 3), out = (int)((i + 1) % 3);
+        if (one_launch) {
+            launch_in_one(in, out);
+            HIP_CHECK(hipEventRecord(data->it_event[out], ctx->stream));
+            launched = i + 1;
+            return;
+        }
         if (diag) {
             run_diag_kernel(data, K, data->shift_dev.as<double>(), false, rec[in]);
         } else if (fused) {
@@ -142,6 +158,38 @@ struct EmLoop {
                                      hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipEventRecord(data->it_event[out], ctx->stream));
         launched = i + 1;
+    }
+
+    /// The same iteration as ONE launch (em_fused_small.hip, TAIL): E-step + statistics, and in the workgroup that finishes last
+    /// the reduction of the partial blocks and the closing arithmetic. Leaves what the three launches leave: statistics in
+    /// stats_dev, parameters in pack `out`, records in ring slot `out`, the info block on its way to the host.
+    void launch_in_one(int in, int out)
+    {
+        FusedArgs a{};
+        a.xt = data->xt.as<double>(); a.ldx = data->ldx; a.n = data->n; a.d = d;
+        a.shift = data->shift_dev.as<double>(); a.params = rec[in]->as<double>(); a.K = K;
+        a.lse = data->lse.as<double>();
+        a.partials = data->partials.as<double>(); a.partials_capacity = data->partials.bytes / sizeof(double);
+        a.ll_partials = data->ll_partials.as<double>(); a.n_ll_partials = kMaxLlPartials;
+        FusedTail t{};
+        t.counter = data->it_counter.as<unsigned>(); t.stats = data->stats_dev.as<double>();
+        t.n_global = (double)data->n_global; t.refine_limit = refine_limit;
+        t.mixing = pack_mixing(out); t.means = pack_means(out); t.covs = pack_covs(out);
+        t.records = rec[out]->as<double>();
+        t.info = info_pinned ? data->it_info_slot[out].as<double>() : pack_base(out);
+        int grid = 0;
+        ctx->timed("em_fused", [&] { grid = mstats::launch_em_fused_small_tail(a, t, ctx->num_cus, ctx->stream); });
+        if (grid <= 0) throw std::runtime_error("fused EM kernel launch failed");
+        HIP_CHECK(hipGetLastError());
+        data->n_ll = grid;
+        data->have_estep = true;
+        data->lw_valid = false;
+        data->stats_mode = kFromLogResp;
+        data->stats_resp = data->lw.as<double>();
+        data->stats_ld = data->ldr;
+        if (!info_pinned)
+            HIP_CHECK(hipMemcpyAsync(data->it_info_slot[out].p, data->it_pack[out].p, sizeof(double) * n_info, hipMemcpyDeviceToHost,
+                                     ctx->stream));
     }
 
     struct Verdict {

@@ -289,7 +289,7 @@ struct mlhip_data {
     // mlhip_em_iterate (em_loop.cpp): parameters and the E-steps' records stay on the device between iterations, in a ring of three --
     // iteration i reads the records of slot i % 3 (params_dev / params_next / params_prev take turns) and writes pack and records
     // (i + 1) % 3; it_pack: [info (1 + 2K) | mixing (K) | means (K d) | covariances]; one pinned read-back slot and event per pack
-    DevBuf params_next, params_prev, it_pack[3];
+    DevBuf params_next, params_prev, it_pack[3], it_counter;   // it_counter: the workgroup ticket of the one-launch iteration
     PinnedBuf it_info_slot[3];
     hipEvent_t it_event[3] = {nullptr, nullptr, nullptr};
     // source of the last statistics pass (for the per-component refinement pass)
@@ -310,7 +310,7 @@ struct mlhip_data {
         for (mlhip_data* p : parts) mlhip_data_free(p);
         for (DevBuf* b : {&xt, &shift_dev, &lw, &lse, &esum, &ll_partials, &params_dev, &partials, &stats_dev, &resp_dev,
                           &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_cent_next, &km_partials, &km_out, &km_mind, &km_probe, &km_scale, &km_cnorm, &km_xt_pad, &kpp_w, &kpp_scr,
-                          &refine_shift, &refine_stats, &params_next, &params_prev, &it_pack[0], &it_pack[1], &it_pack[2]})
+                          &refine_shift, &refine_stats, &params_next, &params_prev, &it_pack[0], &it_pack[1], &it_pack[2], &it_counter})
             b->release();
         for (auto& sl : it_info_slot) sl.release();
         for (auto& e : it_event) if (e) (void)hipEventDestroy(e);
