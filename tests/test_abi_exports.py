@@ -41,6 +41,10 @@ def test_no_cpu_fallback_without_device():
         pytest.skip("a GPU is present")
     with pytest.raises(_lib.NoDeviceError):
         _lib.Context()
+    with pytest.raises(_lib.NoDeviceError):
+        _lib.Context.group(2, device_ids=[0, 0])                 # a device group needs its GPUs just the same
+    with pytest.raises(ValueError):
+        _lib.Context.group(0)                                    # (argument errors come first: 1 to 64 shards)
     from ml_amd.cppyml import clustering
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         clustering.EM(2).fit(np.zeros((10, 3)))
