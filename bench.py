@@ -21,6 +21,10 @@ GPU's share of that job, N=12.5M, d=8, K=256, and the diagonal-covariance GMM of
 own roofline and cpu_baseline. Every line carries `allreduce_ms` (average device time of the statistics all-reduce, max over
 ranks; 0 on one GPU) and the spread of the ranks' own time per step (`ms_per_step_min` / `_max`).
 
+    python bench.py --gpus N --single-process              the same line from ONE process: the library's device group
+        (mlhip_ctx_create_group: the caller's one N x d block row-sharded inside the library, one host thread per shard, RCCL
+        between distinct GPUs, an in-process fixed-order sum when shards share a GPU) -- what ml::EM::fit / cppyml.clustering use
+        when MLHIP_NUM_GPUS is set; the line then carries `processes: 1` and `device_group`.
     python bench.py --workload kmeans [--gpus N ...]       K-means steps/sec at N=100M, d=8, K=256 as the primary line;
         one step = mlhip_kmeans_step = assignment + exact update sums + all-reduce of counts/sums + new centroids
         (ML/KMeans.cpp:82-108).
