@@ -451,6 +451,25 @@ mlhip_data* upload(mlhip_ctx* ctx, const double* x, bool on_device, uint32_t d, 
         gd->first_row.assign((size_t)g->n + 1, 0);
         const uint64_t base = n / (uint64_t)g->n, rem = n % (uint64_t)g->n;
         for (int s = 0; s < g->n; ++s) gd->first_row[(size_t)s + 1] = gd->first_row[(size_t)s] + base + ((uint64_t)s < rem ? 1 : 0);
+        if (on_device && n) {
+            // a block already in device memory must be readable from every shard's GPU: its own GPU, or a peer with access enabled
+            // (a kernel that reads memory it cannot reach faults -- and a fault can take the node's GPUs down)
+            hipPointerAttribute_t attr{};
+            if (hipPointerGetAttributes(&attr, x) != hipSuccess) { (void)hipGetLastError(); throw InvalidArgument("x_dev is not a device pointer"); }
+            std::vector<int> others;
+            for (int dev : g->devices)
+                if (dev != attr.device && std::find(others.begin(), others.end(), dev) == others.end()) others.push_back(dev);
+            for (int dev : others) {
+                int can = 0;
+                HIP_CHECK(hipDeviceCanAccessPeer(&can, dev, attr.device));
+                if (!can) throw Unsupported("device group: the block lives on GPU " + std::to_string(attr.device) + ", which GPU " +
+                                            std::to_string(dev) + " cannot read (no peer access): upload it from host memory");
+                HIP_CHECK(hipSetDevice(dev));
+                const hipError_t e = hipDeviceEnablePeerAccess(attr.device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_CHECK(e);
+                (void)hipGetLastError();
+            }
+        }
         each_shard(ctx, [&](int s, mlhip_ctx* c) {
             const uint64_t lo = gd->first_row[(size_t)s];
             gd->parts[(size_t)s] = upload_common(c, x ? x + (int64_t)lo * ld : nullptr, on_device, d, rows_of(gd, s), ld);

@@ -270,3 +270,19 @@ def test_facade_fit_through_a_group_matches_the_single_gpu_fit():
                 assert a == b, key
             else:
                 assert relerr(b, a) < 1e-9, key
+
+
+def test_group_upload_from_device_memory(group3, single):
+    """mlhip_data_upload_dev through a group: the block already sits in device memory (a torch tensor here); every shard reads its
+    rows from there (same GPU, or a peer with access enabled -- refused, not faulted on, otherwise)."""
+    import torch
+    from ml_amd import _lib
+    X, pi, mu, S = _mixture(5, 3, 10001, 4)
+    t = torch.from_numpy(X).to("cuda:0")
+    torch.cuda.synchronize()
+    g = _lib.Data(group3, device_ptr=t.data_ptr(), shape=X.shape)
+    s = _lib.Data(single, X)
+    a, b = g.em_step(pi, mu, S), s.em_step(pi, mu, S)
+    assert abs(a[0] - b[0]) <= 1e-12 * abs(b[0]) and relerr(a[2], b[2]) < 1e-11
+    assert np.array_equal(g.em_labels(3), s.em_labels(3))
+    g.close(); s.close()
