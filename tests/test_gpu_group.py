@@ -286,3 +286,32 @@ def test_group_upload_from_device_memory(group3, single):
     assert abs(a[0] - b[0]) <= 1e-12 * abs(b[0]) and relerr(a[2], b[2]) < 1e-11
     assert np.array_equal(g.em_labels(3), s.em_labels(3))
     g.close(); s.close()
+
+
+def test_group_reduce_selection_and_a_group_of_one(single, monkeypatch):
+    """MLHIP_GROUP_REDUCE: `rccl` on shards that share a GPU is refused with the reason (RCCL admits one rank per device), `direct` is
+    the in-process sum; a group of ONE shard is an ordinary context behind the group interface (no exchange step at all)."""
+    from ml_amd import _lib
+    monkeypatch.setenv("MLHIP_GROUP_REDUCE", "rccl")
+    with pytest.raises(_lib.MlhipError, match="one GPU"):
+        _lib.Context.group(2, device_ids=[0, 0])
+    monkeypatch.setenv("MLHIP_GROUP_REDUCE", "nonsense")
+    with pytest.raises(ValueError):
+        _lib.Context.group(2, device_ids=[0, 0])
+    monkeypatch.setenv("MLHIP_GROUP_REDUCE", "direct")
+    g2 = _lib.Context.group(2, device_ids=[0, 0])
+    assert g2.reduce_kind == "group-direct"
+    g2.close()
+    monkeypatch.delenv("MLHIP_GROUP_REDUCE")
+    one = _lib.Context.group(1, device_ids=[0])
+    try:
+        assert one.shards == 1 and one.reduce_kind == "none"
+        X, pi, mu, S = _mixture(6, 4, 5000, 12)
+        a, b = _lib.Data(one, X), _lib.Data(single, X)
+        ra, rb = a.em_iterate(pi, mu, S, 8), b.em_iterate(pi, mu, S, 8)
+        assert ra[2] == rb[2] and np.array_equal(ra[4], rb[4])          # one shard: the very same arithmetic
+        a.close(); b.close()
+    finally:
+        one.close()
+    with pytest.raises(ValueError):
+        _lib.Context.group(2, device_ids=[0, 99])                      # no such GPU
