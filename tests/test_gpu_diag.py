@@ -69,7 +69,7 @@ def test_diag_step_matches_sklearn_fixture(ctx, case):
 
 @pytest.mark.parametrize("n,d,K", [(1000, 1, 1), (777, 2, 3), (5000, 3, 16), (4099, 5, 17), (3000, 7, 33), (2500, 8, 64),
                                    (6000, 12, 5), (20000, 16, 16), (3001, 20, 48), (2000, 24, 2), (2000, 28, 31),
-                                   (4000, 32, 64), (63, 4, 2), (64, 6, 4), (65, 16, 16)])
+                                   (4000, 32, 64), (63, 4, 2), (64, 6, 4), (65, 16, 16), (3000, 8, 9), (300, 16, 1), (129, 6, 16)])
 def test_diag_step_matches_oracle(ctx, oracle, n, d, K):
     rng = np.random.default_rng(1000 * d + K)
     means = 3.0 * rng.standard_normal((K, d))
