@@ -118,7 +118,6 @@ __global__ __launch_bounds__(256, (D <= 4 && RBW <= 2) ? 3 : 2) void em_fused_sm
 #pragma unroll
         for (int k4 = 0; k4 < KMAX; k4 += 4) {
             if (k4 < Kt) {
-#pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const double e = exp_nonpos(lwv[k4 + u] - m);       // exp(-inf) = 0 for the clamped tail
                     lwv[k4 + u] = e;
@@ -240,6 +239,150 @@ __global__ __launch_bounds__(256, (D <= 4 && RBW <= 2) ? 3 : 2) void em_fused_sm
     }
 }
 
+/// FEW components in FEW dimensions (K F <= 64 numbers, F = (d+1)(d+2)/2: the reference's own benchmark regime, d = 2, K = 3,
+/// Benchmarks/bm_EM.cpp): the statistics on the VECTOR unit. The matrix-core form above pads K to 16 rows and F to 16 columns of a
+/// 16 x 16 x 4 product -- at d = 2, K = 8 five of six matrix-pipe cycles multiply padding (1 200 cycles per 64 samples for
+/// 6 144 flops), behind an LDS round trip of r and x~. Here every lane keeps K F accumulators in registers,
+///     acc[k][f] += r_ik phi_f(x~_i),   phi = vech([x~ ; 1][x~ ; 1]^T)   (K F fused multiply-adds per sample),
+/// over all its samples, and the lanes are summed ONCE at the end of the kernel (halving exchanges over the wave, see the epilogue;
+/// the four waves in order through LDS): no tiles, no barriers, no matrix instructions in the loop. The densities come from scalar registers as in
+/// em_estep.hip (the records are wave-uniform). Same partial-block layout as the kernel above: the reduction and closing kernels are
+/// shared. Sums are formed per lane, then across lanes: fixed order, reproducible, equal to the matrix-core form to rounding.
+/// (a, b) -> one value per lane: the lower half of the lanes (of the wave: BIT5; of every 32 lanes: the even 16-lane row) gets
+/// a_l + a_partner, the upper half b_partner + b_l, partner = l ^ 32 (l ^ 16). v_permlane32_swap (v_permlane16_swap) exchanges the
+/// upper half of its first operand with the lower half of its second; no LDS traffic.
+template <bool BIT5> __device__ __forceinline__ double halves_fold(double a, double b)
+{
+    const unsigned al = __double2loint(a), ah = __double2hiint(a), bl = __double2loint(b), bh = __double2hiint(b);
+    if constexpr (BIT5) {
+        const auto l = __builtin_amdgcn_permlane32_swap(al, bl, false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap(ah, bh, false, false);
+        return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+    } else {
+        const auto l = __builtin_amdgcn_permlane16_swap(al, bl, false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap(ah, bh, false, false);
+        return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+    }
+}
+
+template <int D, int K>
+__global__ __launch_bounds__(256) void em_fused_valu_kernel(
+    const double* __restrict__ xt, size_t ldx, uint32_t n, const double* __restrict__ shift, const double* __restrict__ params,
+    double* __restrict__ lse_out, double* __restrict__ partials, int KP, int FP, double* __restrict__ ll_partials)
+{
+    constexpr int PS = D + D * (D + 1) / 2 + 1;               // estep_param_stride(D)
+    constexpr int DA = D + 1, F = DA * (DA + 1) / 2;
+    constexpr int V = K * F, VP = (V + 3) / 4 * 4;             // accumulators per lane, padded for the two halving steps of the epilogue
+    __shared__ double fold[4][VP];
+    __shared__ double red[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double acc[VP];                                           // acc[k F + f]
+#pragma unroll
+    for (int e = 0; e < VP; ++e) acc[e] = 0.0;
+    double ll_acc = 0.0;
+    const uint32_t n_tiles = (n + TS - 1) / TS;
+    const uint32_t stride = gridDim.x * 4;
+    double xn[D];                                             // the NEXT tile's sample, in flight while this one is worked on
+    {
+        const uint32_t t0 = blockIdx.x * 4 + wave;
+        const uint32_t i0 = (t0 < n_tiles ? t0 : 0) * TS + lane;
+#pragma unroll
+        for (int j = 0; j < D; ++j) xn[j] = xt[(size_t)j * ldx + i0];
+    }
+    for (uint32_t tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += stride) {
+        const uint32_t i = tile * TS + lane;                  // < n_pad: inside the allocation
+        const bool live = i < n;
+        double x[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) x[j] = xn[j];
+        {
+            const uint32_t tn = tile + stride < n_tiles ? tile + stride : tile;
+#pragma unroll
+            for (int j = 0; j < D; ++j) xn[j] = xt[(size_t)j * ldx + (size_t)tn * TS + lane];
+        }
+        // ---- log-densities (em_estep.hip's arithmetic: z = x - mu, y = W z, lw = coef - |y|^2 / 2), records from scalar registers
+        double lwv[K];
+        double m = -__builtin_inf();
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            {
+                const double* __restrict__ p = params + (size_t)k * PS;
+                double z[D];
+#pragma unroll
+                for (int j = 0; j < D; ++j) z[j] = x[j] - p[j];
+                const double* __restrict__ w = p + D;
+                double q = 0.0;
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    double y = w[j * (j + 1) / 2] * z[0];
+#pragma unroll
+                    for (int l = 1; l <= j; ++l) y = __builtin_fma(w[j * (j + 1) / 2 + l], z[l], y);
+                    q = __builtin_fma(y, y, q);
+                }
+                const double lw = __builtin_fma(-0.5, q, p[PS - 1]);
+                lwv[k] = lw;
+                m = lw > m ? lw : m;
+            }
+        }
+        // ---- normalisation: one exp per (sample, component), the K polynomial chains side by side (exp_nonpos.hpp)
+#pragma unroll
+        for (int k = 0; k < K; ++k) lwv[k] -= m;
+        exp_nonpos_n<K>(lwv);
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) s += lwv[k];
+        const double lse = m + log(s);
+        lse_out[i] = lse;
+        if (live) ll_acc += lse;
+        const double inv = live ? 1.0 / s : 0.0;              // padding samples contribute nothing
+        // ---- statistics: phi_(a, b) = x~_a x~_b, a >= b, x~ = [x - shift ; 1], packed at a (a + 1) / 2 + b
+        double xs[DA];
+#pragma unroll
+        for (int j = 0; j < D; ++j) xs[j] = x[j] - shift[j];
+        xs[D] = 1.0;
+        double phi[F];
+#pragma unroll
+        for (int a = 0; a < DA; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) phi[a * (a + 1) / 2 + b] = a == D ? xs[b] : xs[a] * xs[b];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const double r = lwv[k] * inv;
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc[k * F + f] = __builtin_fma(r, phi[f], acc[k * F + f]);
+        }
+    }
+    // ---- epilogue: the 64 lanes of every accumulator, summed in a fixed order. A plain butterfly moves 6 V values per wave through
+    // the LDS pipe (ds_bpermute; 8 us of a 26 us iteration at K F = 48). Instead the first two steps HALVE the values a lane holds:
+    // lanes 0-31 take accumulators [0, VP / 2) of both halves of the wave, lanes 32-63 the rest (one v_permlane32_swap per word and
+    // one addition per PAIR), then the same between the 16-lane rows; what is left is VP / 4 values over 16 lanes.
+#pragma unroll
+    for (int e = 0; e < VP / 2; ++e) acc[e] = halves_fold<true>(acc[e], acc[e + VP / 2]);
+#pragma unroll
+    for (int e = 0; e < VP / 4; ++e) acc[e] = halves_fold<false>(acc[e], acc[e + VP / 4]);
+#pragma unroll
+    for (int e = 0; e < VP / 4; ++e) {
+        double v = acc[e];
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((lane & 15) == 0) fold[wave][e + (lane >> 4) * (VP / 4)] = v;      // row r of the wave holds accumulators r VP / 4 + e
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ll_acc += __shfl_down(ll_acc, off, 64);
+    if (lane == 0) red[wave] = ll_acc;
+    __syncthreads();
+    double* out = partials + (size_t)blockIdx.x * KP * FP;
+    for (int e = tid; e < K * F; e += 256) {
+        const int k = e / F, f = e - k * F;
+        out[(size_t)k * FP + f] = ((fold[0][e] + fold[1][e]) + fold[2][e]) + fold[3][e];
+    }
+    if (tid == 0) ll_partials[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+/// Largest K the vector-unit form is built for at dimension d (K F <= ~100 accumulators per lane); 0: not built for d.
+constexpr int valu_max_k(int D) { return D == 1 ? 32 : D == 2 ? 16 : D == 3 ? 10 : D == 4 ? 7 : D == 6 ? 4 : 0; }
+
 template <int D, int RBW, int CB, bool TAIL>
 int launch_t(const FusedArgs& a, const FusedTail& t, int grid, hipStream_t stream)
 {
@@ -293,9 +436,68 @@ int launch_em_fused_small_tail(const FusedArgs& a, const FusedTail& t, int num_c
 }
 
 namespace {
+template <int D, int K> void launch_valu_k(const FusedArgs& a, int num_cus, int& grid, hipStream_t stream)
+{
+    if constexpr (K >= 1) {
+        if (a.K == K) {
+            static const int per_cu = [] {                           // workgroups a CU holds (registers: 2 K F accumulator words per lane)
+                int nb = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, em_fused_valu_kernel<D, K>, 256, 0) != hipSuccess || nb < 1) nb = 2;
+                return nb > 8 ? 8 : nb;
+            }();
+            const int full = per_cu * num_cus;
+            if (grid > full) grid = full;
+            hipLaunchKernelGGL((em_fused_valu_kernel<D, K>), dim3(grid), dim3(256), 0, stream, a.xt, a.ldx, a.n, a.shift, a.params, a.lse,
+                               a.partials, em_fused_partial_rows(a.K), em_fused_partial_cols(a.d), a.ll_partials);
+        } else {
+            launch_valu_k<D, K - 1>(a, num_cus, grid, stream);
+        }
+    }
+}
+
+template <int D> int launch_valu(const FusedArgs& a, int num_cus, hipStream_t stream)
+{
+    const uint32_t n_tiles = (a.n + TS - 1) / TS;
+    int grid = 8 * num_cus;                                          // (cut to what the registers of the instantiation allow, below)
+    if ((uint32_t)grid * 4 > n_tiles) grid = (int)((n_tiles + 3) / 4);
+    if (grid < 1) grid = 1;
+    if (grid > a.n_ll_partials) grid = a.n_ll_partials;
+    const size_t block = (size_t)em_fused_partial_rows(a.K) * em_fused_partial_cols(a.d);
+    if ((size_t)grid * block > a.partials_capacity) grid = (int)(a.partials_capacity / block);
+    if (grid < 1) return -2;
+    launch_valu_k<D, valu_max_k(D)>(a, num_cus, grid, stream);       // one instantiation per (d, K): the loops over components are
+    return grid;                                                     // straight-line code, the records sit in scalar registers
+}
+
+/// Shapes that take the vector-unit form (tools/small_shape_sweep.sh, tools/small_shape_ab.sh; profiles/r04_small_shapes.txt):
+/// K F <= 64 accumulators -- at every sample count (d = 2, K = 3: 15.0 against 17.7 us per iteration at N = 16 384, 52 against
+/// 104 us at N = 4 194 304; never slower); up to valu_max_k (K F ~ 100: one or two waves per SIMD, a longer epilogue) from 2^20
+/// samples on, where it still wins by 6 - 36 % (below that the matrix-core form is up to 4 us faster).
+/// MLHIP_FUSED_VALU=0: the matrix-core form instead (A/B runs; read per call).
+bool valu_form_applies(const FusedArgs& a)
+{
+    const char* e = std::getenv("MLHIP_FUSED_VALU");
+    if (e && e[0] == '0') return false;
+    const int D = padded_dim(a.d);
+    if (D != a.d || D > 6 || a.K > valu_max_k(D)) return false;
+    return a.K * stats_count(a.d) <= 64 || a.n >= (1u << 20);
+}
+
 template <bool TAIL> int launch_fused(const FusedArgs& a, const FusedTail& t, int num_cus, hipStream_t stream)
 {
     if (!em_fused_supported(a.d, a.K)) return -1;
+    if constexpr (!TAIL) {
+        if (valu_form_applies(a)) {
+            switch (a.d) {
+            case 1: return launch_valu<1>(a, num_cus, stream);
+            case 2: return launch_valu<2>(a, num_cus, stream);
+            case 3: return launch_valu<3>(a, num_cus, stream);
+            case 4: return launch_valu<4>(a, num_cus, stream);
+            case 6: return launch_valu<6>(a, num_cus, stream);
+            default: break;
+            }
+        }
+    }
     const uint32_t n_tiles = (a.n + TS - 1) / TS;
     const int RB = (a.K + 15) / 16;
     int grid = (padded_dim(a.d) <= 4 && RB <= 2 ? 3 : 2) * num_cus;   // resident workgroups per CU of the instance

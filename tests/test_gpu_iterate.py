@@ -271,6 +271,7 @@ def test_one_launch_iteration_gives_the_same_fit(ctx, d, K, n, monkeypatch):
     dt = _lib.Data(ctx, X)
     _, cov = dt.sample_covariance()
     pi0, S0 = np.full(K, 1.0 / K), np.stack([cov] * K)
+    monkeypatch.setenv("MLHIP_FUSED_VALU", "0")     # the one-launch form is the matrix-core kernel: compare with its three-launch form
     ref = dt.em_iterate(pi0, mu0, S0, 25, atol=1e-10)
     labels = dt.em_labels(K)
     monkeypatch.setenv("MLHIP_ONE_LAUNCH", "1")
