@@ -116,6 +116,8 @@ int em_fused_partial_cols(int d);
 int launch_em_fused_small(const FusedArgs& a, int num_cus, hipStream_t stream);
 /// Components a tail closes at most (four waves take turns).
 constexpr int kFusedTailMaxK = 8;
+/// ... and the largest dimension a tail is built for (the LDS-fed form of the kernel).
+constexpr int kFusedTailMaxDim = 6;
 int launch_em_fused_small_tail(const FusedArgs& a, const FusedTail& t, int num_cus, hipStream_t stream);
 }
 /// Diagonal-covariance EM iteration in one kernel (em_diag.hip): params are em_diag_partial_rows(K) records of

@@ -26,9 +26,38 @@ typedef __attribute__((address_space(3))) const double lds_cdouble;
 template <int D> constexpr int xss() { return D <= 4 ? 7 : 11; }   // LDS row stride of the sample tile (d + 2 doubles used), odd
 constexpr int RSS = 17;   // LDS row stride of one 16-component responsibility block, odd
 
+/// lw = coef - |W (x - mu)|^2 / 2 from one packed record [mean(D) | W lower triangle, row by row | coef] (em_estep.hip's
+/// arithmetic, term by term); P: an LDS pointer (broadcast reads) or a wave-uniform global pointer (scalar loads, SCALAR = true:
+/// a scheduling fence after EVERY row keeps the loads of later rows from being hoisted above the rows that use them -- at d = 8 a
+/// record is 90 SGPRs, and with a fence every second row or fewer the compiler spills: 811 v_readlane + 572 v_writelane per 32
+/// components against 134 + 128, 1.96 against 1.68 ms at N = 10M, K = 32. Two components, or two rows, side by side between the
+/// fences -- more independent FMA chains per wave -- spill the same way).
+template <int D, bool SCALAR, typename P> __device__ __forceinline__ double record_log_density(P p, const double (&x)[D])
+{
+    constexpr int PS = D + D * (D + 1) / 2 + 1;
+    double z[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) z[j] = x[j] - p[j];
+    P w = p + D;
+    double q = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        double y = w[j * (j + 1) / 2] * z[0];
+#pragma unroll
+        for (int l = 1; l <= j; ++l) y = __builtin_fma(w[j * (j + 1) / 2 + l], z[l], y);
+        q = __builtin_fma(y, y, q);
+        if constexpr (SCALAR) __builtin_amdgcn_sched_barrier(0);
+    }
+    return __builtin_fma(-0.5, q, p[PS - 1]);
+}
+
 /// TAIL: the workgroup that finishes LAST (a ticket per workgroup) also reduces the partial blocks and closes the iteration
 /// (FusedTail, device.hpp) -- tiny fits, where the three dependent launches of an iteration cost more than their kernels.
-template <int D, int RBW, int CB, bool TAIL>
+/// SFEED: the component records come from SCALAR registers (wave-uniform s_load of the global records, as in em_estep.hip) instead of
+/// broadcast reads of an LDS copy. At d = 7, 8 a record is 45 doubles: with the LDS feed the density loop of 32 components issues
+/// 1 440 LDS reads per 64 samples next to 2 400 vector instructions, and the four SIMDs of a CU share ONE LDS pipe -- that is what
+/// made the fused form slower than the two-kernel path there; scalar loads leave the LDS pipe to the statistics tiles.
+template <int D, int RBW, int CB, bool TAIL, bool SFEED = false>
 __global__ __launch_bounds__(256, (D <= 4 && RBW <= 2) ? 3 : 2) void em_fused_small_kernel(
     const double* __restrict__ xt, size_t ldx, uint32_t n, int d, const double* __restrict__ shift,
     const double* __restrict__ params, int K, int F, double* __restrict__ lse_out, double* __restrict__ partials, int KP,
@@ -45,9 +74,11 @@ __global__ __launch_bounds__(256, (D <= 4 && RBW <= 2) ? 3 : 2) void em_fused_sm
     double* Rw = Xw + TS * XSS;
     double* recs = smem + 4 * (TS * XSS + TS * RSS);    // [KMAX][PS]: all component records, staged once per workgroup;
     const int da = d + 1;                               // those beyond K are neutral (zeros, coef = -inf: log-density -inf)
-    for (int e = tid; e < KMAX * PS; e += 256)
-        recs[e] = e < K * PS ? params[e] : (e % PS == PS - 1 ? -__builtin_inf() : 0.0);
-    __syncthreads();
+    if constexpr (!SFEED) {
+        for (int e = tid; e < KMAX * PS; e += 256)
+            recs[e] = e < K * PS ? params[e] : (e % PS == PS - 1 ? -__builtin_inf() : 0.0);
+        __syncthreads();
+    }
 
     int offa[CB], offb[CB];
 #pragma unroll
@@ -91,20 +122,15 @@ __global__ __launch_bounds__(256, (D <= 4 && RBW <= 2) ? 3 : 2) void em_fused_sm
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int k = k4 + u;
-                    lds_cdouble* p = recv + k * PS;                              // LDS broadcast reads
-                    double z[D];
-#pragma unroll
-                    for (int j = 0; j < D; ++j) z[j] = x[j] - p[j];
-                    lds_cdouble* w = p + D;
-                    double q = 0.0;
-#pragma unroll
-                    for (int j = 0; j < D; ++j) {
-                        double y = w[j * (j + 1) / 2] * z[0];
-#pragma unroll
-                        for (int l = 1; l <= j; ++l) y = __builtin_fma(w[j * (j + 1) / 2 + l], z[l], y);
-                        q = __builtin_fma(y, y, q);
+                    double lw;
+                    if constexpr (SFEED) {
+                        // a component beyond K inside a live group of four: the last real record again (no read past the K
+                        // records), its log-density replaced by -inf (a scalar select)
+                        lw = record_log_density<D, true>(params + (size_t)(k < Kt ? k : Kt - 1) * PS, x);
+                        lw = k < Kt ? lw : -__builtin_inf();
+                    } else {
+                        lw = record_log_density<D, false>(recv + k * PS, x);     // LDS broadcast reads
                     }
-                    const double lw = __builtin_fma(-0.5, q, p[PS - 1]);
                     lwv[k] = lw;
                     m = lw > m ? lw : m;
                 }
@@ -383,38 +409,61 @@ __global__ __launch_bounds__(256) void em_fused_valu_kernel(
 /// Largest K the vector-unit form is built for at dimension d (K F <= ~100 accumulators per lane); 0: not built for d.
 constexpr int valu_max_k(int D) { return D == 1 ? 32 : D == 2 ? 16 : D == 3 ? 10 : D == 4 ? 7 : D == 6 ? 4 : 0; }
 
-template <int D, int RBW, int CB, bool TAIL>
+template <int D, int RBW, int CB, bool TAIL, bool SFEED = false>
 int launch_t(const FusedArgs& a, const FusedTail& t, int grid, hipStream_t stream)
 {
     constexpr int PS = D + D * (D + 1) / 2 + 1;
     constexpr int XSS = xss<D>();
-    const size_t smem = sizeof(double) * (4 * ((size_t)TS * XSS + (size_t)TS * RSS) + (size_t)16 * RBW * PS);
+    const size_t smem = sizeof(double) * (4 * ((size_t)TS * XSS + (size_t)TS * RSS) + (SFEED ? 0 : (size_t)16 * RBW * PS));
     static_assert(4 * ((size_t)TS * XSS + (size_t)TS * RSS) >= 256 && 4 * ((size_t)TS * XSS + (size_t)TS * RSS) >= 4 * closing::scratch_doubles(D),
                   "the tail reuses the tiles' LDS");
-    hipLaunchKernelGGL((em_fused_small_kernel<D, RBW, CB, TAIL>), dim3(grid), dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d, a.shift,
+    hipLaunchKernelGGL((em_fused_small_kernel<D, RBW, CB, TAIL, SFEED>), dim3(grid), dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d, a.shift,
                        a.params, a.K, stats_count(a.d), a.lse, a.partials, RBW * 16, CB * 16, a.ll_partials, t);
     return grid;
+}
+
+/// Which feed the density loop takes its records from (tools/sfeed_sweep.sh, profiles/r04_fused_feed.txt). Scalar registers: d = 7, 8
+/// always (no LDS-fed form is built there); d >= 3 from 2^19 samples on (N = 8.4M: d = 6, K = 32 1.32 -> 1.04 ms, d = 4, K = 16
+/// 0.416 -> 0.371 ms, d = 3, K = 16 0.346 -> 0.336 ms; below, with one or two tiles per wave, the scalar-load latency of every
+/// record row is exposed: 1 - 6 us slower) ; d = 1, 2: LDS (0.97 against 1.04 ms at d = 1, K = 64). MLHIP_FUSED_SFEED=0 / 1 forces
+/// one feed for d <= 6 (A/B runs; the tail form keeps the LDS feed).
+template <int D> bool scalar_feed(uint32_t n)
+{
+    if constexpr (D >= 8) return true;
+    const char* e = std::getenv("MLHIP_FUSED_SFEED");
+    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+    return D >= 3 && n >= (1u << 19);
 }
 
 template <int D, int CB, bool TAIL>
 int launch_d(const FusedArgs& a, const FusedTail& t, int grid, hipStream_t stream)
 {
     const int RB = (a.K + 15) / 16;
-    if (RB == 1) return launch_t<D, 1, CB, TAIL>(a, t, grid, stream);
     if constexpr (!TAIL) {
-        if (RB == 2) return launch_t<D, 2, CB, false>(a, t, grid, stream);
-        if constexpr (CB == 1) { if (RB <= 4) return launch_t<D, 4, CB, false>(a, t, grid, stream); }
+        if (scalar_feed<D>(a.n)) {
+            if (RB == 1) return launch_t<D, 1, CB, false, true>(a, t, grid, stream);
+            if (RB == 2) return launch_t<D, 2, CB, false, true>(a, t, grid, stream);
+            if constexpr (CB == 1) { if (RB <= 4) return launch_t<D, 4, CB, false, true>(a, t, grid, stream); }
+            return -1;
+        }
+    }
+    if constexpr (D < 8) {
+        if (RB == 1) return launch_t<D, 1, CB, TAIL>(a, t, grid, stream);
+        if constexpr (!TAIL) {
+            if (RB == 2) return launch_t<D, 2, CB, false>(a, t, grid, stream);
+            if constexpr (CB == 1) { if (RB <= 4) return launch_t<D, 4, CB, false>(a, t, grid, stream); }
+        }
     }
     return -1;
 }
 
 }  // namespace
 
-/// Shapes the fused kernel is used for: d <= 6 with K <= 32, d <= 4 with K <= 64 (the K densities and the
+/// Shapes the fused kernel is used for: d <= 8 with K <= 32, d <= 4 with K <= 64 (the K densities and the
 /// accumulator tiles must fit the register file).
 bool em_fused_supported(int d, int K)
 {
-    if (d < 1 || d > 6 || K < 1) return false;       // (d = 7, 8: the two-kernel path is faster)
+    if (d < 1 || d > 8 || K < 1) return false;       // (d = 7, 8: with the records from scalar registers, see the kernel)
     const int RB = (K + 15) / 16, CB = (stats_count(d) + 15) / 16;
     return RB <= 2 || (RB <= 4 && CB == 1);
 }
@@ -431,7 +480,7 @@ int launch_em_fused_small(const FusedArgs& a, int num_cus, hipStream_t stream) {
 
 int launch_em_fused_small_tail(const FusedArgs& a, const FusedTail& t, int num_cus, hipStream_t stream)
 {
-    if (a.K > kFusedTailMaxK || !t.counter || !t.stats) return -1;
+    if (a.K > kFusedTailMaxK || a.d > kFusedTailMaxDim || !t.counter || !t.stats) return -1;
     return launch_fused<true>(a, t, num_cus, stream);
 }
 

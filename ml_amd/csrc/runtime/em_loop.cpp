@@ -111,7 +111,7 @@ struct EmLoop {
         // launches (N=10k, d=4, K=3: 2.28 - 2.35 ms against 1.95 ms per 50-iteration fit on the same box: the last workgroup's
         // serial reduction + closing cost more than the two dispatch gaps they save), so it is opt-in.
         const char* one = std::getenv("MLHIP_ONE_LAUNCH");
-        one_launch = fused && !ctx->reduce_fn && K <= mstats::kFusedTailMaxK && one && one[0] == '1';
+        one_launch = fused && !ctx->reduce_fn && K <= mstats::kFusedTailMaxK && data->d <= mstats::kFusedTailMaxDim && one && one[0] == '1';
         if (one_launch && !data->it_counter.p) {
             data->it_counter.reserve(256);
             HIP_CHECK(hipMemsetAsync(data->it_counter.p, 0, 256, ctx->stream));

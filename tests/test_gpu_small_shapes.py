@@ -104,3 +104,36 @@ def test_fit_loop_on_the_vector_unit_form(ctx, oracle, d, K, n, monkeypatch):
     assert abs(got[2] - ll) <= 1e-11 * abs(ll)
     assert relerr(got[4], em.means) < 1e-9
     dt.close()
+
+
+@pytest.mark.parametrize("d,K", [(7, 1), (7, 5), (8, 3), (8, 16), (8, 17), (7, 32), (8, 32), (6, 20), (5, 32)])
+@pytest.mark.parametrize("n", [1, 65, 4097, 200003])
+def test_fused_step_with_scalar_fed_records(ctx, oracle, d, K, n, monkeypatch):
+    """d = 7, 8 (K <= 32): the fused E+M kernel with the component records in scalar registers (em_fused_small.hip, SFEED) against
+    the two-kernel path (MLHIP_FUSED=0: E-step + statistics kernels) and the oracle; d = 5, 6 take the same feed with
+    MLHIP_FUSED_SFEED=1 (an A/B switch) and must agree with their LDS-fed default bit for bit (same arithmetic, same order)."""
+    from ml_amd import _lib
+    X, pi0, mu0, S0 = _problem(d, K, n, 31 * d + K + n % 89)
+    dt = _lib.Data(ctx, X)
+    if d <= 6:
+        ref = dt.em_step(pi0, mu0, S0)
+        monkeypatch.setenv("MLHIP_FUSED_SFEED", "1")
+    got = dt.em_step(pi0, mu0, S0)
+    R = dt.em_responsibilities(K)
+    if d <= 6:
+        assert got[0] == ref[0] and all(np.array_equal(a, b) for a, b in zip(got[1:], ref[1:]))
+    monkeypatch.setenv("MLHIP_FUSED", "0")
+    two = dt.em_step(pi0, mu0, S0)
+    assert abs(got[0] - two[0]) <= 1e-13 * abs(two[0])
+    assert np.max(np.abs(R - dt.em_responsibilities(K))) < 1e-13
+    em = oracle.EM(K)
+    em.set_parameters(mu0, S0, pi0)
+    em.expectation_step(X)
+    assert abs(got[0] - em.log_likelihood) <= 1e-12 * abs(em.log_likelihood)
+    assert np.max(np.abs(R - em.responsibilities)) < 1e-12
+    if n >= 50 * K:
+        em.maximisation_step(X)
+        for a, b, c, tol in zip(got[1:], two[1:], (em.mixing_probabilities, em.means, em.covariances), (1e-12, 1e-12, 1e-10)):
+            assert relerr(a, c) < tol
+            assert relerr(a, b) < tol
+    dt.close()
