@@ -51,6 +51,7 @@ struct EmLoop {
     double *mixing, *means, *covs;              // the caller's arrays (start -> result)
     // ---- plan of an iteration
     bool fused = false, self_norm = false;
+    bool graphs = false;                        // MLHIP_GRAPH=1: an iteration's launches replayed from a captured HIP graph
     bool one_launch = false;                    // tiny fits: the fused kernel's last workgroup also reduces and closes (FusedTail)
     bool info_pinned = false;                   // full covariances: the closing kernel writes its info block into pinned host memory
     bool pack_pinned = false;                   // diagonal mode: its whole (small) pack lives there
@@ -112,6 +113,10 @@ struct EmLoop {
         // serial reduction + closing cost more than the two dispatch gaps they save), so it is opt-in.
         const char* one = std::getenv("MLHIP_ONE_LAUNCH");
         one_launch = fused && !ctx->reduce_fn && K <= mstats::kFusedTailMaxK && data->d <= mstats::kFusedTailMaxDim && one && one[0] == '1';
+        // MLHIP_GRAPH=1 (single rank, the one-kernel E+M forms, timers off): the three launches of an iteration captured once per
+        // ring slot and replayed -- see launch(). Opt-in: measured in DESIGN.md section 9.
+        const char* gr = std::getenv("MLHIP_GRAPH");
+        graphs = (fused || diag) && !one_launch && !ctx->reduce_fn && !ctx->timing && gr && gr[0] == '1';
         if (one_launch && !data->it_counter.p) {
             data->it_counter.reserve(256);
             HIP_CHECK(hipMemsetAsync(data->it_counter.p, 0, 256, ctx->stream));
@@ -133,6 +138,31 @@ struct EmLoop {
             launched = i + 1;
             return;
         }
+        mlhip_data::IterationGraph* cap = nullptr;
+        if (graphs) {
+            mlhip_data::IterationGraph& g = data->it_graph[in];
+            const void* key[5] = {rec[in]->p, rec[out]->p, pack_base(out), data->it_info_slot[out].p, data->xt.p};
+            const double scalars[3] = {(double)K * (diag ? -1.0 : 1.0), (double)data->n, refine_limit};
+            if (g.exec && std::equal(key, key + 5, g.key) && std::equal(scalars, scalars + 3, g.scalars)) {
+                HIP_CHECK(hipGraphLaunch(g.exec, ctx->stream));
+                data->n_ll = g.grid;                                  // (what the launchers leave behind on the host side)
+                data->have_estep = true;
+                data->lw_valid = false;
+                if (!diag) { data->stats_mode = kFromLogResp; data->stats_resp = data->lw.as<double>(); data->stats_ld = data->ldr; }
+                HIP_CHECK(hipEventRecord(data->it_event[out], ctx->stream));
+                launched = i + 1;
+                return;
+            }
+            g.release();
+            std::copy(key, key + 5, g.key);
+            std::copy(scalars, scalars + 3, g.scalars);
+            HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+            cap = &g;
+        }
+        struct CaptureGuard {                                        // a launcher that throws must not leave the stream capturing
+            hipStream_t stream; bool armed;
+            ~CaptureGuard() { if (armed) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(stream, &g); if (g) (void)hipGraphDestroy(g); } }
+        } guard{ctx->stream, cap != nullptr};
         if (diag) {
             run_diag_kernel(data, K, data->shift_dev.as<double>(), false, rec[in]);
         } else if (fused) {
@@ -156,6 +186,16 @@ struct EmLoop {
         if (!info_pinned && !pack_pinned)
             HIP_CHECK(hipMemcpyAsync(data->it_info_slot[out].p, data->it_pack[out].p, sizeof(double) * (diag ? n_pack : n_info),
                                      hipMemcpyDeviceToHost, ctx->stream));
+        if (cap) {
+            hipGraph_t graph = nullptr;
+            guard.armed = false;
+            HIP_CHECK(hipStreamEndCapture(ctx->stream, &graph));
+            const hipError_t e = hipGraphInstantiate(&cap->exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (e != hipSuccess) { cap->exec = nullptr; throw std::runtime_error("hipGraphInstantiate failed"); }
+            cap->grid = data->n_ll;
+            HIP_CHECK(hipGraphLaunch(cap->exec, ctx->stream));
+        }
         HIP_CHECK(hipEventRecord(data->it_event[out], ctx->stream));
         launched = i + 1;
     }

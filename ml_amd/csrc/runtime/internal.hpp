@@ -292,6 +292,15 @@ struct mlhip_data {
     DevBuf params_next, params_prev, it_pack[3], it_counter;   // it_counter: the workgroup ticket of the one-launch iteration
     PinnedBuf it_info_slot[3];
     hipEvent_t it_event[3] = {nullptr, nullptr, nullptr};
+    /// One iteration's launches (E+M kernel, reduction, closing, info copy) captured as a HIP graph per ring slot and replayed while
+    /// the buffers and the shape it was captured on are the ones in use (em_loop.cpp, MLHIP_GRAPH=1).
+    struct IterationGraph {
+        hipGraphExec_t exec = nullptr;
+        const void* key[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        double scalars[3] = {0, 0, 0};
+        int grid = 0;
+        void release() { if (exec) { (void)hipGraphExecDestroy(exec); exec = nullptr; } }
+    } it_graph[3];
     // source of the last statistics pass (for the per-component refinement pass)
     int stats_mode = 0;
     const double* stats_resp = nullptr;
@@ -314,6 +323,7 @@ struct mlhip_data {
             b->release();
         for (auto& sl : it_info_slot) sl.release();
         for (auto& e : it_event) if (e) (void)hipEventDestroy(e);
+        for (auto& g : it_graph) g.release();
         params_host.release(); stats_host.release(); km_host.release();
     }
 };

@@ -1,5 +1,5 @@
 """Whole-fit wall time of the reference's bm_EM.cpp-sized case (N=10k, d=4, K=3, KPP, 50 iterations) through ml_amd.cppyml: median of
-40 fits. MLHIP_LIBRARY selects another build of the library for A/B runs (e.g. a round-3 build); MLHIP_ONE_LAUNCH=0/1 the launch form."""
+40 fits. MLHIP_LIBRARY selects another build of the library for A/B runs (e.g. a round-3 build); MLHIP_ONE_LAUNCH=0/1 and MLHIP_GRAPH=0/1 the launch form."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -18,4 +18,4 @@ def fit():
 for _ in range(3):
     fit()
 ts = sorted(fit() for _ in range(40))
-print("%s ONE_LAUNCH=%s: median %.3f ms, min %.3f ms" % (os.environ.get("MLHIP_LIBRARY", "current")[-20:], os.environ.get("MLHIP_ONE_LAUNCH", "-"), ts[20] * 1e3, ts[0] * 1e3))
+print("%s ONE_LAUNCH=%s GRAPH=%s: median %.3f ms, min %.3f ms" % (os.environ.get("MLHIP_LIBRARY", "current")[-20:], os.environ.get("MLHIP_ONE_LAUNCH", "-"), os.environ.get("MLHIP_GRAPH", "-"), ts[20] * 1e3, ts[0] * 1e3))
