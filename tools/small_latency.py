@@ -19,6 +19,7 @@ for n, d, K in ((10_000, 4, 3), (100_000, 8, 8), (100_000, 16, 8), (20_000, 32, 
     for _ in range(200):
         ll, pi, mu, S = dt.em_step(pi, mu, S)
     out[f"N={n},d={d},K={K}"] = {"us_per_iteration": (time.perf_counter() - t0) / 200 * 1e6}
+    dt.em_iterate(pi, mu, S, 5)          # first call: ring / pinned buffers, events, the closing kernel's code object (0.5 - 15 ms)
     t0 = time.perf_counter()
     dt.em_iterate(pi, mu, S, 200)
     out[f"N={n},d={d},K={K}"]["us_per_iteration_em_iterate"] = (time.perf_counter() - t0) / 200 * 1e6
