@@ -99,6 +99,7 @@ void destroy_single_context(mlhip_ctx* ctx)
     ctx->small_dev.release();
     ctx->small_host.release();
     for (int b = 0; b < 2; ++b) { ctx->up_stage[b].release(); ctx->up_pin[b].release(); }
+    ctx->pool.drain();
     for (auto& p : ctx->pending) ctx->spare_events.push_back(p.second);
     for (auto& e : ctx->spare_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -61,6 +61,7 @@ mlhip_data* upload_common(mlhip_ctx* ctx, const double* x, bool on_device, uint3
     auto* dt = new mlhip_data;
     try {
         dt->ctx = ctx;
+        dt->attach_pool(&ctx->pool);
         dt->d = (int)d;
         dt->D = D;
         dt->n = (uint32_t)n;

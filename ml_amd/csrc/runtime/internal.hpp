@@ -58,33 +58,101 @@ template <class F> int guarded(F&& f)
     catch (const std::exception& e) { g_error = e.what(); return MLHIP_E_RUNTIME; }
 }
 
-/// Growable device buffer.
+/// Blocks a context's data handles have given back, kept for the next handle: a fit of the reference's benchmark size (N = 10k, d = 4,
+/// K = 3) spends 1.3 of its 2.6 ms in hipMalloc / hipHostMalloc / hipFree (some 25 device and 7 pinned blocks per handle; hipFree
+/// also synchronises the device). One pool per context = per stream: a block goes from one handle to the next in stream order, and
+/// a handle is only released behind a stream synchronisation (mlhip_data_free), so no work of the previous owner is pending on it.
+/// Blocks keep their exact allocation size and are handed out only for requests of at most that size and more than half of it
+/// (powers of two up to 1 MB, multiples of 1 MB above), up to a capped total; the rest goes back to the driver.
+/// MLHIP_POOL=0: every buffer straight from / to the driver.
+struct BufferPool {
+    static constexpr size_t kMaxBlock = size_t(64) << 20, kMaxDevice = size_t(512) << 20, kMaxPinned = size_t(64) << 20;
+    std::mutex m;                                   // (a group's worker thread allocates, its caller's thread releases)
+    std::vector<std::pair<size_t, void*>> dev, pin;
+    size_t dev_bytes = 0, pin_bytes = 0;
+    bool enabled = [] { const char* e = std::getenv("MLHIP_POOL"); return !(e && e[0] == '0'); }();
+
+    static size_t block_size(size_t b)
+    {
+        if (b <= 256) return 256;
+        if (b <= (size_t(1) << 20)) { size_t s = 256; while (s < b) s <<= 1; return s; }
+        return (b + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+    }
+    void* take(bool pinned, size_t cap)
+    {
+        std::lock_guard<std::mutex> lock(m);
+        auto& v = pinned ? pin : dev;
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i].first == cap) {
+                void* p = v[i].second;
+                v[i] = v.back(); v.pop_back();
+                (pinned ? pin_bytes : dev_bytes) -= cap;
+                return p;
+            }
+        return nullptr;
+    }
+    /// false: not kept (the caller frees it).
+    bool give(bool pinned, size_t cap, void* p)
+    {
+        if (!enabled || cap > kMaxBlock) return false;
+        std::lock_guard<std::mutex> lock(m);
+        size_t& total = pinned ? pin_bytes : dev_bytes;
+        if (total + cap > (pinned ? kMaxPinned : kMaxDevice)) return false;
+        (pinned ? pin : dev).emplace_back(cap, p);
+        total += cap;
+        return true;
+    }
+    void drain()
+    {
+        std::lock_guard<std::mutex> lock(m);
+        for (auto& b : dev) (void)hipFree(b.second);
+        for (auto& b : pin) (void)hipHostFree(b.second);
+        dev.clear(); pin.clear(); dev_bytes = pin_bytes = 0;
+    }
+};
+
+/// Growable device buffer. `bytes` is what was asked for (the largest request so far: sizes derived from it -- grids, capacities --
+/// do not depend on which block the pool handed out), `cap` the block behind it.
 struct DevBuf {
     void* p = nullptr;
-    size_t bytes = 0;
+    size_t bytes = 0, cap = 0;
+    BufferPool* pool = nullptr;
     void reserve(size_t b)
     {
         if (b <= bytes) return;
-        if (p) HIP_CHECK(hipFree(p));
-        p = nullptr; bytes = 0;
-        HIP_CHECK(hipMalloc(&p, b));
-        bytes = b;
+        if (b <= cap) { bytes = b; return; }
+        release();
+        const size_t want = pool && pool->enabled ? BufferPool::block_size(b) : b;
+        if (pool && pool->enabled) p = pool->take(false, want);
+        if (!p) HIP_CHECK(hipMalloc(&p, want));
+        bytes = b; cap = want;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    void release()
+    {
+        if (p && !(pool && pool->give(false, cap, p))) (void)hipFree(p);
+        p = nullptr; bytes = 0; cap = 0;
+    }
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 struct PinnedBuf {
     void* p = nullptr;
-    size_t bytes = 0;
+    size_t bytes = 0, cap = 0;
+    BufferPool* pool = nullptr;
     void reserve(size_t b)
     {
         if (b <= bytes) return;
-        if (p) HIP_CHECK(hipHostFree(p));
-        p = nullptr; bytes = 0;
-        HIP_CHECK(hipHostMalloc(&p, b, hipHostMallocDefault));
-        bytes = b;
+        if (b <= cap) { bytes = b; return; }
+        release();
+        const size_t want = pool && pool->enabled ? BufferPool::block_size(b) : b;
+        if (pool && pool->enabled) p = pool->take(true, want);
+        if (!p) HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+        bytes = b; cap = want;
     }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
+    void release()
+    {
+        if (p && !(pool && pool->give(true, cap, p))) (void)hipHostFree(p);
+        p = nullptr; bytes = 0; cap = 0;
+    }
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
@@ -163,6 +231,7 @@ struct mlhip_ctx {
     void* reduce_user = nullptr;
     int reduce_on_device = 0, world_size = 1, rank = 0;
     ncclComm_t comm = nullptr;   // library-owned RCCL communicator (mlhip_ctx_init_rccl); its all-reduce is the hook then
+    BufferPool pool;         // blocks of released data handles, for the next one
     // scratch
     DevBuf small_dev;        // for all-reducing short host vectors through a device hook
     PinnedBuf small_host;
@@ -313,6 +382,16 @@ struct mlhip_data {
     DevBuf kpp_w, kpp_scr;               // mlhip_kpp_draw: the running-minimum weights, block sums / offsets / result
     int km_cur = 0;
     bool km_have_old = false;
+
+    /// Every buffer of the handle draws from / returns to the context's pool.
+    void attach_pool(BufferPool* pool)
+    {
+        for (DevBuf* b : {&xt, &shift_dev, &lw, &lse, &esum, &ll_partials, &params_dev, &partials, &stats_dev, &resp_dev,
+                          &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_cent_next, &km_partials, &km_out, &km_mind, &km_probe, &km_scale, &km_cnorm, &km_xt_pad, &kpp_w, &kpp_scr,
+                          &refine_shift, &refine_stats, &params_next, &params_prev, &it_pack[0], &it_pack[1], &it_pack[2], &it_counter})
+            b->pool = pool;
+        for (PinnedBuf* b : {&params_host, &stats_host, &km_host, &it_info_slot[0], &it_info_slot[1], &it_info_slot[2]}) b->pool = pool;
+    }
 
     ~mlhip_data()
     {
