@@ -17,7 +17,8 @@ sufficient statistics per iteration: ncclAllReduce on the library's own RCCL com
 RCCL unique id, the barriers around the timed region and the max-over-ranks of the elapsed time.
 
 Prints ONE JSON line on rank 0. At N=1 the line also carries `secondary`, a list: K-means (BASELINE.json configs[4]) at one
-GPU's share of that job, N=12.5M, d=8, K=256, and the diagonal-covariance GMM of configs[1] (N=1M, d=16, K=16), each with its
+GPU's share of that job, N=12.5M, d=8, K=256, the diagonal-covariance GMM of configs[1] (N=1M, d=16, K=16) and the reference's own
+benchmark case configs[0] (bm_EM.cpp: N=10k, d=4, K=3 -- latency-bound: three dependent launches per iteration), each with its
 own roofline and cpu_baseline. Every line carries `allreduce_ms` (average device time of the statistics all-reduce, max over
 ranks; 0 on one GPU) and the spread of the ranks' own time per step (`ms_per_step_min` / `_max`).
 
@@ -614,10 +615,14 @@ def main():
             # the headline's step counts, as for the 0.09 ms iterations of the diagonal configuration below)
             sec = kmeans_measure(job, 12_500_000, 8, 256, 5 * args.steps, 10 * args.warmup, with_cpu, args.cpu_samples)
             diag = em_measure(job, 1_000_000, 16, 16, 10 * args.steps, 10 * args.warmup, with_cpu, args.cpu_samples, diagonal=True)
-            if out is not None and sec is not None and diag is not None:
+            # [2] BASELINE.json configs[0], the reference's own benchmark case (Benchmarks/bm_EM.cpp: N=10k, d=4, K=3): an iteration is
+            #     ~18 us -- three dependent launches -- so it gets a hundred times the steps.
+            small = em_measure(job, 10_000, 4, 3, 100 * args.steps, 100 * args.warmup, with_cpu, args.cpu_samples)
+            if out is not None and sec is not None and diag is not None and small is not None:
                 sec["config"]["workload"] += " = one GPU's row shard of BASELINE.json configs[4] (N=100M on 8 GPUs)"
                 diag["config"]["workload"] += " = BASELINE.json configs[1]"
-                out["secondary"] = [sec, diag]
+                small["config"]["workload"] += " = BASELINE.json configs[0] (bm_EM.cpp)"
+                out["secondary"] = [sec, diag, small]
         elif args.gpus > 1 and default_shape and not args.no_secondary:
             # multi-GPU runs: BASELINE.json configs[4] at 12.5M rows per GPU in the same driver-timed run -- N = 100M at 8 GPUs is
             # the configuration itself (weak scaling over the driver's 1 / 2 / 4 / 8 series: per-GPU work is fixed)

@@ -161,7 +161,7 @@ void collect_stats(mlhip_data* dt, int K, size_t count)
 }
 
 
-/// One EM iteration's device work in a single kernel where the shape allows (d <= 6, K <= 32 or d <= 4, K <= 64: em_fused_small.hip): no
+/// One EM iteration's device work in a single kernel where the shape allows (d <= 8, K <= 32 or d <= 4, K <= 64: em_fused_small.hip): no
 /// N x K block in HBM. MLHIP_FUSED=0 keeps the two-kernel path. Returns false when the shape is not covered.
 bool fused_step_applies(const mlhip_data* dt, int K)
 {
