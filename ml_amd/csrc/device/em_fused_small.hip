@@ -522,14 +522,15 @@ template <int D> int launch_valu(const FusedArgs& a, int num_cus, hipStream_t st
 /// K F <= 64 accumulators -- at every sample count (d = 2, K = 3: 15.0 against 17.7 us per iteration at N = 16 384, 52 against
 /// 104 us at N = 4 194 304; never slower); up to valu_max_k (K F ~ 100: one or two waves per SIMD, a longer epilogue) from 2^20
 /// samples on, where it still wins by 6 - 36 % (below that the matrix-core form is up to 4 us faster).
-/// MLHIP_FUSED_VALU=0: the matrix-core form instead (A/B runs; read per call).
+/// MLHIP_FUSED_VALU=0: the matrix-core form instead; =2: the vector-unit form at every N for all shapes it is built for (A/B runs,
+/// tests; read per call).
 bool valu_form_applies(const FusedArgs& a)
 {
     const char* e = std::getenv("MLHIP_FUSED_VALU");
     if (e && e[0] == '0') return false;
     const int D = padded_dim(a.d);
     if (D != a.d || D > 6 || a.K > valu_max_k(D)) return false;
-    return a.K * stats_count(a.d) <= 64 || a.n >= (1u << 20);
+    return a.K * stats_count(a.d) <= 64 || a.n >= (1u << 20) || (e && e[0] == '2');     // (2: every shape it is built for -- tests)
 }
 
 template <bool TAIL> int launch_fused(const FusedArgs& a, const FusedTail& t, int num_cus, hipStream_t stream)
