@@ -12,8 +12,30 @@
 namespace mlhip {
 namespace host {
 
+/// L L^T = A, lower triangle, column-major. Every entry is  (A(i,j) - sum_{l<j} L(i,l) L(j,l)) / L(jj)  with the sum collected in
+/// ascending l, one product and one subtraction at a time. Large d: RIGHT-LOOKING -- as soon as column l is final its products are
+/// subtracted from every later column, contiguous in i (the left-looking loop walks L with stride d: 100 ms per component at
+/// d = 512); each entry still receives its terms in ascending l, so the two forms give the same bits.
 void cholesky_lower(int d, const double* A, double* L)
 {
+    if (d >= 48) {
+        for (int j = 0; j < d; ++j) {
+            for (int i = 0; i < j; ++i) L[j * d + i] = 0.0;
+            for (int i = j; i < d; ++i) L[j * d + i] = A[j * d + i];
+        }
+        for (int l = 0; l < d; ++l) {
+            double* cl = L + (size_t)l * d;
+            const double lll = std::sqrt(cl[l]);
+            cl[l] = lll;
+            for (int i = l + 1; i < d; ++i) cl[i] = cl[i] / lll;
+            for (int j = l + 1; j < d; ++j) {
+                double* cj = L + (size_t)j * d;
+                const double ljl = cl[j];
+                for (int i = j; i < d; ++i) cj[i] -= cl[i] * ljl;
+            }
+        }
+        return;
+    }
     for (int i = 0; i < d * d; ++i) L[i] = 0.0;
     for (int j = 0; j < d; ++j) {
         double s = A[j * d + j];
@@ -86,6 +108,21 @@ int host_threads()
 double whitening_matrix(int d, const double* cov, std::vector<double>& L, std::vector<double>& W)
 {
     cholesky_lower(d, cov, L.data());
+    if (d >= 48) {
+        // column c of W = L^-1 by forward substitution, right-looking: w_l is final once the terms of all l' < l are in, and its
+        // product goes to every later entry at once, contiguous in i; the terms of an entry still arrive in ascending l (same bits
+        // as the loop below, which walks L with stride d)
+        for (int c = 0; c < d; ++c) {
+            double* w = W.data() + (size_t)c * d;
+            for (int i = 0; i < d; ++i) w[i] = (i == c) ? 1.0 : 0.0;
+            for (int l = c; l < d; ++l) {
+                const double* cl = L.data() + (size_t)l * d;
+                const double wl = w[l] / cl[l];
+                w[l] = wl;
+                for (int i = l + 1; i < d; ++i) w[i] -= cl[i] * wl;
+            }
+        }
+    } else {
     for (int c = 0; c < d; ++c) {
         for (int i = 0; i < d; ++i) {
             if (i < c) { W[c * d + i] = 0.0; continue; }
@@ -93,6 +130,7 @@ double whitening_matrix(int d, const double* cov, std::vector<double>& L, std::v
             for (int l = c; l < i; ++l) t -= L[l * d + i] * W[c * d + l];
             W[c * d + i] = t / L[i * d + i];
         }
+    }
     }
     double log_det_half = 0.0;
     for (int j = 0; j < d; ++j) log_det_half += std::log(L[j * d + j]);

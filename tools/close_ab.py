@@ -4,7 +4,7 @@ writes every output to an .npz; run once per build (MLHIP_LIBRARY=...) and compa
 import sys
 import numpy as np
 
-SHAPES = [(1, 3), (2, 3), (3, 5), (4, 16), (6, 7), (8, 32), (11, 5), (12, 9), (16, 16), (20, 6), (24, 5), (28, 3), (32, 64), (32, 4), (40, 3), (64, 4)]
+SHAPES = [(1, 3), (2, 3), (3, 5), (4, 16), (6, 7), (8, 32), (11, 5), (12, 9), (16, 16), (20, 6), (24, 5), (28, 3), (32, 64), (32, 4), (40, 3), (48, 3), (64, 4), (96, 3), (130, 2), (200, 2)]
 
 
 def main():
@@ -28,6 +28,8 @@ def main():
         got = dt.em_iterate(np.full(K, 1.0 / K), mu0, np.stack([cov] * K), 6, atol=0.0)
         for i, v in enumerate(got):
             out["d%d_K%d_%d" % (d, K, i)] = np.asarray(v)
+        for i, v in enumerate(dt.em_step(np.full(K, 1.0 / K), mu0, np.stack([cov] * K))):      # (closing on the host at every d)
+            out["d%d_K%d_step%d" % (d, K, i)] = np.asarray(v)
         dt.close()
     np.savez(sys.argv[1], **out)
     ctx.close()
