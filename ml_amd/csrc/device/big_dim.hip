@@ -1,0 +1,267 @@
+// 128 < d <= 512 on the matrix cores. The tuned kernels of this library keep a sample's coordinates in registers and stop at
+// d = 128; the plain tier behind them (generic_dim.hip: one lane per sample, O(d^2) loads per (sample, component), no matrix
+// instructions) runs at 0.2 - 0.8 TFLOP/s. The reference has no limit on d (ML/EM.cpp:96-101), and at these dimensions both passes
+// of an EM iteration are plain matrix products:
+//   * E-step (EM::expectation_step, ML/EM.cpp:190-219): per component Y = W (X - mu) with W = L^-1 lower triangular, q_i = |y_i|^2.
+//     One wave per 16 samples: the centred tile Z (d x 16) sits in LDS, W streams through as the A operand of v_mfma_f64_16x16x4
+//     row block by row block (16 rows x the columns up to the diagonal), the squares of the 16 x 16 output block are folded into
+//     q on the spot -- Y never exists. Same whitening form as every other E-step here: no cancellation.
+//   * statistics (EM::maximisation_step, ML/EM.cpp:229-248): S_k = sum_i r_ik x~_i x~_i^T, x~ = [x - shift ; 1], lower triangle.
+//     A workgroup owns one 64 x 64 tile of one component's S over one range of samples: panels of 32 samples of the 64 + 64 rows
+//     go through LDS (the A panel scaled by r), four waves hold 2 x 2 output blocks each. The sample ranges of a tile are
+//     separate partial blocks in the packed [K][F] layout, combined in fixed order by em_reduce_kernel like every other kernel's.
+// Records, statistics layout and everything around the two kernels (closing arithmetic, reductions, labels) are the plain tier's.
+// MLHIP_BIG_DIM=0: the plain tier instead (A/B runs, tests).
+#include <cstdlib>
+
+#include "device.hpp"
+#include "em_mstats_common.hpp"
+#include "exp_nonpos.hpp"
+
+namespace mlhip {
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBigMaxDim = 512;
+
+/// Lanes l, l ^ 16, l ^ 32, l ^ 48 hold the partial sums of one sample: all four get the total (fixed order).
+__device__ __forceinline__ double quad_total(double v)
+{
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+    const unsigned lo2 = __double2loint(v), hi2 = __double2hiint(v);
+    l = __builtin_amdgcn_permlane32_swap(lo2, lo2, false, false);
+    h = __builtin_amdgcn_permlane32_swap(hi2, hi2, false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+
+/// Records: estep_param_stride(D) doubles per component, [ mean(D) | W packed lower triangle, row by row | coef ] (layout.hpp).
+/// A workgroup of four waves per 16 samples: ONE centred tile Z[D][16] in LDS serves all four, which share the row blocks of W
+/// (block rb needs rb + 1 column groups: dealt out in a snake, rounds of four, so that every wave gets the same number of
+/// products); the four partial sums of |y|^2 meet in LDS in wave order. (One wave per tile keeps a CU at four waves -- the tile
+/// is 32 KB at d = 256 -- and every product waits for its own gather of W: 7.7 ms at N = 100k, d = 256, K = 8 against 2.1 here.)
+__global__ __launch_bounds__(256) void em_estep_big_kernel(const double* __restrict__ xt, size_t ldx, uint32_t n, uint32_t n_pad, int D,
+                                                            const double* __restrict__ params, int K, double* __restrict__ lw_out,
+                                                            size_t ldr, double* __restrict__ lse_out, double* __restrict__ ll_partials)
+{
+    extern __shared__ __attribute__((aligned(16))) double zt[];       // [D][16], then the partial sums qs[4][16]
+    double* qs = zt + (size_t)D * 16;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t PS = (size_t)D + (size_t)D * (D + 1) / 2 + 1;
+    const int RB = (D + 15) / 16;
+    double ll_acc = 0.0;
+    const uint32_t n_blocks = n_pad / 16;
+    for (uint32_t sb = blockIdx.x; sb < n_blocks; sb += gridDim.x) {
+        const uint32_t i0 = sb * 16;
+        double m = -__builtin_inf(), s = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const double* __restrict__ p = params + (size_t)k * PS;
+            const double* __restrict__ w = p + D;
+            __syncthreads();                                           // the previous component's reads of the tile and of qs are done
+            for (int l = tid >> 4; l < D; l += 16) zt[l * 16 + j] = xt[(size_t)l * ldx + i0 + j] - p[l];
+            __syncthreads();
+            double q = 0.0;
+            for (int round = 0; round * 4 < RB; ++round) {
+                const int rb = round * 4 + ((round & 1) ? 3 - wave : wave);
+                if (rb >= RB) continue;                                // (wave-uniform)
+                const int row = rb * 16 + j;                           // (the A operand's row index is the lane's low four bits too)
+                const bool row_ok = row < D;
+                const double* __restrict__ wr = w + (size_t)row * (row + 1) / 2;
+                const int l_end = (rb * 16 + 16 < D ? rb * 16 + 16 : D);   // columns 0 .. l_end - 1 (a multiple of 4)
+                d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+                int l0 = 0;
+                for (; l0 + 16 <= l_end; l0 += 16) {                    // four gathers of W in flight
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int c = l0 + 4 * u + kq;
+                        av[u] = (row_ok && c <= row) ? wr[c] : 0.0;
+                        bv[u] = zt[c * 16 + j];
+                    }
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc1, 0, 0, 0);
+                }
+                for (; l0 < l_end; l0 += 4) {
+                    const int c0 = l0 + kq;
+                    const double a0 = (row_ok && c0 <= row) ? wr[c0] : 0.0;
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, zt[c0 * 16 + j], acc0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const double y = acc0[g] + acc1[g];                // rows kq + 4 g of the block, sample j
+                    q = __builtin_fma(y, y, q);
+                }
+            }
+            q = quad_total(q);
+            if (kq == 0) qs[wave * 16 + j] = q;
+            __syncthreads();
+            if (wave == 0) {
+                const double qt = ((qs[j] + qs[16 + j]) + qs[32 + j]) + qs[48 + j];
+                const double lw = __builtin_fma(-0.5, qt, p[PS - 1]);
+                if (kq == 0) lw_out[(size_t)k * ldr + i0 + j] = lw;
+                const double e = exp_nonpos(lw == -HUGE_VAL ? -HUGE_VAL : -fabs(lw - m));   // online log-sum-exp (em_estep.hip)
+                const bool up = lw > m;
+                s = up ? __builtin_fma(s, e, 1.0) : s + e;
+                m = up ? lw : m;
+            }
+        }
+        if (wave == 0) {
+            const double lse = m + log(s);
+            if (kq == 0) {
+                lse_out[i0 + j] = lse;
+                if (i0 + j < n) ll_acc += lse;
+            }
+        }
+    }
+    // lanes 0 .. 15 of wave 0 carry the sums of their sample column; fixed-order tree over them
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) ll_acc += __shfl_down(ll_acc, off, 64);
+    if (tid == 0) ll_partials[blockIdx.x] = ll_acc;
+}
+
+// ---- statistics ----------------------------------------------------------------------------------------------------------
+constexpr int MT = 64;        // macro tile: 64 x 64 entries of S_k
+constexpr int SC = 32;        // samples per panel
+constexpr int XS = 34;        // LDS row stride of a panel (== 2 mod 32: the 16 rows x 2 sample columns of a half wave hit 32 banks)
+
+/// grid: (macro tile pair t, component k, sample range s). Tile pair t = (ta, tb), tb <= ta, row-major over the lower triangle.
+__global__ __launch_bounds__(256) void em_mstats_big_kernel(const double* __restrict__ xt, size_t ldx, uint32_t n, int d,
+                                                             const double* __restrict__ shift, const double* __restrict__ lw,
+                                                             size_t ldr, const double* __restrict__ lse, int mode,
+                                                             double* __restrict__ partials, int K, int F, uint32_t chunks_per_split)
+{
+    __shared__ double pa[MT * XS], pb[MT * XS];
+    __shared__ double rr[SC];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int ta = 0;
+    while ((ta + 1) * (ta + 2) / 2 <= (int)blockIdx.x) ++ta;
+    const int tb = (int)blockIdx.x - ta * (ta + 1) / 2;
+    const int k = blockIdx.y;
+    const int a_base = ta * MT, b_base = tb * MT;
+    const int wa = wave >> 1, wb = wave & 1;                            // the wave's 32 x 32 quarter of the macro tile
+    const bool idle = ta == tb && wa < wb;                              // above the diagonal: not needed
+    d4 acc[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
+    const double* __restrict__ wk = lw + (size_t)k * ldr;
+    const uint32_t n_chunks = (n + SC - 1) / SC;
+    const uint32_t c_begin = blockIdx.z * chunks_per_split;
+    uint32_t c_end = c_begin + chunks_per_split;
+    if (c_end > n_chunks) c_end = n_chunks;
+    const int i_r = lane & 15, kq = lane >> 4;
+    for (uint32_t c = c_begin; c < c_end; ++c) {
+        const uint32_t i0 = c * SC;
+        __syncthreads();                                               // the previous panel has been consumed
+        if (tid < SC) {
+            const uint32_t i = i0 + tid;
+            rr[tid] = i < n ? (mode == kFromResp ? wk[i] : exp_nonpos(wk[i] - lse[i])) : 0.0;
+        }
+        __syncthreads();
+        // panels: 64 rows x 32 samples each; thread -> (row = e / 32, sample = e % 32): 256-byte runs along a row of X.
+        // (Issuing the loads of panel c + 1 before the products of panel c -- 16 more registers per thread -- is slower:
+        // 5.8 against 4.4 ms at N = 100k, d = 256, K = 8; four resident workgroups per CU already cover the loads.)
+        for (int e = tid; e < MT * SC; e += 256) {
+            const int r = e / SC, sidx = e - r * SC;
+            const uint32_t i = i0 + sidx;                                // < n_pad (the allocation is padded to the tile)
+            const int a = a_base + r, b = b_base + r;
+            const double xa = a < d ? xt[(size_t)a * ldx + i] - shift[a] : (a == d ? 1.0 : 0.0);
+            const double xb = b < d ? xt[(size_t)b * ldx + i] - shift[b] : (b == d ? 1.0 : 0.0);
+            pa[r * XS + sidx] = xa * rr[sidx];
+            pb[r * XS + sidx] = xb;
+        }
+        __syncthreads();
+        if (!idle) {
+#pragma unroll
+            for (int ks = 0; ks < SC / 4; ++ks) {
+                double av[2], bv[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) av[u] = pa[(wa * 32 + u * 16 + i_r) * XS + ks * 4 + kq];
+#pragma unroll
+                for (int v = 0; v < 2; ++v) bv[v] = pb[(wb * 32 + v * 16 + i_r) * XS + ks * 4 + kq];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[v], acc[u][v], 0, 0, 0);
+            }
+        }
+    }
+    if (idle) return;
+    double* __restrict__ out = partials + ((size_t)blockIdx.z * K + k) * F;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int a = a_base + wa * 32 + u * 16 + kq + 4 * g;   // output row: kq + 4 g of the block; column: lane & 15
+                const int b = b_base + wb * 32 + v * 16 + i_r;
+                if (a <= d && b <= a) out[(size_t)a * (a + 1) / 2 + b] = acc[u][v][g];
+            }
+}
+
+bool big_dim_enabled()
+{
+    const char* e = std::getenv("MLHIP_BIG_DIM");
+    return !(e && e[0] == '0');
+}
+
+}  // namespace
+
+bool big_dim_applies(int d) { return d > kMaxDim && d <= kBigMaxDim && big_dim_enabled(); }
+
+/// Sample ranges a statistics tile is cut into (= partial blocks written): enough workgroups to fill the chip, at most 16.
+int big_dim_splits(int d, int K, int num_cus)
+{
+    const int T = (d + 1 + MT - 1) / MT;
+    const int pairs = T * (T + 1) / 2;
+    int s = (3 * num_cus + pairs * K - 1) / (pairs * K);
+    return s < 1 ? 1 : (s > 16 ? 16 : s);
+}
+
+int launch_em_estep_big(const EstepArgs& a, int num_cus, hipStream_t stream)
+{
+    const uint32_t n_pad = padded_samples(a.n);
+    const size_t smem = sizeof(double) * ((size_t)a.D * 16 + 64);     // <= 64.5 KB at D = 512
+    static bool raised = false;
+    if (smem > 64 * 1024 && !raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(em_estep_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return -1;
+        raised = true;
+    }
+    const int per_cu = (int)(size_t(160 * 1024) / (smem + 1024));
+    uint32_t grid = (uint32_t)num_cus * (uint32_t)(per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+    const uint32_t blocks = n_pad / 16;
+    if (grid > blocks) grid = blocks;
+    if (grid > (uint32_t)a.n_ll_partials) grid = (uint32_t)a.n_ll_partials;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(em_estep_big_kernel, dim3(grid), dim3(256), smem, stream, a.xt, a.ldx, a.n, n_pad, a.D, a.params, a.K, a.lw, a.ldr,
+                       a.lse, a.ll_partials);
+    return (int)grid;
+}
+
+/// Returns the number of partial blocks [K][F] written, or < 0.
+int launch_em_mstats_big(const MstatsArgs& a, int num_cus, hipStream_t stream)
+{
+    const int F = stats_count(a.d);
+    if (a.mode == kFromLogRespSelfNorm) return -3;
+    int splits = big_dim_splits(a.d, a.K, num_cus);
+    const uint32_t n_chunks = (a.n + SC - 1) / SC;
+    if ((uint32_t)splits > n_chunks) splits = (int)(n_chunks ? n_chunks : 1);
+    if ((size_t)splits * a.K * F > a.partials_capacity) splits = (int)(a.partials_capacity / ((size_t)a.K * F));
+    if (splits < 1) return -2;
+    const uint32_t per = (n_chunks + splits - 1) / splits;
+    const int T = (a.d + 1 + MT - 1) / MT;
+    hipLaunchKernelGGL(em_mstats_big_kernel, dim3(T * (T + 1) / 2, a.K, splits), dim3(256), 0, stream, a.xt, a.ldx, a.n, a.d, a.shift, a.lw,
+                       a.ldr, a.lse, a.mode, a.partials, a.K, F, per);
+    return splits;
+}
+
+}  // namespace mlhip

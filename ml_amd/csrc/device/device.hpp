@@ -88,6 +88,11 @@ struct MstatsArgs {
     double* lse_out; double* ll_out;                         // kFromLogRespSelfNorm: per-sample max (-> lse) and exp-sum (n_pad each)
 };
 int launch_em_mstats_generic(const MstatsArgs& a, hipStream_t stream);   // d > kMaxDim: writes ONE partial block [K][F]
+/// 128 < d <= 512 on the matrix cores (big_dim.hip); the plain tier above it and with MLHIP_BIG_DIM=0.
+bool big_dim_applies(int d);
+int big_dim_splits(int d, int K, int num_cus);
+int launch_em_estep_big(const EstepArgs& a, int num_cus, hipStream_t stream);
+int launch_em_mstats_big(const MstatsArgs& a, int num_cus, hipStream_t stream);   // writes big_dim_splits partial blocks [K][F]
 /// Whether the statistics kernel chosen for (d, K) can normalise log-responsibilities itself (mode kFromLogRespSelfNorm).
 bool em_mstats_self_norm_supported(int d, int K, int num_cus);
 /// Fused E-step + statistics for small shapes (em_fused_small.hip): params are the estep_param_stride(D) records.

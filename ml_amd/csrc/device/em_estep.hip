@@ -113,7 +113,17 @@ int launch_em_estep(const EstepArgs& a, hipStream_t stream)
     case 24: return launch_t<24>(a, stream);
     case 28: return launch_t<28>(a, stream);
     case 32: return launch_t<32>(a, stream);
-    default: return a.D > kMaxDim ? launch_em_estep_generic(a, stream) : -1;
+    default:
+        if (a.D <= kMaxDim) return -1;
+        if (big_dim_applies(a.D)) {
+            static const int cus = [] {
+                int dev = 0, n = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+                return n;
+            }();
+            return launch_em_estep_big(a, cus, stream);
+        }
+        return launch_em_estep_generic(a, stream);
     }
 }
 

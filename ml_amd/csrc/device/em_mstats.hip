@@ -129,7 +129,7 @@ Plan make_plan(int d, int K, int num_cus)
         p.n_rbg = p.n_cbg = 1;
         p.KP = K;
         p.FP = F;
-        p.grid_x = 1;
+        p.grid_x = big_dim_applies(d) ? big_dim_splits(d, K, num_cus) : 1;      // (big_dim.hip: one block per sample range)
         p.wg_per_cu = 1;
         return p;
     }
@@ -207,7 +207,7 @@ size_t em_mstats_scratch_doubles(int d, int K, int num_cus)
 
 int launch_em_mstats(const MstatsArgs& a, int num_cus, hipStream_t stream)
 {
-    if (a.d > kMaxDim) return launch_em_mstats_generic(a, stream);
+    if (a.d > kMaxDim) return big_dim_applies(a.d) ? launch_em_mstats_big(a, num_cus, stream) : launch_em_mstats_generic(a, stream);
     const Plan p = make_plan(a.d, a.K, num_cus);
     const uint32_t n_tiles = (a.n + TS - 1) / TS;
     int grid_x = p.grid_x;

@@ -13,9 +13,9 @@ namespace mlhip {
 namespace host {
 
 /// L L^T = A, lower triangle, column-major. Every entry is  (A(i,j) - sum_{l<j} L(i,l) L(j,l)) / L(jj)  with the sum collected in
-/// ascending l, one product and one subtraction at a time. Large d: RIGHT-LOOKING -- as soon as column l is final its products are
-/// subtracted from every later column, contiguous in i (the left-looking loop walks L with stride d: 100 ms per component at
-/// d = 512); each entry still receives its terms in ascending l, so the two forms give the same bits.
+/// ascending l, one product and one subtraction at a time. Large d: by column PANELS with contiguous inner loops (the left-looking
+/// loop walks L with stride d: 100 ms per component at d = 512); each entry still receives its terms in ascending l, so both forms
+/// give the same bits.
 void cholesky_lower(int d, const double* A, double* L)
 {
     if (d >= 48) {
@@ -23,15 +23,33 @@ void cholesky_lower(int d, const double* A, double* L)
             for (int i = 0; i < j; ++i) L[j * d + i] = 0.0;
             for (int i = j; i < d; ++i) L[j * d + i] = A[j * d + i];
         }
-        for (int l = 0; l < d; ++l) {
-            double* cl = L + (size_t)l * d;
-            const double lll = std::sqrt(cl[l]);
-            cl[l] = lll;
-            for (int i = l + 1; i < d; ++i) cl[i] = cl[i] / lll;
-            for (int j = l + 1; j < d; ++j) {
-                double* cj = L + (size_t)j * d;
-                const double ljl = cl[j];
-                for (int i = j; i < d; ++i) cj[i] -= cl[i] * ljl;
+        // Panels of NB columns: (1) the panel receives the terms of all earlier columns, l ascending, one IB-row tile of it at a time
+        // (the tile stays in L1 while the earlier columns stream by -- plain rank-1 updates of the whole trailing matrix move
+        // d^3 / 3 doubles through memory per factorization: 15 ms at d = 512); (2) the panel is factored, right-looking inside it.
+        constexpr int NB = 32, IB = 128;
+        for (int j0 = 0; j0 < d; j0 += NB) {
+            const int j1 = j0 + NB < d ? j0 + NB : d;
+            for (int i0 = j0; i0 < d; i0 += IB) {
+                const int i1 = i0 + IB < d ? i0 + IB : d;
+                for (int l = 0; l < j0; ++l) {
+                    const double* cl = L + (size_t)l * d;
+                    for (int j = j0; j < j1; ++j) {
+                        double* cj = L + (size_t)j * d;
+                        const double ljl = cl[j];
+                        for (int i = (i0 > j ? i0 : j); i < i1; ++i) cj[i] -= cl[i] * ljl;
+                    }
+                }
+            }
+            for (int l = j0; l < j1; ++l) {
+                double* cl = L + (size_t)l * d;
+                const double lll = std::sqrt(cl[l]);
+                cl[l] = lll;
+                for (int i = l + 1; i < d; ++i) cl[i] = cl[i] / lll;
+                for (int j = l + 1; j < j1; ++j) {
+                    double* cj = L + (size_t)j * d;
+                    const double ljl = cl[j];
+                    for (int i = j; i < d; ++i) cj[i] -= cl[i] * ljl;
+                }
             }
         }
         return;
@@ -112,14 +130,24 @@ double whitening_matrix(int d, const double* cov, std::vector<double>& L, std::v
         // column c of W = L^-1 by forward substitution, right-looking: w_l is final once the terms of all l' < l are in, and its
         // product goes to every later entry at once, contiguous in i; the terms of an entry still arrive in ascending l (same bits
         // as the loop below, which walks L with stride d)
-        for (int c = 0; c < d; ++c) {
-            double* w = W.data() + (size_t)c * d;
-            for (int i = 0; i < d; ++i) w[i] = (i == c) ? 1.0 : 0.0;
-            for (int l = c; l < d; ++l) {
+        // ... NB columns of W side by side, so that a column of L is read once for all of them (one column at a time reads the whole
+        // of L per column of W: d^3 / 2 doubles per inverse)
+        constexpr int NB = 32;
+        for (int c0 = 0; c0 < d; c0 += NB) {
+            const int c1 = c0 + NB < d ? c0 + NB : d;
+            for (int c = c0; c < c1; ++c) {
+                double* w = W.data() + (size_t)c * d;
+                for (int i = 0; i < d; ++i) w[i] = (i == c) ? 1.0 : 0.0;
+            }
+            for (int l = c0; l < d; ++l) {
                 const double* cl = L.data() + (size_t)l * d;
-                const double wl = w[l] / cl[l];
-                w[l] = wl;
-                for (int i = l + 1; i < d; ++i) w[i] -= cl[i] * wl;
+                const int c_last = l < c1 - 1 ? l : c1 - 1;             // columns c <= l of the block have an entry l
+                for (int c = c0; c <= c_last; ++c) {
+                    double* w = W.data() + (size_t)c * d;
+                    const double wl = w[l] / cl[l];
+                    w[l] = wl;
+                    for (int i = l + 1; i < d; ++i) w[i] -= cl[i] * wl;
+                }
             }
         }
     } else {
@@ -215,17 +243,23 @@ bool build_estep_params_mfma4(int d, int D, int K, const double* mixing, const d
 void build_estep_params(int d, int D, int K, const double* mixing, const double* means, const double* covariances,
                         double* records)
 {
-    const int PS = estep_param_stride(D);
+    const size_t PS = (size_t)D + (size_t)D * (D + 1) / 2 + 1;       // estep_param_stride(D)
+    // (this layout also serves d > 128, where a factorization is milliseconds: the K of them on the host's threads, like the
+    // builders above)
+#pragma omp parallel num_threads(host_threads()) if (worth_threads(K, d))
+    {
     std::vector<double> L((size_t)d * d), W((size_t)d * d);
+#pragma omp for schedule(static)
     for (int k = 0; k < K; ++k) {
         double* rec = records + (size_t)k * PS;
-        for (int i = 0; i < PS; ++i) rec[i] = 0.0;
+        for (size_t i = 0; i < PS; ++i) rec[i] = 0.0;
         for (int j = 0; j < d; ++j) rec[j] = means[(size_t)k * d + j];
         const double log_det_half = whitening_matrix(d, covariances + (size_t)k * d * d, L, W);
         double* w = rec + D;
-        for (int j = 0; j < d; ++j)
-            for (int l = 0; l <= j; ++l) w[j * (j + 1) / 2 + l] = W[l * d + j];
+        for (int l = 0; l < d; ++l)                                   // (column l of W is contiguous: read it once, scatter into the rows)
+            for (int j = l; j < d; ++j) w[(size_t)j * (j + 1) / 2 + l] = W[(size_t)l * d + j];
         rec[PS - 1] = std::log(mixing[k]) - log_det_half;
+    }
     }
 }
 

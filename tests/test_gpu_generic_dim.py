@@ -1,6 +1,7 @@
-"""Dimensions beyond 128 (ml_amd/csrc/device/generic_dim.hip): the reference has no dimension limit (ML/EM.cpp:96-101), so the
-library runs the same passes in a plain form there. One E + M iteration, labels, sample covariance, one K-means step, the step loops
-and a facade fit against the oracle at d = 129 … 333 (K not a multiple of 16, ragged N)."""
+"""Dimensions beyond 128: the reference has no dimension limit (ML/EM.cpp:96-101). Up to d = 512 the E-step and the statistics run
+on the matrix cores as plain matrix products (ml_amd/csrc/device/big_dim.hip), above that -- and with MLHIP_BIG_DIM=0 -- in a plain
+form (generic_dim.hip). One E + M iteration, labels, sample covariance, one K-means step, the step loops and a facade fit against
+the oracle at d = 129 … 600 (K not a multiple of 16, ragged N), both tiers."""
 import numpy as np
 import pytest
 
@@ -25,9 +26,15 @@ def _problem(d, K, n, seed):
     return X, pi0, mu0, S0
 
 
-@pytest.mark.parametrize("d,K,n", [(129, 3, 1500), (160, 5, 2100), (200, 2, 1111), (256, 4, 1800), (333, 2, 900)])
-def test_one_iteration_labels_covariance_and_kmeans_step_match_the_oracle(oracle, d, K, n):
+@pytest.mark.parametrize("tier", ["matrix-core", "plain"])
+@pytest.mark.parametrize("d,K,n", [(129, 3, 1500), (160, 5, 2100), (200, 2, 1111), (256, 4, 1800), (333, 2, 900), (191, 19, 4001),
+                                   (512, 3, 1300), (600, 2, 700)])
+def test_one_iteration_labels_covariance_and_kmeans_step_match_the_oracle(oracle, d, K, n, tier, monkeypatch):
     from ml_amd import _lib
+    if tier == "plain":
+        if d > 512:
+            pytest.skip("d > 512 is the plain tier either way")
+        monkeypatch.setenv("MLHIP_BIG_DIM", "0")
     X, pi0, mu0, S0 = _problem(d, K, n, 7 * d + K)
     ctx = _lib.Context()
     dt = _lib.Data(ctx, X)
