@@ -231,11 +231,9 @@ int launch_em_estep_big(const EstepArgs& a, int num_cus, hipStream_t stream)
 {
     const uint32_t n_pad = padded_samples(a.n);
     const size_t smem = sizeof(double) * ((size_t)a.D * 16 + 64);     // <= 64.5 KB at D = 512
-    static bool raised = false;
-    if (smem > 64 * 1024 && !raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(em_estep_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return -1;
-        raised = true;
-    }
+    if (smem > 64 * 1024 &&                                           // (per device: asked for on every such launch)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(em_estep_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+        return -1;
     const int per_cu = (int)(size_t(160 * 1024) / (smem + 1024));
     uint32_t grid = (uint32_t)num_cus * (uint32_t)(per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
     const uint32_t blocks = n_pad / 16;
