@@ -208,6 +208,91 @@ __global__ __launch_bounds__(256) void em_mstats_big_kernel(const double* __rest
             }
 }
 
+// ---- K-means assignment -----------------------------------------------------------------------------------------------
+/// KMeans::assignment_step / assign_label (ML/KMeans.cpp:153-178) for 128 < d <= 512: the reference's own arithmetic -- per
+/// (sample, cluster) the ascending-j chain s = fma(x_j - c_kj, x_j - c_kj, s), strict '<' over ascending k -- so labels and
+/// distances are bit for bit the plain tier's (and the oracle's). What changes is the traffic: the plain kernel re-reads a
+/// sample's d coordinates from memory for every cluster; here a lane holds the running sums of SIXTEEN clusters for TWO samples
+/// and walks the dimensions once per such block -- one coordinate load per 64 fused multiply-adds -- with the 16 centroid
+/// coordinates of a dimension arriving as ONE scalar load from a dimension-major copy of the table ([D][Kp], built per launch).
+constexpr int KB = 16;        // clusters per register block
+
+__global__ __launch_bounds__(256) void kmeans_transpose_kernel(const double* __restrict__ cent, int K, int Kp, int D, double* __restrict__ centT)
+{
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < D * Kp; e += gridDim.x * 256) {
+        const int j = e / Kp, k = e - j * Kp;
+        centT[e] = k < K ? cent[(size_t)k * D + j] : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void kmeans_assign_big_kernel(const double* __restrict__ xt, size_t ldx, uint32_t n, uint32_t n_pad, int D,
+                                                                 const double* __restrict__ centT, int Kp, int K,
+                                                                 uint32_t* __restrict__ labels, const uint32_t* __restrict__ old_labels,
+                                                                 int have_old, double* __restrict__ min_dist,
+                                                                 double* __restrict__ partials, size_t pstride)
+{
+    __shared__ double red[8];
+    double inertia = 0.0, changed = 0.0;
+    for (uint32_t base = blockIdx.x * 512u; base < n_pad; base += gridDim.x * 512u) {
+        const uint32_t i0 = base + threadIdx.x, i1 = i0 + 256u;          // samples of this lane (stored only below n)
+        const uint32_t l0 = i0 < n_pad ? i0 : n_pad - 1, l1 = i1 < n_pad ? i1 : n_pad - 1;   // ... read inside the allocation
+        double best0 = __builtin_inf(), best1 = __builtin_inf();
+        uint32_t arg0 = 0, arg1 = 0;
+        for (int kc = 0; kc < Kp; kc += KB) {
+            double s0[KB], s1[KB];
+#pragma unroll
+            for (int u = 0; u < KB; ++u) s0[u] = s1[u] = 0.0;
+            const double* __restrict__ ct = centT + kc;                   // wave-uniform: scalar loads
+#pragma unroll 2
+            for (int j = 0; j < D; ++j) {
+                const double x0 = xt[(size_t)j * ldx + l0], x1 = xt[(size_t)j * ldx + l1];
+                const double* __restrict__ cj = ct + (size_t)j * Kp;
+#pragma unroll
+                for (int u = 0; u < KB; ++u) {
+                    const double c = cj[u];
+                    const double t0 = x0 - c, t1 = x1 - c;
+                    s0[u] = __builtin_fma(t0, t0, s0[u]);
+                    s1[u] = __builtin_fma(t1, t1, s1[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < KB; ++u) {
+                if (kc + u < K) {                                         // (wave-uniform)
+                    if (s0[u] < best0) { best0 = s0[u]; arg0 = (uint32_t)(kc + u); }
+                    if (s1[u] < best1) { best1 = s1[u]; arg1 = (uint32_t)(kc + u); }
+                }
+            }
+        }
+        if (i0 < n) {
+            labels[i0] = arg0;
+            if (min_dist) min_dist[i0] = best0;
+            inertia += best0;
+            changed += (!have_old || old_labels[i0] != arg0) ? 1.0 : 0.0;
+        }
+        if (i1 < n) {
+            labels[i1] = arg1;
+            if (min_dist) min_dist[i1] = best1;
+            inertia += best1;
+            changed += (!have_old || old_labels[i1] != arg1) ? 1.0 : 0.0;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        inertia += __shfl_down(inertia, off, 64);
+        changed += __shfl_down(changed, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = inertia;
+        red[4 + (threadIdx.x >> 6)] = changed;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* my_part = partials + (size_t)blockIdx.x * pstride;
+        my_part[0] = ((red[0] + red[1]) + red[2]) + red[3];
+        my_part[1] = ((red[4] + red[5]) + red[6]) + red[7];
+    }
+}
+
 bool big_dim_enabled()
 {
     const char* e = std::getenv("MLHIP_BIG_DIM");
@@ -260,6 +345,24 @@ int launch_em_mstats_big(const MstatsArgs& a, int num_cus, hipStream_t stream)
     hipLaunchKernelGGL(em_mstats_big_kernel, dim3(T * (T + 1) / 2, a.K, splits), dim3(256), 0, stream, a.xt, a.ldx, a.n, a.d, a.shift, a.lw,
                        a.ldr, a.lse, a.mode, a.partials, a.K, F, per);
     return splits;
+}
+
+/// `grid_max` partial blocks of `pstride` doubles are available; the dimension-major copy of the table takes the last one (the
+/// caller falls back to the plain kernel when it does not fit: fewer than ~8 clusters). Returns the partial blocks used, or 0.
+int launch_kmeans_assign_big(const KmeansArgs& a, int grid_max, size_t pstride, hipStream_t stream)
+{
+    const int Kp = (a.K + KB - 1) / KB * KB;
+    if (grid_max < 2 || (size_t)Kp * a.D > pstride) return 0;
+    double* centT = a.partials + (size_t)(grid_max - 1) * pstride;
+    const uint32_t n_pad = padded_samples(a.n);
+    int grid = grid_max - 1;
+    const uint32_t need = (n_pad + 511) / 512;
+    if ((uint32_t)grid > need) grid = (int)(need ? need : 1);
+    int tb = (Kp * a.D + 255) / 256;
+    hipLaunchKernelGGL(kmeans_transpose_kernel, dim3(tb > 1024 ? 1024 : tb), dim3(256), 0, stream, a.centroids, a.K, Kp, a.D, centT);
+    hipLaunchKernelGGL(kmeans_assign_big_kernel, dim3(grid), dim3(256), 0, stream, a.xt, a.ldx, a.n, n_pad, a.D, centT, Kp, a.K, a.labels,
+                       a.old_labels, a.have_old, a.min_dist, a.partials, pstride);
+    return grid;
 }
 
 }  // namespace mlhip

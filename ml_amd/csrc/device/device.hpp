@@ -197,6 +197,8 @@ size_t kmeans_scratch_doubles(int d, int K, int num_cus);
 /// Assignment kernel; returns the number of per-workgroup partials (>0) or <0 on error.
 int launch_kmeans_assign(const KmeansArgs& a, int num_cus, hipStream_t stream);
 void launch_kmeans_assign_generic(const KmeansArgs& a, int grid, size_t pstride, hipStream_t stream);   // d > kMaxDim (generic_dim.hip)
+/// 128 < d <= 512 (big_dim.hip): the same exact arithmetic, register-blocked; returns the partial blocks used, 0: not applicable.
+int launch_kmeans_assign_big(const KmeansArgs& a, int grid_max, size_t pstride, hipStream_t stream);
 void launch_kmeans_reduce(const KmeansArgs& a, int n_partials, hipStream_t stream);
 /// update_step's closing arithmetic on the (all-reduced) output block [inertia, changed, counts(K), sums(K*d)]: the sums
 /// become the means IN PLACE (empty cluster -> origin, ML/KMeans.cpp:184) and are written as the next centroid table

@@ -143,3 +143,28 @@ def test_diagonal_mode_initialisers_and_seeded_kmeans_fit_at_d150(oracle):
         okm.fit(X)
         assert np.array_equal(np.array(km.labels), okm.labels)
         assert np.max(np.abs(km.centroids - okm.centroids)) <= 1e-13 * np.max(np.abs(okm.centroids))
+
+
+@pytest.mark.parametrize("d,K,n", [(130, 40, 3000), (256, 70, 5000), (300, 8, 2000), (512, 33, 1500), (200, 7, 4097), (136, 300, 9000)])
+def test_kmeans_iterations_agree_between_the_tiers_bit_for_bit(d, K, n, monkeypatch):
+    """K-means at 128 < d <= 512: the register-blocked assignment kernel (big_dim.hip) evaluates the reference's own fma chain, so
+    labels, distances, counts and centroids of a step loop equal the plain tier's (MLHIP_BIG_DIM=0) bit for bit -- also for
+    few clusters, where the dimension-major table does not fit its scratch and the plain kernel runs either way."""
+    from ml_amd import _lib
+    rng = np.random.default_rng(d + K + n)
+    C = 2.0 * rng.standard_normal((K, d))
+    X = np.ascontiguousarray(C[rng.integers(0, K, n)] + rng.standard_normal((n, d)))
+    C0 = C + 0.3 * rng.standard_normal((K, d))
+    ctx = _lib.Context()
+    dt = _lib.Data(ctx, X)
+    got = dt.kmeans_iterate(C0, 6, 0.0)
+    lg, dg = dt.kmeans_labels(), dt.kmeans_distances()
+    monkeypatch.setenv("MLHIP_BIG_DIM", "0")
+    ref = dt.kmeans_iterate(C0, 6, 0.0)
+    assert got[0] == ref[0] and got[1] == ref[1]
+    assert abs(got[2] - ref[2]) <= 1e-14 * ref[2]          # (the inertia: the same distances summed over differently shaped workgroups)
+    for a, b in zip(got[3:], ref[3:]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(lg, dt.kmeans_labels()) and np.array_equal(dg, dt.kmeans_distances())
+    dt.close()
+    ctx.close()
