@@ -1,4 +1,4 @@
-// 128 < d <= 512 on the matrix cores. The tuned kernels of this library keep a sample's coordinates in registers and stop at
+// 128 < d <= 1024 on the matrix cores. The tuned kernels of this library keep a sample's coordinates in registers and stop at
 // d = 128; the plain tier behind them (generic_dim.hip: one lane per sample, O(d^2) loads per (sample, component), no matrix
 // instructions) runs at 0.2 - 0.8 TFLOP/s. The reference has no limit on d (ML/EM.cpp:96-101), and at these dimensions both passes
 // of an EM iteration are plain matrix products:
@@ -23,7 +23,7 @@ namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-constexpr int kBigMaxDim = 512;
+constexpr int kBigMaxDim = 1024;      // (the E-step's centred tile: 128 KB of the CU's 160 KB of LDS)
 
 /// Lanes l, l ^ 16, l ^ 32, l ^ 48 hold the partial sums of one sample: all four get the total (fixed order).
 __device__ __forceinline__ double quad_total(double v)
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void em_mstats_big_kernel(const double* __rest
 }
 
 // ---- K-means assignment -----------------------------------------------------------------------------------------------
-/// KMeans::assignment_step / assign_label (ML/KMeans.cpp:153-178) for 128 < d <= 512: the reference's own arithmetic -- per
+/// KMeans::assignment_step / assign_label (ML/KMeans.cpp:153-178) for 128 < d <= 1024: the reference's own arithmetic -- per
 /// (sample, cluster) the ascending-j chain s = fma(x_j - c_kj, x_j - c_kj, s), strict '<' over ascending k -- so labels and
 /// distances are bit for bit the plain tier's (and the oracle's). What changes is the traffic: the plain kernel re-reads a
 /// sample's d coordinates from memory for every cluster; here a lane holds the running sums of SIXTEEN clusters for TWO samples
@@ -315,9 +315,9 @@ int big_dim_splits(int d, int K, int num_cus)
 int launch_em_estep_big(const EstepArgs& a, int num_cus, hipStream_t stream)
 {
     const uint32_t n_pad = padded_samples(a.n);
-    const size_t smem = sizeof(double) * ((size_t)a.D * 16 + 64);     // <= 64.5 KB at D = 512
+    const size_t smem = sizeof(double) * ((size_t)a.D * 16 + 64);     // 64.5 KB at D = 512, 128.5 KB at D = 1024
     if (smem > 64 * 1024 &&                                           // (per device: asked for on every such launch)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(em_estep_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(em_estep_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess)
         return -1;
     const int per_cu = (int)(size_t(160 * 1024) / (smem + 1024));
     uint32_t grid = (uint32_t)num_cus * (uint32_t)(per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));

@@ -88,7 +88,7 @@ struct MstatsArgs {
     double* lse_out; double* ll_out;                         // kFromLogRespSelfNorm: per-sample max (-> lse) and exp-sum (n_pad each)
 };
 int launch_em_mstats_generic(const MstatsArgs& a, hipStream_t stream);   // d > kMaxDim: writes ONE partial block [K][F]
-/// 128 < d <= 512 on the matrix cores (big_dim.hip); the plain tier above it and with MLHIP_BIG_DIM=0.
+/// 128 < d <= 1024 on the matrix cores (big_dim.hip); the plain tier above it and with MLHIP_BIG_DIM=0.
 bool big_dim_applies(int d);
 int big_dim_splits(int d, int K, int num_cus);
 int launch_em_estep_big(const EstepArgs& a, int num_cus, hipStream_t stream);
@@ -197,7 +197,7 @@ size_t kmeans_scratch_doubles(int d, int K, int num_cus);
 /// Assignment kernel; returns the number of per-workgroup partials (>0) or <0 on error.
 int launch_kmeans_assign(const KmeansArgs& a, int num_cus, hipStream_t stream);
 void launch_kmeans_assign_generic(const KmeansArgs& a, int grid, size_t pstride, hipStream_t stream);   // d > kMaxDim (generic_dim.hip)
-/// 128 < d <= 512 (big_dim.hip): the same exact arithmetic, register-blocked; returns the partial blocks used, 0: not applicable.
+/// 128 < d <= 1024 (big_dim.hip): the same exact arithmetic, register-blocked; returns the partial blocks used, 0: not applicable.
 int launch_kmeans_assign_big(const KmeansArgs& a, int grid_max, size_t pstride, hipStream_t stream);
 void launch_kmeans_reduce(const KmeansArgs& a, int n_partials, hipStream_t stream);
 /// update_step's closing arithmetic on the (all-reduced) output block [inertia, changed, counts(K), sums(K*d)]: the sums

@@ -1,7 +1,8 @@
-"""Dimensions beyond 128: the reference has no dimension limit (ML/EM.cpp:96-101). Up to d = 512 the E-step and the statistics run
+"""Dimensions beyond 128: the reference has no dimension limit (ML/EM.cpp:96-101). Up to d = 1024 the E-step and the statistics run
 on the matrix cores as plain matrix products (ml_amd/csrc/device/big_dim.hip), above that -- and with MLHIP_BIG_DIM=0 -- in a plain
 form (generic_dim.hip). One E + M iteration, labels, sample covariance, one K-means step, the step loops and a facade fit against
-the oracle at d = 129 … 600 (K not a multiple of 16, ragged N), both tiers."""
+the oracle at d = 129 … 600 (the reference's own E-step underflows around d = 1000: exp(-q / 2) with q ~ d; the library
+works in the log domain -- there the two tiers are held against each other) (K not a multiple of 16, ragged N), both tiers."""
 import numpy as np
 import pytest
 
@@ -32,8 +33,6 @@ def _problem(d, K, n, seed):
 def test_one_iteration_labels_covariance_and_kmeans_step_match_the_oracle(oracle, d, K, n, tier, monkeypatch):
     from ml_amd import _lib
     if tier == "plain":
-        if d > 512:
-            pytest.skip("d > 512 is the plain tier either way")
         monkeypatch.setenv("MLHIP_BIG_DIM", "0")
     X, pi0, mu0, S0 = _problem(d, K, n, 7 * d + K)
     ctx = _lib.Context()
@@ -145,9 +144,9 @@ def test_diagonal_mode_initialisers_and_seeded_kmeans_fit_at_d150(oracle):
         assert np.max(np.abs(km.centroids - okm.centroids)) <= 1e-13 * np.max(np.abs(okm.centroids))
 
 
-@pytest.mark.parametrize("d,K,n", [(130, 40, 3000), (256, 70, 5000), (300, 8, 2000), (512, 33, 1500), (200, 7, 4097), (136, 300, 9000)])
+@pytest.mark.parametrize("d,K,n", [(130, 40, 3000), (256, 70, 5000), (300, 8, 2000), (512, 33, 1500), (200, 7, 4097), (136, 300, 9000), (900, 20, 1200)])
 def test_kmeans_iterations_agree_between_the_tiers_bit_for_bit(d, K, n, monkeypatch):
-    """K-means at 128 < d <= 512: the register-blocked assignment kernel (big_dim.hip) evaluates the reference's own fma chain, so
+    """K-means at 128 < d <= 1024: the register-blocked assignment kernel (big_dim.hip) evaluates the reference's own fma chain, so
     labels, distances, counts and centroids of a step loop equal the plain tier's (MLHIP_BIG_DIM=0) bit for bit -- also for
     few clusters, where the dimension-major table does not fit its scratch and the plain kernel runs either way."""
     from ml_amd import _lib
@@ -166,5 +165,26 @@ def test_kmeans_iterations_agree_between_the_tiers_bit_for_bit(d, K, n, monkeypa
     for a, b in zip(got[3:], ref[3:]):
         assert np.array_equal(a, b)
     assert np.array_equal(lg, dt.kmeans_labels()) and np.array_equal(dg, dt.kmeans_distances())
+    dt.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("d,K,n", [(700, 3, 900), (1024, 2, 500), (1000, 5, 1500)])
+def test_matrix_core_tier_against_the_plain_tier_beyond_the_reference_range(d, K, n, monkeypatch):
+    """d ~ 1000: the reference's E-step (and with it the oracle's) underflows -- exp(-q / 2), q ~ d -- while the library's log-domain
+    passes do not; the matrix-core tier (d <= 1024) is held against the plain tier there: log-likelihood, responsibilities, labels,
+    one M-step."""
+    from ml_amd import _lib
+    X, pi0, mu0, S0 = _problem(d, K, n, 11 * d + K)
+    ctx = _lib.Context()
+    dt = _lib.Data(ctx, X)
+    got = dt.em_step(pi0, mu0, S0)
+    R, labels = dt.em_responsibilities(K), dt.em_labels(K)
+    monkeypatch.setenv("MLHIP_BIG_DIM", "0")
+    ref = dt.em_step(pi0, mu0, S0)
+    assert np.isfinite(ref[0]) and abs(got[0] - ref[0]) <= 1e-12 * abs(ref[0])
+    assert np.max(np.abs(R - dt.em_responsibilities(K))) < 1e-11 and np.array_equal(labels, dt.em_labels(K))
+    for a, b, tol in zip(got[1:], ref[1:], (1e-11, 1e-11, 1e-9)):
+        assert relerr(a, b) < tol
     dt.close()
     ctx.close()
