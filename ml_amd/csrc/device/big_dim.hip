@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void em_mstats_big_kernel(const double* __rest
 // ---- K-means assignment -----------------------------------------------------------------------------------------------
 /// KMeans::assignment_step / assign_label (ML/KMeans.cpp:153-178) for 128 < d <= 1024: the reference's own arithmetic -- per
 /// (sample, cluster) the ascending-j chain s = fma(x_j - c_kj, x_j - c_kj, s), strict '<' over ascending k -- so labels and
-/// distances are bit for bit the plain tier's (and the oracle's). What changes is the traffic: the plain kernel re-reads a
+/// distances are bit for bit the plain tier's. What changes is the traffic: the plain kernel re-reads a
 /// sample's d coordinates from memory for every cluster; here a lane holds the running sums of SIXTEEN clusters for TWO samples
 /// and walks the dimensions once per such block -- one coordinate load per 64 fused multiply-adds -- with the 16 centroid
 /// coordinates of a dimension arriving as ONE scalar load from a dimension-major copy of the table ([D][Kp], built per launch).
