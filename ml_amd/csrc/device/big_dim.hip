@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void em_mstats_big_kernel(const double* __rest
 }
 
 // ---- K-means assignment -----------------------------------------------------------------------------------------------
-/// KMeans::assignment_step / assign_label (ML/KMeans.cpp:153-178) for 128 < d <= 1024: the reference's own arithmetic -- per
+/// KMeans::assignment_step / assign_label (ML/KMeans.cpp:153-178) for d > 128: the reference's own arithmetic -- per
 /// (sample, cluster) the ascending-j chain s = fma(x_j - c_kj, x_j - c_kj, s), strict '<' over ascending k -- so labels and
 /// distances are bit for bit the plain tier's. What changes is the traffic: the plain kernel re-reads a
 /// sample's d coordinates from memory for every cluster; here a lane holds the running sums of SIXTEEN clusters for TWO samples
@@ -302,6 +302,8 @@ bool big_dim_enabled()
 }  // namespace
 
 bool big_dim_applies(int d) { return d > kMaxDim && d <= kBigMaxDim && big_dim_enabled(); }
+/// The K-means assignment kernel of this file has no upper limit on d (no tile in LDS).
+bool big_dim_kmeans_applies(int d) { return d > kMaxDim && big_dim_enabled(); }
 
 /// Sample ranges a statistics tile is cut into (= partial blocks written): enough workgroups to fill the chip, at most 16.
 int big_dim_splits(int d, int K, int num_cus)

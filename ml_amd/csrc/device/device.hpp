@@ -90,6 +90,7 @@ struct MstatsArgs {
 int launch_em_mstats_generic(const MstatsArgs& a, hipStream_t stream);   // d > kMaxDim: writes ONE partial block [K][F]
 /// 128 < d <= 1024 on the matrix cores (big_dim.hip); the plain tier above it and with MLHIP_BIG_DIM=0.
 bool big_dim_applies(int d);
+bool big_dim_kmeans_applies(int d);                                       // (its K-means kernel: any d > 128)
 int big_dim_splits(int d, int K, int num_cus);
 int launch_em_estep_big(const EstepArgs& a, int num_cus, hipStream_t stream);
 int launch_em_mstats_big(const MstatsArgs& a, int num_cus, hipStream_t stream);   // writes big_dim_splits partial blocks [K][F]

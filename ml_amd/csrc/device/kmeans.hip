@@ -291,8 +291,8 @@ int launch_kmeans_assign(const KmeansArgs& a_in, int num_cus, hipStream_t stream
     if ((!force_valu || a_in.D > kMidDim) && kmeans_mfma_supported(a_in.D, a_in.K)) return launch_kmeans_mfma(a_in, num_cus, stream);
     const size_t pstride = 2 + (size_t)a_in.K * (3 * a_in.d + 1);
     if (a_in.D > kMaxDim) {
-        // big_dim.hip (128 < d <= 1024) or generic_dim.hip: plain assignment, update sums by the separate sweep
-        if (big_dim_applies(a_in.D) && (size_t)kmeans_grid(num_cus) * pstride <= a_in.partials_capacity) {
+        // big_dim.hip (register-blocked) or generic_dim.hip (plain): exact assignment, update sums by the separate sweep
+        if (big_dim_kmeans_applies(a_in.D) && (size_t)kmeans_grid(num_cus) * pstride <= a_in.partials_capacity) {
             const int used = launch_kmeans_assign_big(a_in, kmeans_grid(num_cus), pstride, stream);
             if (used > 0) {
                 if (a_in.accumulate) launch_kmeans_update(a_in, used, pstride, stream);
