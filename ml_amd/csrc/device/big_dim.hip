@@ -130,53 +130,57 @@ constexpr int MT = 64;        // macro tile: 64 x 64 entries of S_k
 constexpr int SC = 32;        // samples per panel
 constexpr int XS = 34;        // LDS row stride of a panel (== 2 mod 32: the 16 rows x 2 sample columns of a half wave hit 32 banks)
 
-/// grid: (macro tile pair t, component k, sample range s). Tile pair t = (ta, tb), tb <= ta, row-major over the lower triangle.
+/// grid: (macro tile pair t, group of KC components, sample range s). Tile pair t = (ta, tb), tb <= ta, row-major over the lower
+/// triangle. The panels of X are the same for every component -- only the responsibilities differ -- so ONE pair of panels in LDS
+/// serves KC components: the A operand is the raw x~ scaled by the component's r on its way into the matrix instruction. (One
+/// component per workgroup re-reads the panels K times: 12 GB through L2 per launch at N = 100k, d = 256, K = 8 -- 2.7 TB/s, which is
+/// what bound the first form of this kernel at 4.4 ms.)
+constexpr int KC = 4;
+
 __global__ __launch_bounds__(256) void em_mstats_big_kernel(const double* __restrict__ xt, size_t ldx, uint32_t n, int d,
                                                              const double* __restrict__ shift, const double* __restrict__ lw,
                                                              size_t ldr, const double* __restrict__ lse, int mode,
                                                              double* __restrict__ partials, int K, int F, uint32_t chunks_per_split)
 {
     __shared__ double pa[MT * XS], pb[MT * XS];
-    __shared__ double rr[SC];
+    __shared__ double rr[KC * SC];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int ta = 0;
     while ((ta + 1) * (ta + 2) / 2 <= (int)blockIdx.x) ++ta;
     const int tb = (int)blockIdx.x - ta * (ta + 1) / 2;
-    const int k = blockIdx.y;
+    const int k0 = blockIdx.y * KC;
     const int a_base = ta * MT, b_base = tb * MT;
     const int wa = wave >> 1, wb = wave & 1;                            // the wave's 32 x 32 quarter of the macro tile
     const bool idle = ta == tb && wa < wb;                              // above the diagonal: not needed
-    d4 acc[2][2];
+    d4 acc[KC][2][2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int c = 0; c < KC; ++c)
 #pragma unroll
-        for (int v = 0; v < 2; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
-    const double* __restrict__ wk = lw + (size_t)k * ldr;
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) acc[c][u][v] = d4{0.0, 0.0, 0.0, 0.0};
     const uint32_t n_chunks = (n + SC - 1) / SC;
     const uint32_t c_begin = blockIdx.z * chunks_per_split;
     uint32_t c_end = c_begin + chunks_per_split;
     if (c_end > n_chunks) c_end = n_chunks;
     const int i_r = lane & 15, kq = lane >> 4;
-    for (uint32_t c = c_begin; c < c_end; ++c) {
-        const uint32_t i0 = c * SC;
-        __syncthreads();                                               // the previous panel has been consumed
-        if (tid < SC) {
-            const uint32_t i = i0 + tid;
-            rr[tid] = i < n ? (mode == kFromResp ? wk[i] : exp_nonpos(wk[i] - lse[i])) : 0.0;
+    for (uint32_t ch = c_begin; ch < c_end; ++ch) {
+        const uint32_t i0 = ch * SC;
+        __syncthreads();                                               // the previous panels have been consumed
+        if (tid < KC * SC) {                                           // responsibilities of the group's components for the 32 samples
+            const int c = tid / SC, sidx = tid - c * SC;
+            const uint32_t i = i0 + sidx;
+            const int k = k0 + c;
+            rr[tid] = (k < K && i < n) ? (mode == kFromResp ? lw[(size_t)k * ldr + i] : exp_nonpos(lw[(size_t)k * ldr + i] - lse[i])) : 0.0;
         }
-        __syncthreads();
-        // panels: 64 rows x 32 samples each; thread -> (row = e / 32, sample = e % 32): 256-byte runs along a row of X.
-        // (Issuing the loads of panel c + 1 before the products of panel c -- 16 more registers per thread -- is slower:
-        // 5.8 against 4.4 ms at N = 100k, d = 256, K = 8; four resident workgroups per CU already cover the loads.)
+        // panels: 64 rows x 32 samples each; thread -> (row = e / 32, sample = e % 32): 256-byte runs along a row of X
         for (int e = tid; e < MT * SC; e += 256) {
             const int r = e / SC, sidx = e - r * SC;
             const uint32_t i = i0 + sidx;                                // < n_pad (the allocation is padded to the tile)
             const int a = a_base + r, b = b_base + r;
-            const double xa = a < d ? xt[(size_t)a * ldx + i] - shift[a] : (a == d ? 1.0 : 0.0);
-            const double xb = b < d ? xt[(size_t)b * ldx + i] - shift[b] : (b == d ? 1.0 : 0.0);
-            pa[r * XS + sidx] = xa * rr[sidx];
-            pb[r * XS + sidx] = xb;
+            pa[r * XS + sidx] = a < d ? xt[(size_t)a * ldx + i] - shift[a] : (a == d ? 1.0 : 0.0);
+            pb[r * XS + sidx] = b < d ? xt[(size_t)b * ldx + i] - shift[b] : (b == d ? 1.0 : 0.0);
         }
         __syncthreads();
         if (!idle) {
@@ -188,24 +192,35 @@ __global__ __launch_bounds__(256) void em_mstats_big_kernel(const double* __rest
 #pragma unroll
                 for (int v = 0; v < 2; ++v) bv[v] = pb[(wb * 32 + v * 16 + i_r) * XS + ks * 4 + kq];
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int c = 0; c < KC; ++c) {
+                    const double r = rr[c * SC + ks * 4 + kq];           // the A operand's sample: 4 ks + (lane >> 4)
 #pragma unroll
-                    for (int v = 0; v < 2; ++v) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[v], acc[u][v], 0, 0, 0);
+                    for (int u = 0; u < 2; ++u) {
+                        const double a = av[u] * r;
+#pragma unroll
+                        for (int v = 0; v < 2; ++v) acc[c][u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[v], acc[c][u][v], 0, 0, 0);
+                    }
+                }
             }
         }
     }
     if (idle) return;
-    double* __restrict__ out = partials + ((size_t)blockIdx.z * K + k) * F;
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int c = 0; c < KC; ++c) {
+        const int k = k0 + c;
+        if (k >= K) break;
+        double* __restrict__ out = partials + ((size_t)blockIdx.z * K + k) * F;
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int a = a_base + wa * 32 + u * 16 + kq + 4 * g;   // output row: kq + 4 g of the block; column: lane & 15
-                const int b = b_base + wb * 32 + v * 16 + i_r;
-                if (a <= d && b <= a) out[(size_t)a * (a + 1) / 2 + b] = acc[u][v][g];
-            }
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int a = a_base + wa * 32 + u * 16 + kq + 4 * g;   // output row: kq + 4 g of the block; column: lane & 15
+                    const int b = b_base + wb * 32 + v * 16 + i_r;
+                    if (a <= d && b <= a) out[(size_t)a * (a + 1) / 2 + b] = acc[c][u][v][g];
+                }
+    }
 }
 
 // ---- K-means assignment -----------------------------------------------------------------------------------------------
@@ -305,13 +320,13 @@ bool big_dim_applies(int d) { return d > kMaxDim && d <= kBigMaxDim && big_dim_e
 /// The K-means assignment kernel of this file has no upper limit on d (no tile in LDS).
 bool big_dim_kmeans_applies(int d) { return d > kMaxDim && big_dim_enabled(); }
 
-/// Sample ranges a statistics tile is cut into (= partial blocks written): enough workgroups to fill the chip, at most 16.
+/// Sample ranges a statistics tile is cut into (= partial blocks written): enough workgroups to fill the chip, at most 32.
 int big_dim_splits(int d, int K, int num_cus)
 {
     const int T = (d + 1 + MT - 1) / MT;
-    const int pairs = T * (T + 1) / 2;
-    int s = (3 * num_cus + pairs * K - 1) / (pairs * K);
-    return s < 1 ? 1 : (s > 16 ? 16 : s);
+    const int units = T * (T + 1) / 2 * ((K + KC - 1) / KC);            // (tile pair, component group)
+    int s = (3 * num_cus + units - 1) / units;
+    return s < 1 ? 1 : (s > 32 ? 32 : s);
 }
 
 int launch_em_estep_big(const EstepArgs& a, int num_cus, hipStream_t stream)
@@ -344,7 +359,7 @@ int launch_em_mstats_big(const MstatsArgs& a, int num_cus, hipStream_t stream)
     if (splits < 1) return -2;
     const uint32_t per = (n_chunks + splits - 1) / splits;
     const int T = (a.d + 1 + MT - 1) / MT;
-    hipLaunchKernelGGL(em_mstats_big_kernel, dim3(T * (T + 1) / 2, a.K, splits), dim3(256), 0, stream, a.xt, a.ldx, a.n, a.d, a.shift, a.lw,
+    hipLaunchKernelGGL(em_mstats_big_kernel, dim3(T * (T + 1) / 2, (a.K + KC - 1) / KC, splits), dim3(256), 0, stream, a.xt, a.ldx, a.n, a.d, a.shift, a.lw,
                        a.ldr, a.lse, a.mode, a.partials, a.K, F, per);
     return splits;
 }
