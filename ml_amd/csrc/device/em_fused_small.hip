@@ -6,12 +6,13 @@
 // kernel reads them back (d = 4, K = 16, N = 10M: 1.28 GB each way next to 0.32 GB of samples). Here a wave owns a stream
 // of 64-sample tiles (lane = sample while the densities are evaluated):
 //   1. lw_k = log pi_k - sum log L_jj - |W_k (x - mu_k)|^2 / 2 for all K components (same arithmetic as em_estep.hip), the
-//      component records staged once per workgroup in LDS and read as broadcasts at compile-time offsets (statically
-//      unrolled over K, scalar loads would need more SGPRs than exist), the K values kept in VGPRs;
+//      K values kept in VGPRs; the component records come from scalar registers row by row of W (SFEED: d = 7, 8, and d >= 3
+//      with many samples) or from a copy staged once per workgroup in LDS, read as broadcasts at compile-time offsets;
 //   2. m = max_k lw_k, e_k = exp(lw_k - m), s = sum_k e_k, lse = m + log s (written: log-likelihood, later
 //      responsibilities), r_k = e_k / s -- one exp per (sample, component) instead of one in each of the two kernels;
 //   3. r and x~ = [x - shift; 1] go to the wave's private LDS tiles and the statistics GEMM stats[K x F] += R^T Phi runs
 //      on the matrix cores exactly as in em_mstats_small.hip.
+// Few components in few dimensions (K F <= ~100 sums): em_fused_valu_kernel below keeps the statistics on the vector unit instead.
 // HBM traffic per iteration: X once, LSE once. The log-responsibility block is produced on demand (labels /
 // responsibilities after the fit) by the ordinary E-step kernel from the same parameter records.
 #include "em_close_body.hpp"
