@@ -115,7 +115,7 @@ int mlhip_ctx_world(const mlhip_ctx* ctx, int* world_size, int* rank);
 /* Copies this rank's d x n block to HBM (stored dimension-major for coalesced per-sample access) and
  * computes the statistics shift (global column mean; all-reduced when a hook is set). The host block is
  * only read during the call (the reference borrows `data` for the duration of fit, ML/EM.cpp:91).
- * 1 <= d <= 4096 (MLHIP_E_UNSUPPORTED above; d > 128 runs plain, untuned kernels: device/generic_dim.hip), n < 2^32 - 256 per rank. */
+ * 1 <= d <= 4096 (MLHIP_E_UNSUPPORTED above; 128 < d <= 1024: matrix-core kernels of device/big_dim.hip; above: plain, untuned kernels, device/generic_dim.hip), n < 2^32 - 256 per rank. */
 int mlhip_data_upload(mlhip_ctx* ctx, const double* x, uint32_t d, uint64_t n, int64_t ld, mlhip_data** out);
 /* Same, from a sample-major block already in device memory (e.g. a torch tensor's data_ptr()). */
 int mlhip_data_upload_dev(mlhip_ctx* ctx, const double* x_dev, uint32_t d, uint64_t n, int64_t ld, mlhip_data** out);
