@@ -97,6 +97,9 @@ def test_group_em_step_and_outputs_match_a_single_context(group3, single, d, K, 
     (4, 3, 10000, False),       # fused small-shape kernel, lagged loop: speculative all-reduces of all shards stay paired
     (16, 16, 30000, True),      # diagonal covariances
     (100, 3, 4001, False),      # host closing (d > 64)
+    (200, 3, 4001, False),      # d > 128: the matrix-core tier of big_dim.hip in every shard
+    (8, 20, 30000, False),      # fused kernel, records from scalar registers
+    (2, 3, 50000, False),       # vector-unit statistics
 ])
 def test_group_em_iterate_matches_a_single_context(group3, single, d, K, n, diagonal):
     from ml_amd import _lib
@@ -113,7 +116,7 @@ def test_group_em_iterate_matches_a_single_context(group3, single, d, K, n, diag
     g.close(); s.close()
 
 
-@pytest.mark.parametrize("d,K,n", [(8, 32, 50001), (2, 4, 20000), (32, 7, 9000), (3, 130, 20000)])
+@pytest.mark.parametrize("d,K,n", [(8, 32, 50001), (2, 4, 20000), (32, 7, 9000), (3, 130, 20000), (200, 24, 6000)])
 def test_group_kmeans_matches_a_single_context(group3, single, d, K, n):
     from ml_amd import _lib
     rng = np.random.default_rng(11 + d)
