@@ -609,15 +609,16 @@ def main():
             # In the same driver-timed run (the EM block has been freed above), as a LIST:
             # [0] BASELINE.json configs[4] (K-means N=100M, d=8, K=256 on 8 GPUs) at ONE GPU's share of it;
             # [1] BASELINE.json configs[1] (N=1M, d=16, K=16 diagonal-covariance GMM on one GPU) -- an iteration is ~0.1 ms, so
-            #     it gets ten times the steps.
+            #     it gets fifty times the steps (a timed region of 18 ms -- ten times -- was at the mercy of one host hiccup: 6 242
+            #     instead of 10 900 iterations/s in one run of round 4 with the kernel at its usual 79.6 us).
             # (1.1 ms steps: the clock of the chip ramps for ~15 ms after the idle gap of the upload -- profiles/r04_kmeans_clock.txt: every
             # dispatch takes the same 2.41e6 cycles at 2.03 ... 2.28 GHz -- so the warm-up is ten times and the timed region five times
             # the headline's step counts, as for the 0.09 ms iterations of the diagonal configuration below)
             sec = kmeans_measure(job, 12_500_000, 8, 256, 5 * args.steps, 10 * args.warmup, with_cpu, args.cpu_samples)
-            diag = em_measure(job, 1_000_000, 16, 16, 10 * args.steps, 10 * args.warmup, with_cpu, args.cpu_samples, diagonal=True)
+            diag = em_measure(job, 1_000_000, 16, 16, 50 * args.steps, 10 * args.warmup, with_cpu, args.cpu_samples, diagonal=True)
             # [2] BASELINE.json configs[0], the reference's own benchmark case (Benchmarks/bm_EM.cpp: N=10k, d=4, K=3): an iteration is
-            #     ~18 us -- three dependent launches -- so it gets a hundred times the steps.
-            small = em_measure(job, 10_000, 4, 3, 100 * args.steps, 100 * args.warmup, with_cpu, args.cpu_samples)
+            #     ~18 us -- three dependent launches -- so it gets five hundred times the steps (a region of 0.18 s).
+            small = em_measure(job, 10_000, 4, 3, 500 * args.steps, 100 * args.warmup, with_cpu, args.cpu_samples)
             if out is not None and sec is not None and diag is not None and small is not None:
                 sec["config"]["workload"] += " = one GPU's row shard of BASELINE.json configs[4] (N=100M on 8 GPUs)"
                 diag["config"]["workload"] += " = BASELINE.json configs[1]"
