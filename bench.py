@@ -63,10 +63,11 @@ def mstats_flops(n, d, K, self_norm=False):
     return float(n) * K * (d * d + 3 * d + (25 if self_norm else 0))
 
 
-def kmeans_uses_matrix_cores(d, K):
-    """device/kmeans.hip serves d = 1, 2, 3, 5, 6 with K < 128 on the vector unit (direct form, 3d flops per pair);
-    everything else runs kmeans_mfma.hip, which EXECUTES 2d flops per pair (scores x.c - |c|^2/2) plus the exact recheck."""
-    return not (d in (1, 2, 3, 5, 6) and K < 128)
+def kmeans_uses_matrix_cores(d, K, n_local=1 << 30):
+    """device/kmeans.hip serves d = 1, 2, 3, 5, 6 with K < 128, few clusters (K <= 16 at d <= 32, from 2^21 rows on) and d > 128 on the vector unit
+    (direct form, 3d flops per pair); everything else runs kmeans_mfma.hip, which EXECUTES 2d flops per pair (scores
+    x.c - |c|^2/2) plus the exact recheck."""
+    return not ((d in (1, 2, 3, 5, 6) and K < 128) or (K <= 16 and d <= 32 and n_local >= (1 << 21)) or d > 128)
 
 
 def diag_flops(n, d, K):
@@ -316,7 +317,7 @@ def kmeans_measure(job, n, d, K, steps, warmup, with_cpu, cpu_samples):
         n_local = n_locals[0]
         flops = float(n_local) * K * 3 * d                  # N*K*3d (direct-form distances)
         algorithmic = flops / (k_ms * 1e-3) / 1e12
-        matrix = kmeans_uses_matrix_cores(d, K)
+        matrix = kmeans_uses_matrix_cores(d, K, n_local)
         # the matrix-core kernel executes 2d flops per pair: `frac` prices what the pipe executes, the 3d form is
         # reported beside it
         achieved = algorithmic * (2.0 / 3.0 if matrix else 1.0)

@@ -284,11 +284,19 @@ int launch_kmeans_mfma(const KmeansArgs& a, int num_cus, hipStream_t stream);
 
 int launch_kmeans_assign(const KmeansArgs& a_in, int num_cus, hipStream_t stream)
 {
-    // Matrix-core search with exact recheck (kmeans_mfma.hip) where it applies; MLHIP_KMEANS=valu forces this file's kernel.
+    // Matrix-core search with exact recheck (kmeans_mfma.hip) where it applies; MLHIP_KMEANS=valu forces this file's kernel,
+    // MLHIP_KMEANS=mfma the matrix-core one wherever it exists.
     const char* e = std::getenv("MLHIP_KMEANS");
-    const bool force_valu = e && e[0] == 'v';
+    const bool force_valu = e && e[0] == 'v', force_mfma = e && e[0] == 'm';
+    // Few clusters (K <= 16, d <= 32): the direct-form kernel of this file -- the matrix-core search pads K to 16 rows and pays its
+    // exact recheck per sample whatever K is (round 4, N = 10M: d = 4, K = 8 0.230 -> 0.155 ms, K = 16 0.212 -> 0.164; d = 8, K = 16
+    // 0.318 -> 0.276; d = 16, K = 8 0.595 -> 0.515; d = 32, K = 16 0.486 -> 0.474; K = 32: the matrix cores win again). Labels and
+    // distances are the same bits either way.
+    // From 2^21 samples on: below, this kernel's 1024-thread workgroups (zeroing and flushing their LDS accumulators) are the
+    // slower ones (N = 20k, d = 32, K = 4: 69 against 52 us per step; N = 1M, d = 16, K = 16: 87 against 83).
+    const bool few = a_in.K <= 16 && a_in.D <= kRegDim && a_in.n >= (1u << 21) && !force_mfma;
     // (above d = 64 only the matrix-core kernel exists)
-    if ((!force_valu || a_in.D > kMidDim) && kmeans_mfma_supported(a_in.D, a_in.K)) return launch_kmeans_mfma(a_in, num_cus, stream);
+    if ((!(force_valu || few) || a_in.D > kMidDim) && kmeans_mfma_supported(a_in.D, a_in.K)) return launch_kmeans_mfma(a_in, num_cus, stream);
     const size_t pstride = 2 + (size_t)a_in.K * (3 * a_in.d + 1);
     if (a_in.D > kMaxDim) {
         // big_dim.hip (register-blocked) or generic_dim.hip (plain): exact assignment, update sums by the separate sweep
