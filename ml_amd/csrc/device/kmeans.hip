@@ -34,9 +34,12 @@ template <int D, bool USE_LDS, int BS>
 __global__ __launch_bounds__(BS) void kmeans_assign_kernel(
     const double* __restrict__ xt, size_t ldx, uint32_t n, int d, const double* __restrict__ cent, int K,
     const double* __restrict__ scale, uint32_t* __restrict__ labels, const uint32_t* __restrict__ old_labels,
-    int have_old, double* __restrict__ min_dist, int accumulate, double* __restrict__ partials, size_t pstride)
+    int have_old, double* __restrict__ min_dist, int accumulate, double* __restrict__ partials, size_t pstride, int copies)
 {
-    extern __shared__ u64 acc_lds[];      // [K][3d+1] when USE_LDS
+    // [copies][K][3d+1] when USE_LDS. With few clusters most lanes of a wave add to the SAME few rows and the LDS atomics serialise
+    // (K = 3: ~21 lanes per address); `copies` (a power of two, as many as fit) tables indexed by the low lane bits spread them --
+    // integer sums: the copies add up exactly, in any order.
+    extern __shared__ u64 acc_lds[];
     __shared__ double red[2 * (BS / 64)];
     const int tid = threadIdx.x;
     const int W = 3 * d + 1;
@@ -44,7 +47,7 @@ __global__ __launch_bounds__(BS) void kmeans_assign_kernel(
     u64* my_words = reinterpret_cast<u64*>(my_part + 2);
     if (accumulate) {
         if (USE_LDS) {
-            for (int e = tid; e < K * W; e += BS) acc_lds[e] = 0;
+            for (int e = tid; e < copies * K * W; e += BS) acc_lds[e] = 0;
         } else {
             for (int e = tid; e < K * W; e += BS) my_words[e] = 0;
         }
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(BS) void kmeans_assign_kernel(
         inertia += best;
         changed += (!have_old || old_labels[i] != arg) ? 1.0 : 0.0;
         if (accumulate) {
-            u64* row = (USE_LDS ? acc_lds : my_words) + (size_t)arg * W;
+            u64* row = (USE_LDS ? acc_lds + (size_t)(tid & (copies - 1)) * K * W : my_words) + (size_t)arg * W;
 #pragma unroll
             for (int j = 0; j < D; ++j) {
                 if (j < d) {
@@ -133,7 +136,11 @@ __global__ __launch_bounds__(BS) void kmeans_assign_kernel(
         my_part[1] = b;
     }
     if (accumulate && USE_LDS) {
-        for (int e = tid; e < K * W; e += BS) my_words[e] = acc_lds[e];
+        for (int e = tid; e < K * W; e += BS) {
+            u64 v = acc_lds[e];
+            for (int c = 1; c < copies; ++c) v += acc_lds[(size_t)c * K * W + e];
+            my_words[e] = v;
+        }
     }
 }
 
@@ -244,13 +251,16 @@ template <int D>
 void launch_t(const KmeansArgs& a, int grid, int use_lds, size_t pstride, hipStream_t stream)
 {
     constexpr int BSZ = D <= kRegDim ? BS : BS_BIG;
-    const size_t smem = use_lds ? sizeof(u64) * (size_t)a.K * (3 * a.d + 1) : 0;
+    const size_t table = sizeof(u64) * (size_t)a.K * (3 * a.d + 1);
+    int copies = 1;                                              // as many accumulator tables as fit 64 KB, at most 8
+    while (use_lds && copies < 8 && 2 * copies * table <= 64 * 1024) copies *= 2;
+    const size_t smem = use_lds ? copies * table : 0;
     if (use_lds)
         hipLaunchKernelGGL((kmeans_assign_kernel<D, true, BSZ>), dim3(grid), dim3(BSZ), smem, stream, a.xt, a.ldx, a.n, a.d,
-                           a.centroids, a.K, a.scale, a.labels, a.old_labels, a.have_old, a.min_dist, a.accumulate, a.partials, pstride);
+                           a.centroids, a.K, a.scale, a.labels, a.old_labels, a.have_old, a.min_dist, a.accumulate, a.partials, pstride, copies);
     else
         hipLaunchKernelGGL((kmeans_assign_kernel<D, false, BSZ>), dim3(grid), dim3(BSZ), smem, stream, a.xt, a.ldx, a.n, a.d,
-                           a.centroids, a.K, a.scale, a.labels, a.old_labels, a.have_old, a.min_dist, a.accumulate, a.partials, pstride);
+                           a.centroids, a.K, a.scale, a.labels, a.old_labels, a.have_old, a.min_dist, a.accumulate, a.partials, pstride, 1);
 }
 
 inline int kmeans_grid(int num_cus) { return num_cus * 2; }   // two 1024-thread workgroups (32 waves) per CU
