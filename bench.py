@@ -64,10 +64,10 @@ def mstats_flops(n, d, K, self_norm=False):
 
 
 def kmeans_uses_matrix_cores(d, K, n_local=1 << 30):
-    """device/kmeans.hip serves d = 1, 2, 3, 5, 6 with K < 128, few clusters (K <= 16 at d <= 32, from 2^21 rows on) and d > 128 on the vector unit
+    """device/kmeans.hip serves d = 1, 2, 3, 5, 6 with K < 128, few clusters (K <= 16 at d <= 32, K <= 24 at d <= 8, from 2^21 rows on) and d > 128 on the vector unit
     (direct form, 3d flops per pair); everything else runs kmeans_mfma.hip, which EXECUTES 2d flops per pair (scores
     x.c - |c|^2/2) plus the exact recheck."""
-    return not ((d in (1, 2, 3, 5, 6) and K < 128) or (K <= 16 and d <= 32 and n_local >= (1 << 21)) or d > 128)
+    return not ((d in (1, 2, 3, 5, 6) and K < 128) or (K <= (24 if d <= 8 else 16) and d <= 32 and n_local >= (1 << 21)) or d > 128)
 
 
 def diag_flops(n, d, K):

@@ -304,7 +304,7 @@ int launch_kmeans_assign(const KmeansArgs& a_in, int num_cus, hipStream_t stream
     // distances are the same bits either way.
     // From 2^21 samples on: below, this kernel's 1024-thread workgroups (zeroing and flushing their LDS accumulators) are the
     // slower ones (N = 20k, d = 32, K = 4: 69 against 52 us per step; N = 1M, d = 16, K = 16: 87 against 83).
-    const bool few = a_in.K <= 16 && a_in.D <= kRegDim && a_in.n >= (1u << 21) && !force_mfma;
+    const bool few = a_in.K <= (a_in.D <= 8 ? 24 : 16) && a_in.D <= kRegDim && a_in.n >= (1u << 21) && !force_mfma;   // (K = 24: d = 4 -14 %, d = 8 -7 %)
     // (above d = 64 only the matrix-core kernel exists)
     if ((!(force_valu || few) || a_in.D > kMidDim) && kmeans_mfma_supported(a_in.D, a_in.K)) return launch_kmeans_mfma(a_in, num_cus, stream);
     const size_t pstride = 2 + (size_t)a_in.K * (3 * a_in.d + 1);
