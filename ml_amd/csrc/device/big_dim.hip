@@ -73,19 +73,29 @@ __global__ __launch_bounds__(256) void em_estep_big_kernel(const double* __restr
                 const double* __restrict__ wr = w + (size_t)row * (row + 1) / 2;
                 const int l_end = (rb * 16 + 16 < D ? rb * 16 + 16 : D);   // columns 0 .. l_end - 1 (a multiple of 4)
                 d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+                // The columns LEFT of the diagonal block need no triangle test, and only the last row block can hold rows >= D: the
+                // bulk of the products runs without predicates, the lane's row pointer and its LDS address advancing by constants
+                // (13 vector instructions per product before -- address arithmetic and selects --, counters in profiles/r04_pmc_new_kernels.txt).
+                const double* __restrict__ wp = wr + kq;
+                const double* zp = zt + kq * 16 + j;
+                const int l_full = rb * 16;                            // (a multiple of 16)
                 int l0 = 0;
-                for (; l0 + 16 <= l_end; l0 += 16) {                    // four gathers of W in flight
-                    double av[4], bv[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int c = l0 + 4 * u + kq;
-                        av[u] = (row_ok && c <= row) ? wr[c] : 0.0;
-                        bv[u] = zt[c * 16 + j];
+                if (rb * 16 + 16 <= D) {
+                    for (; l0 < l_full; l0 += 16) {                     // four gathers of W in flight
+                        const double a0 = wp[l0], a1 = wp[l0 + 4], a2 = wp[l0 + 8], a3 = wp[l0 + 12];
+                        const double b0 = zp[l0 * 16], b1 = zp[(l0 + 4) * 16], b2 = zp[(l0 + 8) * 16], b3 = zp[(l0 + 12) * 16];
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, acc1, 0, 0, 0);
                     }
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc1, 0, 0, 0);
+                }
+                for (; l0 + 8 <= l_end; l0 += 8) {                      // the diagonal block (and all of the last row block)
+                    const int c0 = l0 + kq, c1 = l0 + 4 + kq;
+                    const double a0 = (row_ok && c0 <= row) ? wr[c0] : 0.0;
+                    const double a1 = (row_ok && c1 <= row) ? wr[c1] : 0.0;
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, zt[c0 * 16 + j], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, zt[c1 * 16 + j], acc1, 0, 0, 0);
                 }
                 for (; l0 < l_end; l0 += 4) {
                     const int c0 = l0 + kq;
