@@ -207,3 +207,35 @@ def test_config_E_full_size_on_one_gpu_and_as_eight_shards(ctx, oracle):
         g.close()
     finally:
         grp.close()
+
+
+@pytest.mark.parametrize("d,K", [(4, 3), (8, 20), (16, 9), (32, 16)])
+def test_few_cluster_kmeans_takes_the_direct_form_kernel_with_the_same_bits(d, K, monkeypatch):
+    """From 2^21 rows on, K-means with few clusters (K <= 16, K <= 24 at d <= 8) runs on the direct-form kernel with its copies of
+    the LDS accumulator table instead of the matrix-core search (kmeans.hip launch_kmeans_assign): labels, distances, counts and new
+    centroids are the same bits as the matrix-core kernel's (MLHIP_KMEANS=mfma), the labels of a prefix the oracle's."""
+    from ml_amd import _lib
+    from oracle import oracle_ctypes as oracle
+    n = (1 << 21) + 777
+    rng = np.random.default_rng(d * 100 + K)
+    C = 3.0 * rng.standard_normal((K, d))
+    X = np.ascontiguousarray(C[rng.integers(0, K, n)] + rng.standard_normal((n, d)))
+    C0 = C + 0.5 * rng.standard_normal((K, d))
+    ctx = _lib.Context()
+    dt = _lib.Data(ctx, X)
+    a = dt.kmeans_step(C0)
+    la, da = dt.kmeans_labels(), dt.kmeans_distances()
+    it_a = dt.kmeans_iterate(C0, 4, 0.0)
+    monkeypatch.setenv("MLHIP_KMEANS", "mfma")
+    b = dt.kmeans_step(C0)
+    assert np.array_equal(la, dt.kmeans_labels()) and np.array_equal(da, dt.kmeans_distances())
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and abs(a[0] - b[0]) <= 1e-13 * b[0]
+    it_b = dt.kmeans_iterate(C0, 4, 0.0)
+    assert it_a[0] == it_b[0] and np.array_equal(it_a[3], it_b[3]) and np.array_equal(it_a[4], it_b[4])
+    m = 30000
+    km = oracle.KMeans(K)
+    km.set_centroids(C0, m)
+    km.assignment_step(X[:m])
+    assert np.array_equal(la[:m], km.labels)
+    dt.close()
+    ctx.close()
