@@ -104,27 +104,41 @@ struct FusedArgs {
     double* partials; size_t partials_capacity;              // scratch: [grid][KP][FP]
     double* ll_partials; int n_ll_partials;                  // out: per-workgroup log-likelihood sums (grid of them)
 };
-/// The tail of the ONE-kernel iteration of tiny fits (em_fused_small.hip): the last workgroup to finish combines the partial blocks
-/// in the order of the reduction kernel (-> stats, K*F + 1 doubles) and closes the iteration (em_close_body.hpp) -- new parameters,
-/// the next E-step's records, the info block -- so that an iteration is one launch instead of three. Single rank only (the
-/// statistics all-reduce would sit between the reduction and the closing).
-struct FusedTail {
-    unsigned* counter;                                       // device, zero before the first launch (the kernel leaves it zero)
-    double* stats;                                           // out: [K*F statistics | log-likelihood sum]
-    double n_global; double refine_limit;
-    double* mixing; double* means; double* covs;             // out (CloseArgs)
-    double* records; double* info;                           // out: the next records (estep_param_stride layout), the info block
-};
 namespace mstats {
 bool em_fused_supported(int d, int K);
 int em_fused_partial_rows(int K);
 int em_fused_partial_cols(int d);
 int launch_em_fused_small(const FusedArgs& a, int num_cus, hipStream_t stream);
-/// Components a tail closes at most (four waves take turns).
-constexpr int kFusedTailMaxK = 8;
-/// ... and the largest dimension a tail is built for (the LDS-fed form of the kernel).
-constexpr int kFusedTailMaxDim = 6;
-int launch_em_fused_small_tail(const FusedArgs& a, const FusedTail& t, int num_cus, hipStream_t stream);
+/// The grid launch_em_fused_small would use for these arguments if the shape takes the vector-unit form with at most one
+/// workgroup per CU; 0 otherwise.
+int em_fused_valu_small_grid(const FusedArgs& a, int num_cus);
+}
+/// The whole loop of EM::fit (ML/EM.cpp:143-170) in ONE launch for short fits (em_resident.hip): resident workgroups, one
+/// hand-off of the partial statistics per iteration, the closing arithmetic and the convergence test on the device. Pointers in
+/// ring order: iteration i reads the records of slot i % 3 (slot 0 on entry) and leaves parameters / records in slot (i + 1) % 3,
+/// exactly what the launches of runtime/em_loop.cpp leave.
+struct ResidentArgs {
+    const double* xt; size_t ldx; uint32_t n; int d; int K;
+    const double* shift;
+    double* records[3];                                      // estep_param_stride(d) records (device)
+    double* info[3]; double* mixing[3]; double* means[3]; double* covs[3];   // the packs' parts (device, or pinned host memory)
+    double* xch;                                             // device: em_resident_exchange_doubles(d, K, vgrid) doubles
+    unsigned* sync;                                          // device: [arrivals, give-up flag], zeroed before the launch
+    int vgrid;                                               // partial blocks = workgroups (em_fused_valu_small_grid)
+    double n_global, refine_limit, atol, rtol, ll_offset;    // log-likelihood = sum / n_global - ll_offset
+    uint32_t max_steps;
+    double* history;                                         // pinned host: max_steps log-likelihoods
+    uint32_t* result;                                        // pinned host: [status, iterations evaluated, converged]; status 1 = loop over,
+                                                             // 2 = iteration `result[1]` flagged a refinement (not closed), 3 = a wait gave up
+    unsigned long long* profile;                             // null, or kResidentStamps clock stamps per iteration (MLHIP_RESIDENT_PROFILE=1)
+};
+namespace mstats {
+constexpr int kResidentSlices = 32;                          // (= em_reduce_kernel's slices: the same summation order)
+constexpr int kResidentMaxGrid = 64;                          // workgroups (= partial blocks = CUs used): N <= 16 384
+constexpr int kResidentStamps = 24;
+size_t em_resident_exchange_doubles(int d, int K, int vgrid);
+bool em_resident_supported(int d, int K, int vgrid, int num_cus);
+bool launch_em_resident(const ResidentArgs& a, hipStream_t stream);
 }
 /// Diagonal-covariance EM iteration in one kernel (em_diag.hip): params are em_diag_partial_rows(K) records of
 /// diag_param_stride(padded_dim(d)) -- K real ones, then neutral padding (coef = -inf) -- and shift holds padded_dim(d)

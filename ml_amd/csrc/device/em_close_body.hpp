@@ -28,11 +28,14 @@ __host__ __device__ constexpr size_t scratch_doubles(int d) { return (size_t)(d 
     } while (0)
 
 /// Component k, by the NT threads tid = 0 .. NT - 1 of one wave, with `sm` = scratch_doubles(d) doubles of LDS of their own.
-template <int LAYOUT, int DT>
+struct NoProbe { __device__ __forceinline__ void operator()(int) const {} };   // (diagnostic hook: see em_resident.hip)
+
+template <int LAYOUT, int DT, typename Probe = NoProbe>
 __device__ __forceinline__ void close_component(const double* __restrict__ stats, int K, int d, int D, const double* __restrict__ shift,
                                                 double n_global, double refine_limit, double* __restrict__ mixing,
                                                 double* __restrict__ means, double* __restrict__ covs, double* __restrict__ records,
-                                                int PS, double* __restrict__ info, const int k, const int tid, double* sm)
+                                                int PS, double* __restrict__ info, const int k, const int tid, double* sm,
+                                                const Probe& probe = Probe())
 {
 #pragma clang fp contract(off)     // the host's closing arithmetic, statement by statement (em_close.hip)
     const int F = (d + 1) * (d + 2) / 2;
@@ -56,7 +59,9 @@ __device__ __forceinline__ void close_component(const double* __restrict__ stats
         mean[tid] = shift[tid] + m[tid];
         means[(size_t)k * d + tid] = mean[tid];
     }
-    if (tid == 0) { s_mix = s0 / n_global; mixing[k] = s_mix; }                      // ML/EM.cpp:257
+    const double mix = s0 / n_global;                                                // ML/EM.cpp:257 (every lane: the same value)
+    const double log_mix = log(mix);                                                 // (needed at the very end: its latency hides behind the factorization)
+    if (tid == 0) { s_mix = mix; mixing[k] = mix; }
     MLHIP_CLOSE_SYNC();
     for (int e = tid; e < d * d; e += NT) {
         const int a = e % d, b = e / d;                                              // element (a, b), column-major
@@ -83,6 +88,7 @@ __device__ __forceinline__ void close_component(const double* __restrict__ stats
         info[1 + k] = flag;
     }
 
+    probe(12);
     // ---- Cholesky (host/em_math.cpp cholesky_lower) and W = L^-1 (whitening_matrix).
     if constexpr (DT > 0) {
         // d <= 32: thread i keeps ROW i of the factor in registers; what another thread's row contributes arrives through
@@ -105,6 +111,7 @@ __device__ __forceinline__ void close_component(const double* __restrict__ stats
                 Li[jj] = tid == jj ? ljj : t / ljj;                                      // rows above the diagonal: unused
             }
         }
+        probe(13);
         // W, one thread per column `col`: w[i] = ((i == col) - sum_{l<i} L(i,l) w[l]) / L(i,i). Entries above the diagonal are
         // exact zeros, so the host's sum over l = col .. i-1 may as well start at l = 0 (t - L * 0 == t): same bits.
         double w[DT];
@@ -116,6 +123,7 @@ __device__ __forceinline__ void close_component(const double* __restrict__ stats
             for (int l = 0; l < ii; ++l) t -= lane_value(Li[l], ii < d ? ii : 0) * w[l];
             w[ii] = (ii < col || ii >= d) ? 0.0 : t / lane_value(Li[ii], ii < d ? ii : 0);
         }
+        probe(14);
         if (tid < d) {
 #pragma unroll
             for (int c0 = 0; c0 < DT; ++c0)
@@ -148,12 +156,19 @@ __device__ __forceinline__ void close_component(const double* __restrict__ stats
             }
         }
     }
+    probe(15);
+    // sum_j log L_jj in the host's order (ascending j, one addition at a time) -- the d logarithms themselves side by side, one per
+    // lane: evaluated one after the other by a single lane they were a third of this function's time (d = 4: 1.2 of 4.8 us; d = 32:
+    // 32 dependent calls of ~0.25 us each)
+    for (int j = tid; j < d; j += NT) tcol[j] = log(A[j * d + j]);
+    MLHIP_CLOSE_SYNC();
     if (tid == 0) {
         double ldh = 0.0;
-        for (int j = 0; j < d; ++j) ldh += log(A[j * d + j]);
+        for (int j = 0; j < d; ++j) ldh += tcol[j];
         s_ldh = ldh;
     }
     MLHIP_CLOSE_SYNC();
+    probe(16);
     if (tid < d) {
         double acc = 0.0;
         for (int col = 0; col <= tid; ++col) acc += W[col * d + tid] * (mean[col] - shift[col]);
@@ -171,9 +186,10 @@ __device__ __forceinline__ void close_component(const double* __restrict__ stats
         info[1 + K + k] = finite ? biggest : __builtin_inf();
         if (k == 0) info[0] = stats[(size_t)K * F];                                  // the log-likelihood sum rides along
     }
+    probe(17);
     // ---- the next E-step's record
     double* rec = records + (size_t)k * PS;
-    const double coef = log(s_mix) - s_ldh;
+    const double coef = log_mix - s_ldh;
     if constexpr (LAYOUT == 2) {
         const int Q = D / 4, NB = Q * (Q + 1) / 2;
         for (int e = tid; e < NB * 16; e += NT) {

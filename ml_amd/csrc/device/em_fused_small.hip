@@ -15,9 +15,7 @@
 // Few components in few dimensions (K F <= ~100 sums): em_fused_valu_kernel below keeps the statistics on the vector unit instead.
 // HBM traffic per iteration: X once, LSE once. The log-responsibility block is produced on demand (labels /
 // responsibilities after the fit) by the ordinary E-step kernel from the same parameter records.
-#include "em_close_body.hpp"
-#include "em_mstats_common.hpp"
-#include "exp_nonpos.hpp"
+#include "em_fused_valu_body.hpp"
 
 namespace mlhip {
 namespace mstats {
@@ -52,17 +50,15 @@ template <int D, bool SCALAR, typename P> __device__ __forceinline__ double reco
     return __builtin_fma(-0.5, q, p[PS - 1]);
 }
 
-/// TAIL: the workgroup that finishes LAST (a ticket per workgroup) also reduces the partial blocks and closes the iteration
-/// (FusedTail, device.hpp) -- tiny fits, where the three dependent launches of an iteration cost more than their kernels.
 /// SFEED: the component records come from SCALAR registers (wave-uniform s_load of the global records, as in em_estep.hip) instead of
 /// broadcast reads of an LDS copy. At d = 7, 8 a record is 45 doubles: with the LDS feed the density loop of 32 components issues
 /// 1 440 LDS reads per 64 samples next to 2 400 vector instructions, and the four SIMDs of a CU share ONE LDS pipe -- that is what
 /// made the fused form slower than the two-kernel path there; scalar loads leave the LDS pipe to the statistics tiles.
-template <int D, int RBW, int CB, bool TAIL, bool SFEED = false>
+template <int D, int RBW, int CB, bool SFEED = false>
 __global__ __launch_bounds__(256, (D <= 4 && RBW <= 2) ? 3 : 2) void em_fused_small_kernel(
     const double* __restrict__ xt, size_t ldx, uint32_t n, int d, const double* __restrict__ shift,
     const double* __restrict__ params, int K, int F, double* __restrict__ lse_out, double* __restrict__ partials, int KP,
-    int FP, double* __restrict__ ll_partials, FusedTail tail)
+    int FP, double* __restrict__ ll_partials)
 {
     constexpr int PS = D + D * (D + 1) / 2 + 1;    // estep_param_stride(D)
     constexpr int KMAX = 16 * RBW;
@@ -214,92 +210,24 @@ __global__ __launch_bounds__(256, (D <= 4 && RBW <= 2) ? 3 : 2) void em_fused_sm
     if (lane == 0) red[wave] = ll_acc;
     __syncthreads();
     if (tid == 0) ll_partials[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
-
-    if constexpr (TAIL) {
-        __shared__ unsigned s_ticket;
-        __threadfence();                                    // this thread's partial-block / log-likelihood writes: device-wide
-        __syncthreads();
-        if (tid == 0) s_ticket = atomicAdd(tail.counter, 1u);
-        __syncthreads();
-        if (s_ticket != gridDim.x - 1) return;              // (workgroup-uniform)
-        __threadfence();                                    // the other workgroups' partial blocks
-        // ---- reduction, in the order of em_reduce_kernel (em_mstats.hip): 8 outputs per pass, each summed by 32 threads over
-        // the block slices b = s, s + 32, ... (ascending), the 32 slice sums added in ascending s -- the same bits
-        const int total = K * F, nb = (int)gridDim.x;
-        double* buf = smem;                                 // (the tiles are done with)
-        for (int e0 = 0; e0 < total; e0 += 8) {
-            const int o = tid & 7, sl = tid >> 3, e = e0 + o;
-            double s = 0.0;
-            if (e < total) {
-                const int k = e / F, f = e - k * F;
-                const double* p = partials + (size_t)k * FP + f;
-                for (int b = sl; b < nb; b += 32) s += p[(size_t)b * KP * FP];
-            }
-            buf[tid] = s;
-            __syncthreads();
-            if (sl == 0 && e < total) {
-                double t = buf[o];
-#pragma unroll
-                for (int q = 1; q < 32; ++q) t += buf[q * 8 + o];
-                tail.stats[e] = t;
-            }
-            __syncthreads();
-        }
-        {   // log-likelihood partials: the fixed-order tree of em_reduce_kernel's extra block
-            double s = 0.0;
-            for (int b = tid; b < nb; b += 256) s += ll_partials[b];
-            buf[tid] = s;
-            __syncthreads();
-            for (int off = 128; off > 0; off >>= 1) {
-                if (tid < off) buf[tid] += buf[tid + off];
-                __syncthreads();
-            }
-            if (tid == 0) { tail.stats[total] = buf[0]; *tail.counter = 0u; }   // (the counter is ready for the next launch)
-        }
-        __threadfence();                                    // the statistics are read back from memory by the closing waves
-        __syncthreads();
-        // ---- closing arithmetic, one wave per component, the four waves taking turns (em_close_body.hpp)
-        double* sm = smem + (size_t)wave * closing::scratch_doubles(d);
-        for (int k = wave; k < K; k += 4)
-            closing::close_component<0, D>(tail.stats, K, d, D, shift, tail.n_global, tail.refine_limit, tail.mixing, tail.means,
-                                           tail.covs, tail.records, PS, tail.info, k, lane, sm);
-    }
 }
 
 /// FEW components in FEW dimensions (K F <= 64 numbers, F = (d+1)(d+2)/2: the reference's own benchmark regime, d = 2, K = 3,
 /// Benchmarks/bm_EM.cpp): the statistics on the VECTOR unit. The matrix-core form above pads K to 16 rows and F to 16 columns of a
 /// 16 x 16 x 4 product -- at d = 2, K = 8 five of six matrix-pipe cycles multiply padding (1 200 cycles per 64 samples for
-/// 6 144 flops), behind an LDS round trip of r and x~. Here every lane keeps K F accumulators in registers,
-///     acc[k][f] += r_ik phi_f(x~_i),   phi = vech([x~ ; 1][x~ ; 1]^T)   (K F fused multiply-adds per sample),
-/// over all its samples, and the lanes are summed ONCE at the end of the kernel (halving exchanges over the wave, see the epilogue;
-/// the four waves in order through LDS): no tiles, no barriers, no matrix instructions in the loop. The densities come from scalar registers as in
-/// em_estep.hip (the records are wave-uniform). Same partial-block layout as the kernel above: the reduction and closing kernels are
-/// shared. Sums are formed per lane, then across lanes: fixed order, reproducible, equal to the matrix-core form to rounding.
-/// (a, b) -> one value per lane: the lower half of the lanes (of the wave: BIT5; of every 32 lanes: the even 16-lane row) gets
-/// a_l + a_partner, the upper half b_partner + b_l, partner = l ^ 32 (l ^ 16). v_permlane32_swap (v_permlane16_swap) exchanges the
-/// upper half of its first operand with the lower half of its second; no LDS traffic.
-template <bool BIT5> __device__ __forceinline__ double halves_fold(double a, double b)
-{
-    const unsigned al = __double2loint(a), ah = __double2hiint(a), bl = __double2loint(b), bh = __double2hiint(b);
-    if constexpr (BIT5) {
-        const auto l = __builtin_amdgcn_permlane32_swap(al, bl, false, false);
-        const auto h = __builtin_amdgcn_permlane32_swap(ah, bh, false, false);
-        return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
-    } else {
-        const auto l = __builtin_amdgcn_permlane16_swap(al, bl, false, false);
-        const auto h = __builtin_amdgcn_permlane16_swap(ah, bh, false, false);
-        return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
-    }
-}
-
+/// 6 144 flops), behind an LDS round trip of r and x~. Here every lane keeps K F accumulators in registers over all its samples and
+/// the lanes are summed ONCE at the end of the kernel: no tiles, no barriers, no matrix instructions in the loop
+/// (em_fused_valu_body.hpp: the pass itself, shared with the device-resident loop of em_resident.hip). The densities come from
+/// scalar registers as in em_estep.hip (the records are wave-uniform). Same partial-block layout as the kernel above: the reduction
+/// and closing kernels are shared. Sums are formed per lane, then across lanes: fixed order, reproducible, equal to the matrix-core
+/// form to rounding.
 template <int D, int K>
 __global__ __launch_bounds__(256) void em_fused_valu_kernel(
     const double* __restrict__ xt, size_t ldx, uint32_t n, const double* __restrict__ shift, const double* __restrict__ params,
     double* __restrict__ lse_out, double* __restrict__ partials, int KP, int FP, double* __restrict__ ll_partials)
 {
-    constexpr int PS = D + D * (D + 1) / 2 + 1;               // estep_param_stride(D)
-    constexpr int DA = D + 1, F = DA * (DA + 1) / 2;
-    constexpr int V = K * F, VP = (V + 3) / 4 * 4;             // accumulators per lane, padded for the two halving steps of the epilogue
+    using S = ValuShape<D, K>;
+    constexpr int F = S::F, VP = S::VP;
     __shared__ double fold[4][VP];
     __shared__ double red[4];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -308,96 +236,13 @@ __global__ __launch_bounds__(256) void em_fused_valu_kernel(
 #pragma unroll
     for (int e = 0; e < VP; ++e) acc[e] = 0.0;
     double ll_acc = 0.0;
-    const uint32_t n_tiles = (n + TS - 1) / TS;
-    const uint32_t stride = gridDim.x * 4;
     double xn[D];                                             // the NEXT tile's sample, in flight while this one is worked on
     {
-        const uint32_t t0 = blockIdx.x * 4 + wave;
-        const uint32_t i0 = (t0 < n_tiles ? t0 : 0) * TS + lane;
-#pragma unroll
-        for (int j = 0; j < D; ++j) xn[j] = xt[(size_t)j * ldx + i0];
+        const uint32_t n_tiles = (n + TS - 1) / TS, t0 = blockIdx.x * 4 + wave;
+        valu_load_tile<D>(xt, ldx, t0 < n_tiles ? t0 : 0, lane, xn);
     }
-    for (uint32_t tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += stride) {
-        const uint32_t i = tile * TS + lane;                  // < n_pad: inside the allocation
-        const bool live = i < n;
-        double x[D];
-#pragma unroll
-        for (int j = 0; j < D; ++j) x[j] = xn[j];
-        {
-            const uint32_t tn = tile + stride < n_tiles ? tile + stride : tile;
-#pragma unroll
-            for (int j = 0; j < D; ++j) xn[j] = xt[(size_t)j * ldx + (size_t)tn * TS + lane];
-        }
-        // ---- log-densities (em_estep.hip's arithmetic: z = x - mu, y = W z, lw = coef - |y|^2 / 2), records from scalar registers
-        double lwv[K];
-        double m = -__builtin_inf();
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            {
-                const double* __restrict__ p = params + (size_t)k * PS;
-                double z[D];
-#pragma unroll
-                for (int j = 0; j < D; ++j) z[j] = x[j] - p[j];
-                const double* __restrict__ w = p + D;
-                double q = 0.0;
-#pragma unroll
-                for (int j = 0; j < D; ++j) {
-                    double y = w[j * (j + 1) / 2] * z[0];
-#pragma unroll
-                    for (int l = 1; l <= j; ++l) y = __builtin_fma(w[j * (j + 1) / 2 + l], z[l], y);
-                    q = __builtin_fma(y, y, q);
-                }
-                const double lw = __builtin_fma(-0.5, q, p[PS - 1]);
-                lwv[k] = lw;
-                m = lw > m ? lw : m;
-            }
-        }
-        // ---- normalisation: one exp per (sample, component), the K polynomial chains side by side (exp_nonpos.hpp)
-#pragma unroll
-        for (int k = 0; k < K; ++k) lwv[k] -= m;
-        exp_nonpos_n<K>(lwv);
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < K; ++k) s += lwv[k];
-        const double lse = m + log(s);
-        lse_out[i] = lse;
-        if (live) ll_acc += lse;
-        const double inv = live ? 1.0 / s : 0.0;              // padding samples contribute nothing
-        // ---- statistics: phi_(a, b) = x~_a x~_b, a >= b, x~ = [x - shift ; 1], packed at a (a + 1) / 2 + b
-        double xs[DA];
-#pragma unroll
-        for (int j = 0; j < D; ++j) xs[j] = x[j] - shift[j];
-        xs[D] = 1.0;
-        double phi[F];
-#pragma unroll
-        for (int a = 0; a < DA; ++a)
-#pragma unroll
-            for (int b = 0; b <= a; ++b) phi[a * (a + 1) / 2 + b] = a == D ? xs[b] : xs[a] * xs[b];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const double r = lwv[k] * inv;
-#pragma unroll
-            for (int f = 0; f < F; ++f) acc[k * F + f] = __builtin_fma(r, phi[f], acc[k * F + f]);
-        }
-    }
-    // ---- epilogue: the 64 lanes of every accumulator, summed in a fixed order. A plain butterfly moves 6 V values per wave through
-    // the LDS pipe (ds_bpermute; 8 us of a 26 us iteration at K F = 48). Instead the first two steps HALVE the values a lane holds:
-    // lanes 0-31 take accumulators [0, VP / 2) of both halves of the wave, lanes 32-63 the rest (one v_permlane32_swap per word and
-    // one addition per PAIR), then the same between the 16-lane rows; what is left is VP / 4 values over 16 lanes.
-#pragma unroll
-    for (int e = 0; e < VP / 2; ++e) acc[e] = halves_fold<true>(acc[e], acc[e + VP / 2]);
-#pragma unroll
-    for (int e = 0; e < VP / 4; ++e) acc[e] = halves_fold<false>(acc[e], acc[e + VP / 4]);
-#pragma unroll
-    for (int e = 0; e < VP / 4; ++e) {
-        double v = acc[e];
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if ((lane & 15) == 0) fold[wave][e + (lane >> 4) * (VP / 4)] = v;      // row r of the wave holds accumulators r VP / 4 + e
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ll_acc += __shfl_down(ll_acc, off, 64);
-    if (lane == 0) red[wave] = ll_acc;
+    valu_tiles<D, K>(xt, ldx, n, shift, params, lse_out, blockIdx.x, gridDim.x, wave, lane, xn, acc, ll_acc);
+    valu_fold<VP>(acc, ll_acc, wave, lane, fold, red);
     __syncthreads();
     double* out = partials + (size_t)blockIdx.x * KP * FP;
     for (int e = tid; e < K * F; e += 256) {
@@ -407,19 +252,14 @@ __global__ __launch_bounds__(256) void em_fused_valu_kernel(
     if (tid == 0) ll_partials[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
-/// Largest K the vector-unit form is built for at dimension d (K F <= ~100 accumulators per lane); 0: not built for d.
-constexpr int valu_max_k(int D) { return D == 1 ? 32 : D == 2 ? 16 : D == 3 ? 10 : D == 4 ? 7 : D == 6 ? 4 : 0; }
-
-template <int D, int RBW, int CB, bool TAIL, bool SFEED = false>
-int launch_t(const FusedArgs& a, const FusedTail& t, int grid, hipStream_t stream)
+template <int D, int RBW, int CB, bool SFEED = false>
+int launch_t(const FusedArgs& a, int grid, hipStream_t stream)
 {
     constexpr int PS = D + D * (D + 1) / 2 + 1;
     constexpr int XSS = xss<D>();
     const size_t smem = sizeof(double) * (4 * ((size_t)TS * XSS + (size_t)TS * RSS) + (SFEED ? 0 : (size_t)16 * RBW * PS));
-    static_assert(4 * ((size_t)TS * XSS + (size_t)TS * RSS) >= 256 && 4 * ((size_t)TS * XSS + (size_t)TS * RSS) >= 4 * closing::scratch_doubles(D),
-                  "the tail reuses the tiles' LDS");
-    hipLaunchKernelGGL((em_fused_small_kernel<D, RBW, CB, TAIL, SFEED>), dim3(grid), dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d, a.shift,
-                       a.params, a.K, stats_count(a.d), a.lse, a.partials, RBW * 16, CB * 16, a.ll_partials, t);
+    hipLaunchKernelGGL((em_fused_small_kernel<D, RBW, CB, SFEED>), dim3(grid), dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d, a.shift,
+                       a.params, a.K, stats_count(a.d), a.lse, a.partials, RBW * 16, CB * 16, a.ll_partials);
     return grid;
 }
 
@@ -427,7 +267,7 @@ int launch_t(const FusedArgs& a, const FusedTail& t, int grid, hipStream_t strea
 /// always (no LDS-fed form is built there); d >= 3 from 2^19 samples on (N = 8.4M: d = 6, K = 32 1.32 -> 1.04 ms, d = 4, K = 16
 /// 0.416 -> 0.371 ms, d = 3, K = 16 0.346 -> 0.336 ms; below, with one or two tiles per wave, the scalar-load latency of every
 /// record row is exposed: 1 - 6 us slower) ; d = 1, 2: LDS (0.97 against 1.04 ms at d = 1, K = 64). MLHIP_FUSED_SFEED=0 / 1 forces
-/// one feed for d <= 6 (A/B runs; the tail form keeps the LDS feed).
+/// one feed for d <= 6 (A/B runs).
 template <int D> bool scalar_feed(uint32_t n)
 {
     if constexpr (D >= 8) return true;
@@ -436,67 +276,51 @@ template <int D> bool scalar_feed(uint32_t n)
     return D >= 3 && n >= (1u << 19);
 }
 
-template <int D, int CB, bool TAIL>
-int launch_d(const FusedArgs& a, const FusedTail& t, int grid, hipStream_t stream)
+template <int D, int CB>
+int launch_d(const FusedArgs& a, int grid, hipStream_t stream)
 {
     const int RB = (a.K + 15) / 16;
-    if constexpr (!TAIL) {
-        if (scalar_feed<D>(a.n)) {
-            if (RB == 1) return launch_t<D, 1, CB, false, true>(a, t, grid, stream);
-            if (RB == 2) return launch_t<D, 2, CB, false, true>(a, t, grid, stream);
-            if constexpr (CB == 1) { if (RB <= 4) return launch_t<D, 4, CB, false, true>(a, t, grid, stream); }
-            return -1;
-        }
+    if (scalar_feed<D>(a.n)) {
+        if (RB == 1) return launch_t<D, 1, CB, true>(a, grid, stream);
+        if (RB == 2) return launch_t<D, 2, CB, true>(a, grid, stream);
+        if constexpr (CB == 1) { if (RB <= 4) return launch_t<D, 4, CB, true>(a, grid, stream); }
+        return -1;
     }
     if constexpr (D < 8) {
-        if (RB == 1) return launch_t<D, 1, CB, TAIL>(a, t, grid, stream);
-        if constexpr (!TAIL) {
-            if (RB == 2) return launch_t<D, 2, CB, false>(a, t, grid, stream);
-            if constexpr (CB == 1) { if (RB <= 4) return launch_t<D, 4, CB, false>(a, t, grid, stream); }
-        }
+        if (RB == 1) return launch_t<D, 1, CB>(a, grid, stream);
+        if (RB == 2) return launch_t<D, 2, CB>(a, grid, stream);
+        if constexpr (CB == 1) { if (RB <= 4) return launch_t<D, 4, CB>(a, grid, stream); }
     }
     return -1;
 }
 
-}  // namespace
-
-/// Shapes the fused kernel is used for: d <= 8 with K <= 32, d <= 4 with K <= 64 (the K densities and the
-/// accumulator tiles must fit the register file).
-bool em_fused_supported(int d, int K)
+/// Workgroups the vector-unit form is launched with before the cut to what a CU's registers hold (launch_valu_k): one per four
+/// tiles, at most 8 per CU, the capacity of the partial-block scratch.
+int valu_grid_uncut(const FusedArgs& a, int num_cus)
 {
-    if (d < 1 || d > 8 || K < 1) return false;       // (d = 7, 8: with the records from scalar registers, see the kernel)
-    const int RB = (K + 15) / 16, CB = (stats_count(d) + 15) / 16;
-    return RB <= 2 || (RB <= 4 && CB == 1);
+    const uint32_t n_tiles = (a.n + TS - 1) / TS;
+    int grid = 8 * num_cus;
+    if ((uint32_t)grid * 4 > n_tiles) grid = (int)((n_tiles + 3) / 4);
+    if (grid < 1) grid = 1;
+    if (grid > a.n_ll_partials) grid = a.n_ll_partials;
+    const size_t block = (size_t)em_fused_partial_rows(a.K) * em_fused_partial_cols(a.d);
+    if ((size_t)grid * block > a.partials_capacity) grid = (int)(a.partials_capacity / block);
+    return grid;
 }
 
-int em_fused_partial_rows(int K) { const int RB = (K + 15) / 16; return (RB == 1 ? 1 : RB == 2 ? 2 : 4) * 16; }
-int em_fused_partial_cols(int d) { return ((stats_count(d) + 15) / 16) * 16; }
-
-namespace {
-template <bool TAIL> int launch_fused(const FusedArgs& a, const FusedTail& t, int num_cus, hipStream_t stream);
-}
-
-/// Returns the number of per-workgroup partial blocks written (stats and log-likelihood alike), or < 0.
-int launch_em_fused_small(const FusedArgs& a, int num_cus, hipStream_t stream) { return launch_fused<false>(a, FusedTail{}, num_cus, stream); }
-
-int launch_em_fused_small_tail(const FusedArgs& a, const FusedTail& t, int num_cus, hipStream_t stream)
-{
-    if (a.K > kFusedTailMaxK || a.d > kFusedTailMaxDim || !t.counter || !t.stats) return -1;
-    return launch_fused<true>(a, t, num_cus, stream);
-}
-
-namespace {
 template <int D, int K> void launch_valu_k(const FusedArgs& a, int num_cus, int& grid, hipStream_t stream)
 {
     if constexpr (K >= 1) {
         if (a.K == K) {
-            static const int per_cu = [] {                           // workgroups a CU holds (registers: 2 K F accumulator words per lane)
-                int nb = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, em_fused_valu_kernel<D, K>, 256, 0) != hipSuccess || nb < 1) nb = 2;
-                return nb > 8 ? 8 : nb;
-            }();
-            const int full = per_cu * num_cus;
-            if (grid > full) grid = full;
+            if (grid > num_cus) {                                    // (every instantiation holds at least one workgroup per CU)
+                static const int per_cu = [] {                       // workgroups a CU holds (registers: 2 K F accumulator words per lane)
+                    int nb = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, em_fused_valu_kernel<D, K>, 256, 0) != hipSuccess || nb < 1) nb = 2;
+                    return nb > 8 ? 8 : nb;
+                }();
+                const int full = per_cu * num_cus;
+                if (grid > full) grid = full;
+            }
             hipLaunchKernelGGL((em_fused_valu_kernel<D, K>), dim3(grid), dim3(256), 0, stream, a.xt, a.ldx, a.n, a.shift, a.params, a.lse,
                                a.partials, em_fused_partial_rows(a.K), em_fused_partial_cols(a.d), a.ll_partials);
         } else {
@@ -507,13 +331,7 @@ template <int D, int K> void launch_valu_k(const FusedArgs& a, int num_cus, int&
 
 template <int D> int launch_valu(const FusedArgs& a, int num_cus, hipStream_t stream)
 {
-    const uint32_t n_tiles = (a.n + TS - 1) / TS;
-    int grid = 8 * num_cus;                                          // (cut to what the registers of the instantiation allow, below)
-    if ((uint32_t)grid * 4 > n_tiles) grid = (int)((n_tiles + 3) / 4);
-    if (grid < 1) grid = 1;
-    if (grid > a.n_ll_partials) grid = a.n_ll_partials;
-    const size_t block = (size_t)em_fused_partial_rows(a.K) * em_fused_partial_cols(a.d);
-    if ((size_t)grid * block > a.partials_capacity) grid = (int)(a.partials_capacity / block);
+    int grid = valu_grid_uncut(a, num_cus);                          // (cut to what the registers of the instantiation allow, above)
     if (grid < 1) return -2;
     launch_valu_k<D, valu_max_k(D)>(a, num_cus, grid, stream);       // one instantiation per (d, K): the loops over components are
     return grid;                                                     // straight-line code, the records sit in scalar registers
@@ -534,19 +352,42 @@ bool valu_form_applies(const FusedArgs& a)
     return a.K * stats_count(a.d) <= 64 || a.n >= (1u << 20) || (e && e[0] == '2');     // (2: every shape it is built for -- tests)
 }
 
-template <bool TAIL> int launch_fused(const FusedArgs& a, const FusedTail& t, int num_cus, hipStream_t stream)
+}  // namespace
+
+/// Shapes the fused kernel is used for: d <= 8 with K <= 32, d <= 4 with K <= 64 (the K densities and the
+/// accumulator tiles must fit the register file).
+bool em_fused_supported(int d, int K)
+{
+    if (d < 1 || d > 8 || K < 1) return false;       // (d = 7, 8: with the records from scalar registers, see the kernel)
+    const int RB = (K + 15) / 16, CB = (stats_count(d) + 15) / 16;
+    return RB <= 2 || (RB <= 4 && CB == 1);
+}
+
+int em_fused_partial_rows(int K) { const int RB = (K + 15) / 16; return (RB == 1 ? 1 : RB == 2 ? 2 : 4) * 16; }
+int em_fused_partial_cols(int d) { return ((stats_count(d) + 15) / 16) * 16; }
+
+/// The grid the vector-unit form would be launched with for these arguments when that is at most one workgroup per CU (no
+/// register cut applies then); 0 when the shape takes another form or a larger grid. What the device-resident loop
+/// (em_resident.hip) needs to reproduce the partial blocks of this kernel.
+int em_fused_valu_small_grid(const FusedArgs& a, int num_cus)
+{
+    if (!em_fused_supported(a.d, a.K) || !valu_form_applies(a)) return 0;
+    const int grid = valu_grid_uncut(a, num_cus);
+    return grid >= 1 && grid <= num_cus ? grid : 0;
+}
+
+/// Returns the number of per-workgroup partial blocks written (stats and log-likelihood alike), or < 0.
+int launch_em_fused_small(const FusedArgs& a, int num_cus, hipStream_t stream)
 {
     if (!em_fused_supported(a.d, a.K)) return -1;
-    if constexpr (!TAIL) {
-        if (valu_form_applies(a)) {
-            switch (a.d) {
-            case 1: return launch_valu<1>(a, num_cus, stream);
-            case 2: return launch_valu<2>(a, num_cus, stream);
-            case 3: return launch_valu<3>(a, num_cus, stream);
-            case 4: return launch_valu<4>(a, num_cus, stream);
-            case 6: return launch_valu<6>(a, num_cus, stream);
-            default: break;
-            }
+    if (valu_form_applies(a)) {
+        switch (a.d) {
+        case 1: return launch_valu<1>(a, num_cus, stream);
+        case 2: return launch_valu<2>(a, num_cus, stream);
+        case 3: return launch_valu<3>(a, num_cus, stream);
+        case 4: return launch_valu<4>(a, num_cus, stream);
+        case 6: return launch_valu<6>(a, num_cus, stream);
+        default: break;
         }
     }
     const uint32_t n_tiles = (a.n + TS - 1) / TS;
@@ -559,16 +400,15 @@ template <bool TAIL> int launch_fused(const FusedArgs& a, const FusedTail& t, in
     if ((size_t)grid * block > a.partials_capacity) grid = (int)(a.partials_capacity / block);
     if (grid < 1) return -2;
     switch (padded_dim(a.d)) {
-    case 1: return launch_d<1, 1, TAIL>(a, t, grid, stream);
-    case 2: return launch_d<2, 1, TAIL>(a, t, grid, stream);
-    case 3: return launch_d<3, 1, TAIL>(a, t, grid, stream);
-    case 4: return launch_d<4, 1, TAIL>(a, t, grid, stream);
-    case 6: return launch_d<6, 2, TAIL>(a, t, grid, stream);
-    case 8: return launch_d<8, 3, TAIL>(a, t, grid, stream);
+    case 1: return launch_d<1, 1>(a, grid, stream);
+    case 2: return launch_d<2, 1>(a, grid, stream);
+    case 3: return launch_d<3, 1>(a, grid, stream);
+    case 4: return launch_d<4, 1>(a, grid, stream);
+    case 6: return launch_d<6, 2>(a, grid, stream);
+    case 8: return launch_d<8, 3>(a, grid, stream);
     default: return -1;
     }
 }
-}  // namespace
 
 }  // namespace mstats
 }  // namespace mlhip

@@ -5,9 +5,11 @@
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <functional>
 #include <vector>
 
 #include "../device/layout.hpp"
+#include "team.hpp"
 
 namespace mlhip {
 namespace host {
@@ -92,7 +94,7 @@ void process_covariance(int d, const double* cov, double* inverse, double* sqrt_
 namespace {
 /// Threads used for the K independent per-component d x d factorizations (serial section of an EM iteration: every
 /// microsecond here is paid by all GPUs of a row-sharded job). At most 8, and never more than this process's share of
-/// the host cores when several ranks run on one node (set_host_ranks): oversubscribed OpenMP teams spin against each other.
+/// the host cores when several ranks run on one node (set_host_ranks): oversubscribed teams only take turns on the same cores.
 std::atomic<int> g_host_threads{0};
 
 int resolve_host_threads(int local_ranks)
@@ -120,6 +122,25 @@ int host_threads()
         g_host_threads.store(t, std::memory_order_relaxed);
     }
     return t;
+}
+
+/// fn(k, L, W) for the K components, L and W two d x d scratch matrices of the thread that runs k: on this thread's team
+/// (host/team.hpp) when the K factorizations are worth waking it, else a plain loop. Every k is handled by exactly one thread and
+/// touches only its own outputs: the results do not depend on the number of threads.
+template <class Fn> void for_each_component(int K, int d, Fn&& fn)
+{
+    const int threads = worth_threads(K, d) ? host_threads() : 1;
+    if (threads <= 1 || K <= 1) {
+        std::vector<double> L((size_t)d * d), W((size_t)d * d);
+        for (int k = 0; k < K; ++k) fn(k, L, W);
+        return;
+    }
+    const std::function<void(int)> body = [&](int k) {
+        thread_local std::vector<double> L, W;                 // (grown once per worker, reused by every region)
+        if (L.size() < (size_t)d * d) { L.resize((size_t)d * d); W.resize((size_t)d * d); }
+        fn(k, L, W);
+    };
+    Team::mine().for_each(K, threads, body);
 }
 
 /// W = L^-1 (lower triangular, column-major d x d) and sum_j log L_jj for one covariance.
@@ -199,12 +220,8 @@ bool build_estep_params_mfma4(int d, int D, int K, const double* mixing, const d
     const int NB = estep_mfma4_block_count(D);
     const int Q = D / 4;
     std::vector<double> folded(shift ? (size_t)K * d : 0);     // c_k = W_k (mu_k - shift)
-    double biggest = 0.0;
-#pragma omp parallel num_threads(host_threads()) if (worth_threads(K, d))
-    {
-    std::vector<double> L((size_t)d * d), W((size_t)d * d);
-#pragma omp for schedule(static) reduction(max : biggest)
-    for (int k = 0; k < K; ++k) {
+    std::vector<double> biggest_of((size_t)K, 0.0);            // per component; the maximum below is order-independent
+    for_each_component(K, d, [&](int k, std::vector<double>& L, std::vector<double>& W) {
         double* rec = records + (size_t)k * PS;
         for (int i = 0; i < PS; ++i) rec[i] = 0.0;
         const double log_det_half = whitening_matrix(d, covariances + (size_t)k * d * d, L, W);
@@ -219,6 +236,7 @@ bool build_estep_params_mfma4(int d, int D, int K, const double* mixing, const d
         for (int j = 0; j < d; ++j) rec[NB * 16 + j] = means[(size_t)k * d + j];
         rec[NB * 16 + 2 * D] = std::log(mixing[k]) - log_det_half;
         if (shift) {
+            double biggest = 0.0;
             for (int row = 0; row < d; ++row) {
                 double c = 0.0;
                 for (int col = 0; col <= row; ++col) c += W[col * d + row] * (means[(size_t)k * d + col] - shift[col]);
@@ -226,9 +244,11 @@ bool build_estep_params_mfma4(int d, int D, int K, const double* mixing, const d
                 const double a = std::fabs(c);
                 if (a > biggest) biggest = a;
             }
+            biggest_of[k] = biggest;
         }
-    }
-    }
+    });
+    double biggest = 0.0;
+    for (int k = 0; k < K; ++k) biggest = biggest_of[k] > biggest ? biggest_of[k] : biggest;
     if (!shift) return false;
     // the accumulator initialiser of the FOLD form (sign flipped); usable while every entry is small and finite
     bool finite = true;
@@ -246,11 +266,7 @@ void build_estep_params(int d, int D, int K, const double* mixing, const double*
     const size_t PS = (size_t)D + (size_t)D * (D + 1) / 2 + 1;       // estep_param_stride(D)
     // (this layout also serves d > 128, where a factorization is milliseconds: the K of them on the host's threads, like the
     // builders above)
-#pragma omp parallel num_threads(host_threads()) if (worth_threads(K, d))
-    {
-    std::vector<double> L((size_t)d * d), W((size_t)d * d);
-#pragma omp for schedule(static)
-    for (int k = 0; k < K; ++k) {
+    for_each_component(K, d, [&](int k, std::vector<double>& L, std::vector<double>& W) {
         double* rec = records + (size_t)k * PS;
         for (size_t i = 0; i < PS; ++i) rec[i] = 0.0;
         for (int j = 0; j < d; ++j) rec[j] = means[(size_t)k * d + j];
@@ -259,19 +275,14 @@ void build_estep_params(int d, int D, int K, const double* mixing, const double*
         for (int l = 0; l < d; ++l)                                   // (column l of W is contiguous: read it once, scatter into the rows)
             for (int j = l; j < d; ++j) w[(size_t)j * (j + 1) / 2 + l] = W[(size_t)l * d + j];
         rec[PS - 1] = std::log(mixing[k]) - log_det_half;
-    }
-    }
+    });
 }
 
 void finalize_mstep(int d, int K, const double* stats, const double* shift, double n_global, double* mixing,
                     double* means, double* covariances)
 {
     const int F = stats_count(d);
-#pragma omp parallel num_threads(host_threads()) if (worth_threads(K, d))
-    {
-    std::vector<double> m(d);
-#pragma omp for schedule(static)
-    for (int k = 0; k < K; ++k) {
+    for_each_component(K, d, [&](int k, std::vector<double>& m, std::vector<double>&) {   // (m: d of the d x d scratch doubles)
         const double* s = stats + (size_t)k * F;
         const double s0 = s[stats_index(d, d)];
         for (int a = 0; a < d; ++a) {
@@ -288,8 +299,7 @@ void finalize_mstep(int d, int K, const double* stats, const double* shift, doub
         static constexpr double epsilon = 1e-15;   // ML/EM.cpp:252
         for (int a = 0; a < d; ++a) cov[a * d + a] += epsilon;
         mixing[k] = s0 / n_global;                 // ML/EM.cpp:257
-    }
-    }
+    });
 }
 
 void build_diag_params(int d, int D, int K, int K_padded, const double* mixing, const double* means, const double* variances,

@@ -7,7 +7,9 @@
 //                                 writes the new parameters into pack (i + 1) % 3 and the next records into ring slot (i + 1) % 3:
 //                                 the same indexing for every loop policy, no buffer swapping while the loop runs;
 //   * the loop policies        -- run_synchronous (launch, wait, test: every shape), run_lagged (iteration i + 1 is launched before
-//                                 the host looks at iteration i: short iterations), host_closing_loop (d > 64, MLHIP_DEVICE_CLOSE=0);
+//                                 the host looks at iteration i: short iterations), run_resident (the WHOLE loop in one launch of
+//                                 resident workgroups, em_resident.hip: fits whose iteration is a few microseconds),
+//                                 host_closing_loop (d > 64, MLHIP_DEVICE_CLOSE=0);
 //   * close_on_host(i)         -- the one iteration a refinement flag (far, tight component) sends through the per-step arithmetic.
 // finish() leaves the device state as the per-step entry points expect it (records of the LAST E-step in params_dev).
 #include "internal.hpp"
@@ -51,8 +53,8 @@ struct EmLoop {
     double *mixing, *means, *covs;              // the caller's arrays (start -> result)
     // ---- plan of an iteration
     bool fused = false, self_norm = false;
-    bool graphs = false;                        // MLHIP_GRAPH=1: an iteration's launches replayed from a captured HIP graph
-    bool one_launch = false;                    // tiny fits: the fused kernel's last workgroup also reduces and closes (FusedTail)
+    int resident_grid = 0;                      // > 0: the whole loop can run in one launch of this many resident workgroups
+    bool resident_gave_up = false;
     bool info_pinned = false;                   // full covariances: the closing kernel writes its info block into pinned host memory
     bool pack_pinned = false;                   // diagonal mode: its whole (small) pack lives there
     size_t n_cov = 0, F = 0, n_info = 0, n_pack = 0;
@@ -108,18 +110,13 @@ struct EmLoop {
         data->diag_step = diag;
         fused = !diag && data->estep_variant == 0 && fused_step_applies(data, K);
         self_norm = !diag && !fused && data->estep_variant == 2 && self_norm_applies(data, K);
-        // MLHIP_ONE_LAUNCH=1 (single rank, few components): the whole iteration in ONE launch -- measured SLOWER than the three
-        // launches (N=10k, d=4, K=3: 2.28 - 2.35 ms against 1.95 ms per 50-iteration fit on the same box: the last workgroup's
-        // serial reduction + closing cost more than the two dispatch gaps they save), so it is opt-in.
-        const char* one = std::getenv("MLHIP_ONE_LAUNCH");
-        one_launch = fused && !ctx->reduce_fn && K <= mstats::kFusedTailMaxK && data->d <= mstats::kFusedTailMaxDim && one && one[0] == '1';
-        // MLHIP_GRAPH=1 (single rank, the one-kernel E+M forms, timers off): the three launches of an iteration captured once per
-        // ring slot and replayed -- see launch(). Opt-in: measured in DESIGN.md section 9.
-        const char* gr = std::getenv("MLHIP_GRAPH");
-        graphs = (fused || diag) && !one_launch && !ctx->reduce_fn && !ctx->timing && gr && gr[0] == '1';
-        if (one_launch && !data->it_counter.p) {
-            data->it_counter.reserve(256);
-            HIP_CHECK(hipMemsetAsync(data->it_counter.p, 0, 256, ctx->stream));
+        // Single rank, a shape of the vector-unit E+M form with at most one workgroup per CU: the whole loop in one launch.
+        // MLHIP_RESIDENT=0: off.
+        resident_grid = 0;
+        if (fused && !ctx->reduce_fn && ctx->world_size <= 1 && env_allows("MLHIP_RESIDENT")) {
+            const FusedArgs fa = fused_args(rec[0]);
+            const int g = mstats::em_fused_valu_small_grid(fa, ctx->num_cus);
+            if (g > 0 && mstats::em_resident_supported(d, K, g, ctx->num_cus)) resident_grid = g;
         }
         fold_allowed = env_allows("MLHIP_ESTEP_FOLD");
         refine_limit = refine_ratio();
@@ -132,37 +129,6 @@ struct EmLoop {
     void launch(uint32_t i)
     {
         const int in = (int)(i % 3), out = (int)((i + 1) % 3);
-        if (one_launch) {
-            launch_in_one(in, out);
-            HIP_CHECK(hipEventRecord(data->it_event[out], ctx->stream));
-            launched = i + 1;
-            return;
-        }
-        mlhip_data::IterationGraph* cap = nullptr;
-        if (graphs) {
-            mlhip_data::IterationGraph& g = data->it_graph[in];
-            const void* key[5] = {rec[in]->p, rec[out]->p, pack_base(out), data->it_info_slot[out].p, data->xt.p};
-            const double scalars[3] = {(double)K * (diag ? -1.0 : 1.0), (double)data->n, refine_limit};
-            if (g.exec && std::equal(key, key + 5, g.key) && std::equal(scalars, scalars + 3, g.scalars)) {
-                HIP_CHECK(hipGraphLaunch(g.exec, ctx->stream));
-                data->n_ll = g.grid;                                  // (what the launchers leave behind on the host side)
-                data->have_estep = true;
-                data->lw_valid = false;
-                if (!diag) { data->stats_mode = kFromLogResp; data->stats_resp = data->lw.as<double>(); data->stats_ld = data->ldr; }
-                HIP_CHECK(hipEventRecord(data->it_event[out], ctx->stream));
-                launched = i + 1;
-                return;
-            }
-            g.release();
-            std::copy(key, key + 5, g.key);
-            std::copy(scalars, scalars + 3, g.scalars);
-            HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
-            cap = &g;
-        }
-        struct CaptureGuard {                                        // a launcher that throws must not leave the stream capturing
-            hipStream_t stream; bool armed;
-            ~CaptureGuard() { if (armed) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(stream, &g); if (g) (void)hipGraphDestroy(g); } }
-        } guard{ctx->stream, cap != nullptr};
         if (diag) {
             run_diag_kernel(data, K, data->shift_dev.as<double>(), false, rec[in]);
         } else if (fused) {
@@ -186,50 +152,117 @@ struct EmLoop {
         if (!info_pinned && !pack_pinned)
             HIP_CHECK(hipMemcpyAsync(data->it_info_slot[out].p, data->it_pack[out].p, sizeof(double) * (diag ? n_pack : n_info),
                                      hipMemcpyDeviceToHost, ctx->stream));
-        if (cap) {
-            hipGraph_t graph = nullptr;
-            guard.armed = false;
-            HIP_CHECK(hipStreamEndCapture(ctx->stream, &graph));
-            const hipError_t e = hipGraphInstantiate(&cap->exec, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            if (e != hipSuccess) { cap->exec = nullptr; throw std::runtime_error("hipGraphInstantiate failed"); }
-            cap->grid = data->n_ll;
-            HIP_CHECK(hipGraphLaunch(cap->exec, ctx->stream));
-        }
         HIP_CHECK(hipEventRecord(data->it_event[out], ctx->stream));
         launched = i + 1;
     }
 
-    /// The same iteration as ONE launch (em_fused_small.hip, TAIL): E-step + statistics, and in the workgroup that finishes last
-    /// the reduction of the partial blocks and the closing arithmetic. Leaves what the three launches leave: statistics in
-    /// stats_dev, parameters in pack `out`, records in ring slot `out`, the info block on its way to the host.
-    void launch_in_one(int in, int out)
+    /// The fused kernel's arguments on the records of `records` (launch_fused_step builds the same).
+    FusedArgs fused_args(const DevBuf* records) const
     {
         FusedArgs a{};
         a.xt = data->xt.as<double>(); a.ldx = data->ldx; a.n = data->n; a.d = d;
-        a.shift = data->shift_dev.as<double>(); a.params = rec[in]->as<double>(); a.K = K;
+        a.shift = data->shift_dev.as<double>(); a.params = records->as<double>(); a.K = K;
         a.lse = data->lse.as<double>();
         a.partials = data->partials.as<double>(); a.partials_capacity = data->partials.bytes / sizeof(double);
         a.ll_partials = data->ll_partials.as<double>(); a.n_ll_partials = kMaxLlPartials;
-        FusedTail t{};
-        t.counter = data->it_counter.as<unsigned>(); t.stats = data->stats_dev.as<double>();
-        t.n_global = (double)data->n_global; t.refine_limit = refine_limit;
-        t.mixing = pack_mixing(out); t.means = pack_means(out); t.covs = pack_covs(out);
-        t.records = rec[out]->as<double>();
-        t.info = info_pinned ? data->it_info_slot[out].as<double>() : pack_base(out);
-        int grid = 0;
-        ctx->timed("em_fused", [&] { grid = mstats::launch_em_fused_small_tail(a, t, ctx->num_cus, ctx->stream); });
-        if (grid <= 0) throw std::runtime_error("fused EM kernel launch failed");
+        return a;
+    }
+
+    /// Resident policy (em_resident.hip): ONE launch runs the iterations 0 .. until the convergence test of ML/EM.cpp:161-168 fires
+    /// on the device, max_steps is reached or a refinement flag comes up; the host waits once and reads [status, iterations, converged]
+    /// and the log-likelihood history from pinned memory. The kernel evaluates the same pass, sums and closing arithmetic as the
+    /// three launches of launch(), so everything it leaves in the ring is bit for bit what they leave. Returns true when the loop is
+    /// over; false when the synchronous policy has to take over at iteration *resume_at (a refinement flag there -- or, with
+    /// *resume_at = 0 and nothing consumed, a wait inside the kernel that gave up: the GPU was not ours alone).
+    bool run_resident(ConvergenceTest& test, uint32_t max_steps, uint32_t* resume_at)
+    {
+        const size_t head = 4;                                           // result words (as doubles' worth of space), then the history
+        data->it_history.reserve(sizeof(double) * (head + max_steps));
+        data->it_sync.reserve(256);
+        data->it_xch.reserve(sizeof(double) * mstats::em_resident_exchange_doubles(d, K, resident_grid));
+        uint32_t* result = data->it_history.as<uint32_t>();
+        double* history = data->it_history.as<double>() + head;
+        result[0] = result[1] = result[2] = 0;
+        HIP_CHECK(hipMemsetAsync(data->it_sync.p, 0, 256, ctx->stream));
+        // (the exchanged values carry their iteration's number as a tag, counted from 1 in every launch: no left-over of an earlier fit may look valid)
+        HIP_CHECK(hipMemsetAsync(data->it_xch.p, 0, sizeof(double) * mstats::em_resident_exchange_doubles(d, K, resident_grid), ctx->stream));
+        ResidentArgs a{};
+        a.xt = data->xt.as<double>(); a.ldx = data->ldx; a.n = data->n; a.d = d; a.K = K;
+        a.shift = data->shift_dev.as<double>();
+        for (int s = 0; s < 3; ++s) {
+            a.records[s] = rec[s]->as<double>();
+            a.info[s] = info_pinned ? data->it_info_slot[s].as<double>() : pack_base(s);
+            a.mixing[s] = pack_mixing(s); a.means[s] = pack_means(s); a.covs[s] = pack_covs(s);
+        }
+        a.xch = data->it_xch.as<double>(); a.sync = data->it_sync.as<unsigned>(); a.vgrid = resident_grid;
+        a.n_global = (double)data->n_global; a.refine_limit = refine_limit; a.atol = test.atol; a.rtol = test.rtol;
+        a.ll_offset = (double)d * log_two_pi() / 2;                       // (read(): the same expression)
+        a.max_steps = max_steps; a.history = history; a.result = result;
+        // MLHIP_RESIDENT_PROFILE=1: per-phase clock stamps of workgroup 0, averaged over the iterations, on stderr (diagnostic)
+        static const bool profile = [] { const char* e = std::getenv("MLHIP_RESIDENT_PROFILE"); return e && e[0] == '1'; }();
+        DevBuf stamps;
+        if (profile) {
+            stamps.reserve(sizeof(unsigned long long) * mstats::kResidentStamps * max_steps);
+            HIP_CHECK(hipMemsetAsync(stamps.p, 0, stamps.bytes, ctx->stream));
+            a.profile = stamps.as<unsigned long long>();
+        }
+        struct Release { DevBuf& b; ~Release() { b.release(); } } release_stamps{stamps};
+        bool ok = false;
+        ctx->timed("em_resident", [&] { ok = mstats::launch_em_resident(a, ctx->stream); });
+        if (!ok) throw std::runtime_error("resident EM kernel not instantiated for this shape");
         HIP_CHECK(hipGetLastError());
-        data->n_ll = grid;
+        ctx->sync();
+        const uint32_t status = result[0], evaluated = result[1];
+        if (profile && evaluated > 1 && evaluated <= max_steps) {
+            constexpr int NS = mstats::kResidentStamps;
+            std::vector<unsigned long long> t((size_t)NS * evaluated);
+            HIP_CHECK(hipMemcpy(t.data(), stamps.p, sizeof(unsigned long long) * t.size(), hipMemcpyDeviceToHost));
+            // (from, to) stamp slots of the named spans; slot 0 of the NEXT iteration closes the last one
+            struct Span { const char* name; int from, to; };
+            const Span spans[] = {{"pass", 0, 1}, {"  densities", 0, 8}, {"  exp+log+1/s", 8, 9}, {"  statistics", 9, 10}, {"  lane fold+barrier", 11, 1},
+                                  {"publish", 1, 2}, {"exchange (wait + gather)", 2, 4}, {"sums", 4, 5}, {"closing", 5, 6},
+                                  {"  statistics->cov", 5, 12}, {"  factorization", 12, 13}, {"  inverse", 13, 14}, {"  store L, W", 14, 15},
+                                  {"  log det", 15, 16}, {"  c, info", 16, 17}, {"  records+barrier", 17, 6}, {"outputs", 6, 7}};
+            std::string line;
+            char buf[96];
+            const double us = 0.01 / (evaluated - 1);                     // 100 MHz stamps; iteration 0 (cold loads) left out
+            for (const Span& sp : spans) {
+                double sum = 0;
+                for (uint32_t i = 1; i < evaluated; ++i) sum += (double)(long long)(t[(size_t)NS * i + sp.to] - t[(size_t)NS * i + sp.from]);
+                std::snprintf(buf, sizeof buf, "%s %.2f, ", sp.name, sum * us);
+                line += buf;
+            }
+            double whole = 0;
+            for (uint32_t i = 1; i < evaluated; ++i) whole += (double)(t[(size_t)NS * i] - t[(size_t)NS * (i - 1)]);
+            std::fprintf(stderr, "[mlhip] resident loop, N=%u d=%d K=%d grid=%d, us per iteration (thread 0 of workgroup 0): %siteration %.2f\n",
+                         data->n, d, K, resident_grid, line.c_str(), whole * us);
+        }
+        if (status == 3 || status == 0 || evaluated > max_steps) {          // a wait gave up (or nothing came back): the ordinary loop, from the start
+            *resume_at = 0;
+            launched = 0;
+            resident_gave_up = true;                                      // (the ring may hold later iterations' records by now)
+            return false;
+        }
+        data->n_ll = resident_grid;                                       // (what launch_fused_step leaves behind on the host side)
         data->have_estep = true;
         data->lw_valid = false;
         data->stats_mode = kFromLogResp;
         data->stats_resp = data->lw.as<double>();
         data->stats_ld = data->ldr;
-        if (!info_pinned)
-            HIP_CHECK(hipMemcpyAsync(data->it_info_slot[out].p, data->it_pack[out].p, sizeof(double) * n_info, hipMemcpyDeviceToHost,
-                                     ctx->stream));
+        for (uint32_t i = 0; i < evaluated; ++i) {                        // the host's own test over the history: the same decisions
+            const bool stopped = test(i, history[i]);
+            if (stopped != (status == 1 && i + 1 == evaluated && result[2] != 0))
+                throw std::runtime_error("resident EM loop: the device's convergence test disagrees with the host's");
+        }
+        launched = evaluated;
+        if (status == 2) {                                                // iteration `evaluated` flagged: run it again, closed on the host
+            if (evaluated > 0) fetch_parameters((int)(evaluated % 3));
+            *resume_at = evaluated;
+            return false;
+        }
+        fetch_parameters((int)(evaluated % 3));                           // P_(last + 1): the newest parameters
+        finish(evaluated - 1);
+        return true;
     }
 
     struct Verdict {
@@ -409,6 +442,12 @@ void em_iterate(mlhip_data* data, int K, bool diag, double* mixing, double* mean
         return;
     }
     uint32_t first = 0;
+    if (loop.resident_grid > 0) {
+        if (loop.run_resident(test, max_steps, &first)) return;
+        if (loop.resident_gave_up) loop.prepare();                        // records R_0 again, from the caller's (untouched) arrays
+        loop.run_synchronous(test, first, max_steps);
+        return;
+    }
     if (loop.lagged_applies(max_steps) && loop.run_lagged(test, max_steps, &first)) return;
     loop.run_synchronous(test, first, max_steps);
 }

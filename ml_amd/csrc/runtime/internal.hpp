@@ -358,18 +358,10 @@ struct mlhip_data {
     // mlhip_em_iterate (em_loop.cpp): parameters and the E-steps' records stay on the device between iterations, in a ring of three --
     // iteration i reads the records of slot i % 3 (params_dev / params_next / params_prev take turns) and writes pack and records
     // (i + 1) % 3; it_pack: [info (1 + 2K) | mixing (K) | means (K d) | covariances]; one pinned read-back slot and event per pack
-    DevBuf params_next, params_prev, it_pack[3], it_counter;   // it_counter: the workgroup ticket of the one-launch iteration
-    PinnedBuf it_info_slot[3];
+    DevBuf params_next, params_prev, it_pack[3];
+    DevBuf it_sync, it_xch;       // device-resident loop (em_resident.hip): arrival counter / give-up flag, exchange blocks
+    PinnedBuf it_info_slot[3], it_history;   // it_history: [result words | log-likelihood history] of the resident loop
     hipEvent_t it_event[3] = {nullptr, nullptr, nullptr};
-    /// One iteration's launches (E+M kernel, reduction, closing, info copy) captured as a HIP graph per ring slot and replayed while
-    /// the buffers and the shape it was captured on are the ones in use (em_loop.cpp, MLHIP_GRAPH=1).
-    struct IterationGraph {
-        hipGraphExec_t exec = nullptr;
-        const void* key[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-        double scalars[3] = {0, 0, 0};
-        int grid = 0;
-        void release() { if (exec) { (void)hipGraphExecDestroy(exec); exec = nullptr; } }
-    } it_graph[3];
     // source of the last statistics pass (for the per-component refinement pass)
     int stats_mode = 0;
     const double* stats_resp = nullptr;
@@ -388,9 +380,9 @@ struct mlhip_data {
     {
         for (DevBuf* b : {&xt, &shift_dev, &lw, &lse, &esum, &ll_partials, &params_dev, &partials, &stats_dev, &resp_dev,
                           &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_cent_next, &km_partials, &km_out, &km_mind, &km_probe, &km_scale, &km_cnorm, &km_xt_pad, &kpp_w, &kpp_scr,
-                          &refine_shift, &refine_stats, &params_next, &params_prev, &it_pack[0], &it_pack[1], &it_pack[2], &it_counter})
+                          &refine_shift, &refine_stats, &params_next, &params_prev, &it_pack[0], &it_pack[1], &it_pack[2], &it_sync, &it_xch})
             b->pool = pool;
-        for (PinnedBuf* b : {&params_host, &stats_host, &km_host, &it_info_slot[0], &it_info_slot[1], &it_info_slot[2]}) b->pool = pool;
+        for (PinnedBuf* b : {&params_host, &stats_host, &km_host, &it_info_slot[0], &it_info_slot[1], &it_info_slot[2], &it_history}) b->pool = pool;
     }
 
     ~mlhip_data()
@@ -398,12 +390,11 @@ struct mlhip_data {
         for (mlhip_data* p : parts) mlhip_data_free(p);
         for (DevBuf* b : {&xt, &shift_dev, &lw, &lse, &esum, &ll_partials, &params_dev, &partials, &stats_dev, &resp_dev,
                           &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_cent_next, &km_partials, &km_out, &km_mind, &km_probe, &km_scale, &km_cnorm, &km_xt_pad, &kpp_w, &kpp_scr,
-                          &refine_shift, &refine_stats, &params_next, &params_prev, &it_pack[0], &it_pack[1], &it_pack[2], &it_counter})
+                          &refine_shift, &refine_stats, &params_next, &params_prev, &it_pack[0], &it_pack[1], &it_pack[2], &it_sync, &it_xch})
             b->release();
         for (auto& sl : it_info_slot) sl.release();
         for (auto& e : it_event) if (e) (void)hipEventDestroy(e);
-        for (auto& g : it_graph) g.release();
-        params_host.release(); stats_host.release(); km_host.release();
+        params_host.release(); stats_host.release(); km_host.release(); it_history.release();
     }
 };
 

@@ -259,48 +259,3 @@ def test_kmeans_iterate_entered_again_after_convergence(ctx, d, K, n):
     inertia, changed = dt.kmeans_assign(a[4])
     assert changed == 0 and inertia == a[2]
     dt.close()
-
-
-@pytest.mark.parametrize("d,K,n", [(4, 3, 10000), (2, 8, 12000), (6, 5, 700), (3, 1, 5000)])
-def test_one_launch_iteration_gives_the_same_fit(ctx, d, K, n, monkeypatch):
-    """MLHIP_ONE_LAUNCH=1 (opt-in; measured slower): the fused kernel's last workgroup reduces the partial
-    blocks in the reduction kernel's order and runs the closing arithmetic of em_close_body.hpp -- bit for bit what the three
-    launches compute."""
-    from ml_amd import _lib
-    X, mu0, _, _ = _problem(d, K, n, 11 * d + K)
-    dt = _lib.Data(ctx, X)
-    _, cov = dt.sample_covariance()
-    pi0, S0 = np.full(K, 1.0 / K), np.stack([cov] * K)
-    monkeypatch.setenv("MLHIP_FUSED_VALU", "0")     # the one-launch form is the matrix-core kernel: compare with its three-launch form
-    ref = dt.em_iterate(pi0, mu0, S0, 25, atol=1e-10)
-    labels = dt.em_labels(K)
-    monkeypatch.setenv("MLHIP_ONE_LAUNCH", "1")
-    got = dt.em_iterate(pi0, mu0, S0, 25, atol=1e-10)
-    assert got[0] == ref[0] and got[1] == ref[1] and got[2] == ref[2]
-    assert np.array_equal(got[6], ref[6])
-    for a, b in zip(got[3:6], ref[3:6]):
-        assert np.array_equal(a, b)
-    assert np.array_equal(dt.em_labels(K), labels)
-    dt.close()
-
-
-@pytest.mark.parametrize("d,K,n,diagonal", [(4, 3, 10000, False), (8, 20, 30000, False), (16, 16, 20000, True)])
-def test_iteration_replayed_from_a_hip_graph_gives_the_same_fit(ctx, d, K, n, diagonal, monkeypatch):
-    """MLHIP_GRAPH=1 (opt-in; measured no faster): the launches of an iteration captured per ring slot and
-    replayed -- the same kernels on the same buffers, so the fit is bit for bit the one of the plain launches; a second call on the
-    same data replays (or re-captures when the ring's buffers changed places) and agrees too."""
-    from ml_amd import _lib
-    X, mu0, _, _ = _problem(d, K, n, 5 * d + K)
-    dt = _lib.Data(ctx, X)
-    _, cov = dt.sample_covariance()
-    pi0 = np.full(K, 1.0 / K)
-    S0 = np.stack([np.diag(cov).copy()] * K) if diagonal else np.stack([cov] * K)
-    ref = dt.em_iterate(pi0, mu0, S0, 30, atol=1e-10, diagonal=diagonal)
-    monkeypatch.setenv("MLHIP_GRAPH", "1")
-    for _ in range(2):
-        got = dt.em_iterate(pi0, mu0, S0, 30, atol=1e-10, diagonal=diagonal)
-        assert got[0] == ref[0] and got[1] == ref[1] and got[2] == ref[2]
-        assert np.array_equal(got[6], ref[6])
-        for a, b in zip(got[3:6], ref[3:6]):
-            assert np.array_equal(a, b)
-    dt.close()
