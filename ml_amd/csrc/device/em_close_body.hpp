@@ -1,8 +1,9 @@
 // The per-component closing arithmetic of the M-step as a device function, shared by em_close.hip (one wave per component, K
-// workgroups side by side) and em_fused_small.hip (the tail of the one-kernel iteration of tiny fits: the last workgroup to finish
-// closes the iteration). See em_close.hip for what it computes and why it mirrors the host's arithmetic statement by statement.
+// workgroups side by side) and em_resident.hip (the device-resident loop of short fits: every workgroup closes every iteration
+// itself). See em_close.hip for what it computes and why it mirrors the host's arithmetic statement by statement.
 #pragma once
 #include "device.hpp"
+#include "lane_ops.hpp"
 
 namespace mlhip {
 namespace closing {
@@ -28,9 +29,11 @@ __host__ __device__ constexpr size_t scratch_doubles(int d) { return (size_t)(d 
     } while (0)
 
 /// Component k, by the NT threads tid = 0 .. NT - 1 of one wave, with `sm` = scratch_doubles(d) doubles of LDS of their own.
-struct NoProbe { __device__ __forceinline__ void operator()(int) const {} };   // (diagnostic hook: see em_resident.hip)
-
-template <int LAYOUT, int DT, typename Probe = NoProbe>
+/// STATS_LOCAL: `stats` is LDS of the calling workgroup, written behind a workgroup barrier (the device-resident loop): read in
+/// place; otherwise (global memory: the closing kernel) the component's F sums are staged into LDS first.
+/// The order of the steps (and which of them share a lane barrier) is chosen for latency; every VALUE is formed by the host's
+/// operations on the host's operands, so the bits are the host's (host/em_math.cpp finalize_mstep).
+template <int LAYOUT, int DT, bool STATS_LOCAL = false, typename Probe = NoProbe>
 __device__ __forceinline__ void close_component(const double* __restrict__ stats, int K, int d, int D, const double* __restrict__ shift,
                                                 double n_global, double refine_limit, double* __restrict__ mixing,
                                                 double* __restrict__ means, double* __restrict__ covs, double* __restrict__ records,
@@ -39,54 +42,49 @@ __device__ __forceinline__ void close_component(const double* __restrict__ stats
 {
 #pragma clang fp contract(off)     // the host's closing arithmetic, statement by statement (em_close.hip)
     const int F = (d + 1) * (d + 2) / 2;
-    double* s = sm;                    // F statistics of this component
-    double* A = s + F;                 // d x d column-major: covariance, overwritten by its Cholesky factor (lower)
+    double* staged = sm;               // F statistics of this component (unless STATS_LOCAL)
+    double* A = staged + F;            // d x d column-major: covariance, overwritten by its Cholesky factor (lower)
     double* W = A + d * d;             // d x d column-major: L^-1 (lower)
-    double* m = W + d * d;             // d: S1'/S0
+    double* m = W + d * d;             // d: S1'/S0 (kept for readers of the scratch; the lanes below form the quotients they need themselves)
     double* mean = m + d;              // d
     double* c = mean + d;              // d: W (mean - shift)
-    double* tcol = c + d;              // d: column scratch of the factorization
+    double* tcol = c + d;              // d: column scratch of the factorization, then the d logarithms
     double& s_ljj = tcol[d];
     double& s_ldh = tcol[d + 1];
     double& s_mix = tcol[d + 2];
     int* codes = reinterpret_cast<int*>(tcol + d + 4);     // d ints
 
-    for (int e = tid; e < F; e += NT) s[e] = stats[(size_t)k * F + e];
-    MLHIP_CLOSE_SYNC();
+    const double* s = stats + (size_t)k * F;
+    if constexpr (!STATS_LOCAL) {
+        for (int e = tid; e < F; e += NT) staged[e] = s[e];
+        MLHIP_CLOSE_SYNC();
+        s = staged;
+    }
     const double s0 = s[sidx(d, d)];
     if (tid < d) {
-        m[tid] = s[sidx(d, tid)] / s0;
-        mean[tid] = shift[tid] + m[tid];
+        const double mt = s[sidx(d, tid)] / s0;
+        m[tid] = mt;
+        mean[tid] = shift[tid] + mt;
         means[(size_t)k * d + tid] = mean[tid];
     }
     const double mix = s0 / n_global;                                                // ML/EM.cpp:257 (every lane: the same value)
-    const double log_mix = log(mix);                                                 // (needed at the very end: its latency hides behind the factorization)
     if (tid == 0) { s_mix = mix; mixing[k] = mix; }
-    MLHIP_CLOSE_SYNC();
     for (int e = tid; e < d * d; e += NT) {
         const int a = e % d, b = e / d;                                              // element (a, b), column-major
         const int hi = a > b ? a : b, lo = a > b ? b : a;
-        double v = (s[sidx(hi, lo)] - s[sidx(d, hi)] * m[lo]) / s0;
+        const double mlo = s[sidx(d, lo)] / s0;                                      // = m[lo]: formed again here instead of fetched through LDS behind a barrier
+        double v = (s[sidx(hi, lo)] - s[sidx(d, hi)] * mlo) / s0;
         if (a == b) v += 1e-15;                                                      // ML/EM.cpp:252
         A[e] = v;
         covs[(size_t)k * d * d + e] = v;
     }
     MLHIP_CLOSE_SYNC();
-    // refinement criterion of the host path (mlhip_abi.cpp finalize_out): scanned in order, a non-finite entry ends the scan
+    // refinement criterion of the host path (runtime/em.cpp finalize_out); the codes are scanned further down, behind the next barrier
     if (tid < d) {
         const double off = mean[tid] - shift[tid], var = A[tid * d + tid];
         codes[tid] = (!isfinite(off) || !isfinite(var)) ? 2 : ((refine_limit > 0 && off * off > refine_limit * var) ? 1 : 0);
     }
-    MLHIP_CLOSE_SYNC();
-    if (tid == 0) {
-        int flag = 0;
-        if (s_mix > 0 && isfinite(s_mix))
-            for (int a = 0; a < d; ++a) {
-                if (codes[a] == 2) break;
-                if (codes[a] == 1) { flag = 1; break; }
-            }
-        info[1 + k] = flag;
-    }
+    double log_mix;                                                                  // log of the mixing weight: needed at the very end
 
     probe(12);
     // ---- Cholesky (host/em_math.cpp cholesky_lower) and W = L^-1 (whitening_matrix).
@@ -101,6 +99,7 @@ __device__ __forceinline__ void close_component(const double* __restrict__ stats
         double Li[DT];
 #pragma unroll
         for (int c0 = 0; c0 < DT; ++c0) Li[c0] = (tid < d && c0 < d) ? A[c0 * d + tid] : 0.0;   // A(tid, c0)
+        log_mix = log(mix);                                                              // (independent work for the stalls of the chain below)
 #pragma unroll
         for (int jj = 0; jj < DT; ++jj) {
             if (jj < d) {                                                                // (uniform)
@@ -155,37 +154,44 @@ __device__ __forceinline__ void close_component(const double* __restrict__ stats
                 W[col * d + ii] = t / A[ii * d + ii];
             }
         }
+        log_mix = log(mix);
     }
     probe(15);
     // sum_j log L_jj in the host's order (ascending j, one addition at a time) -- the d logarithms themselves side by side, one per
     // lane: evaluated one after the other by a single lane they were a third of this function's time (d = 4: 1.2 of 4.8 us; d = 32:
     // 32 dependent calls of ~0.25 us each)
     for (int j = tid; j < d; j += NT) tcol[j] = log(A[j * d + j]);
-    MLHIP_CLOSE_SYNC();
+    MLHIP_CLOSE_SYNC();                                                              // (W, the logarithms and the codes: visible to every lane)
+    probe(16);
     if (tid == 0) {
+        // scanned in order, a non-finite entry ends the scan
+        int flag = 0;
+        if (s_mix > 0 && isfinite(s_mix))
+            for (int a = 0; a < d; ++a) {
+                if (codes[a] == 2) break;
+                if (codes[a] == 1) { flag = 1; break; }
+            }
+        info[1 + k] = flag;
         double ldh = 0.0;
         for (int j = 0; j < d; ++j) ldh += tcol[j];
         s_ldh = ldh;
     }
-    MLHIP_CLOSE_SYNC();
-    probe(16);
-    if (tid < d) {
-        double acc = 0.0;
-        for (int col = 0; col <= tid; ++col) acc += W[col * d + tid] * (mean[col] - shift[col]);
-        c[tid] = acc;
-    }
-    MLHIP_CLOSE_SYNC();
-    if (tid == 0) {
-        double biggest = 0.0;
-        bool finite = true;
-        for (int j = 0; j < d; ++j) {
-            const double a = fabs(c[j]);
-            if (a > biggest) biggest = a;
-            finite = finite && isfinite(c[j]);
+    {
+        // c = W (mean - shift) and max_j |c_j| (infinite when an entry is not finite): the maximum over the lanes on the vector unit
+        double reach = 0.0;
+        if (tid < d) {
+            double acc = 0.0;
+            for (int col = 0; col <= tid; ++col) acc += W[col * d + tid] * (mean[col] - shift[col]);
+            c[tid] = acc;
+            reach = isfinite(acc) ? fabs(acc) : __builtin_inf();
         }
-        info[1 + K + k] = finite ? biggest : __builtin_inf();
-        if (k == 0) info[0] = stats[(size_t)K * F];                                  // the log-likelihood sum rides along
+        reach = wave_max_nonneg(reach);
+        if (tid == 0) {
+            info[1 + K + k] = reach;
+            if (k == 0) info[0] = stats[(size_t)K * F];                              // the log-likelihood sum rides along
+        }
     }
+    MLHIP_CLOSE_SYNC();
     probe(17);
     // ---- the next E-step's record
     double* rec = records + (size_t)k * PS;

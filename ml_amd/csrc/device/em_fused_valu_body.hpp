@@ -10,6 +10,7 @@
 #pragma once
 #include "em_mstats_common.hpp"
 #include "exp_nonpos.hpp"
+#include "lane_ops.hpp"
 
 namespace mlhip {
 namespace mstats {
@@ -30,10 +31,6 @@ template <bool BIT5> __device__ __forceinline__ double halves_fold(double a, dou
         return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
     }
 }
-
-/// Diagnostic hook of the device functions below and of em_close_body.hpp: `probe(slot)` marks a point in the instruction stream.
-/// The default does nothing and costs nothing; em_resident.hip passes one that stamps the clock (MLHIP_RESIDENT_PROFILE=1).
-struct NoProbe { __device__ __forceinline__ void operator()(int) const {} };
 
 template <int D, int K> struct ValuShape {
     static constexpr int PS = D + D * (D + 1) / 2 + 1;            // estep_param_stride(D)
@@ -124,24 +121,6 @@ __device__ __forceinline__ void valu_tiles(const double* __restrict__ xt, size_t
         }
         probe(10);
     }
-}
-
-/// Lane l <- lane l + OFF of its 16-lane row (OFF = 8, 4, 2, 1; lanes whose source lies beyond the row get 0.0): two DPP moves on the
-/// vector unit, a few cycles, where a ds_bpermute round trip through the LDS pipe is > 100.
-template <int OFF> __device__ __forceinline__ double row_shift_left(double v)
-{
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x100 + OFF, 0xf, 0xf, true);   // row_shl:OFF
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x100 + OFF, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-/// Lanes 0-31 <- lanes 32-63 (BIT5) / the even 16-lane rows <- the odd ones: v_permlane32_swap / v_permlane16_swap of v with itself.
-template <bool BIT5> __device__ __forceinline__ double upper_half(double v)
-{
-    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
-    if constexpr (BIT5)
-        return __hiloint2double((int)__builtin_amdgcn_permlane32_swap(hi, hi, false, false)[1], (int)__builtin_amdgcn_permlane32_swap(lo, lo, false, false)[1]);
-    else
-        return __hiloint2double((int)__builtin_amdgcn_permlane16_swap(hi, hi, false, false)[1], (int)__builtin_amdgcn_permlane16_swap(lo, lo, false, false)[1]);
 }
 
 /// The 64 lanes of every accumulator, summed in a fixed order, into row `wave` of fold[4][VP] (and the wave's log-likelihood sum

@@ -32,7 +32,6 @@ namespace mlhip {
 namespace mstats {
 namespace {
 
-typedef __attribute__((address_space(1))) unsigned long long gu64;   // relaxed agent-scope accesses: global_load / store_dwordx2 ... sc1
 typedef __attribute__((address_space(1))) unsigned gu32;
 typedef __attribute__((address_space(3))) const double lds_cdouble;
 
@@ -51,44 +50,52 @@ struct StampProbe {
     __device__ __forceinline__ void operator()(int slot) const { stamp(prof, i, slot, g, tid); }
 };
 
+/// One exchanged value: 16 bytes = two 8-byte granules {half of the double, tag}, written by ONE write-through (sc1) store and read
+/// by ONE sc1 load; a value is there when BOTH its granules carry the iteration's tag (each aligned 8-byte half arrives whole).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kAuxSc1 = 16;                                        // cache-policy bit of the raw buffer intrinsics: sc1
+__device__ __forceinline__ u32x4 tagged(double v, unsigned tag)
+{
+    return u32x4{(unsigned)__double2loint(v), tag, (unsigned)__double2hiint(v), tag};
+}
+
 /// Every workgroup's partial block of iteration `epoch - 1` -> vals[b * XS + e] in LDS. A thread takes the values p = tid, tid + 256,
-/// ... of the G XS exchanged ones; ALL its loads are issued before the first is looked at, and they are read again until every
-/// granule carries this iteration's tag: waiting for the other workgroups and gathering their sums is ONE round trip when they
-/// are on time. Returns false when the wait gave up (bounded spin, or another workgroup raised the flag).
+/// ... of the G XS exchanged ones (starting at byte `base` of the exchange buffer); ALL its loads are issued before the first is
+/// looked at, and they are read again until every granule carries this iteration's tag: waiting for the other workgroups and
+/// gathering their sums is ONE round trip (~0.9 us to the memory side and back: write-through stores leave no copy in any L2)
+/// when they are on time. (Two reads in flight a quarter of a microsecond apart, so that a value landing just behind the first is
+/// caught by the second, were measured SLOWER at 40 workgroups -- 3.9 against 2.3 us: the all-to-all read is G^2 blocks of
+/// uncached requests, and doubling them costs more than the saved wait.)
+/// Returns false when the wait gave up (bounded spin, or another workgroup raised the flag).
 template <int XS>
-__device__ __forceinline__ bool gather_blocks(const gu64* xb, uint32_t G, unsigned epoch, int tid, double* vals, gu32* give_up)
+__device__ __forceinline__ bool gather_blocks(__amdgpu_buffer_rsrc_t xch, unsigned base, uint32_t G, unsigned epoch, int tid, double* vals,
+                                              gu32* give_up)
 {
     constexpr int MAXP = (kResidentMaxGrid * XS + 255) / 256;      // values per thread at the largest grid
     const int total = (int)G * XS;
-    unsigned long long lo[MAXP], hi[MAXP];
+    u32x4 v[MAXP];
     unsigned spins = 0;
-    bool alive = true;
     for (;;) {
-        bool ok = true;
 #pragma unroll
         for (int j = 0; j < MAXP; ++j) {
             const int p = tid + 256 * j;
-            if (p < total) {
-                lo[j] = __hip_atomic_load(xb + 2 * (size_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                hi[j] = __hip_atomic_load(xb + 2 * (size_t)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (p < total) v[j] = __builtin_amdgcn_raw_buffer_load_b128(xch, base + 16u * (unsigned)p, 0, kAuxSc1);
         }
+        bool ok = true;
 #pragma unroll
         for (int j = 0; j < MAXP; ++j)
-            if (tid + 256 * j < total) ok = ok && (unsigned)(lo[j] >> 32) == epoch && (unsigned)(hi[j] >> 32) == epoch;
+            if (tid + 256 * j < total) ok = ok && v[j].y == epoch && v[j].w == epoch;
         if (ok) break;
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > kSpinLimit || ((spins & 255u) == 0 && __hip_atomic_load(give_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-            alive = false;
-            break;
-        }
+        if (++spins > kSpinLimit || ((spins & 255u) == 0 && __hip_atomic_load(give_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u))
+            return false;
     }
 #pragma unroll
     for (int j = 0; j < MAXP; ++j) {
         const int p = tid + 256 * j;
-        if (p < total) vals[p] = __hiloint2double((int)(unsigned)hi[j], (int)(unsigned)lo[j]);
+        if (p < total) vals[p] = __hiloint2double((int)v[j].z, (int)v[j].x);
     }
-    return alive;
+    return true;
 }
 
 template <int D, int K>
@@ -113,7 +120,9 @@ __global__ __launch_bounds__(256) void em_resident_valu_kernel(ResidentArgs a)
     const uint32_t G = gridDim.x, g = blockIdx.x;                  // one resident workgroup per partial block
     const uint32_t n_tiles = (a.n + TS - 1) / TS;
     gu32* give_up = (gu32*)a.sync;
-    gu64* xq = (gu64*)a.xch;
+    // the exchange buffer as a raw buffer (byte offsets, bounds-checked by the hardware): 16-byte sc1 loads / stores with the compiler's
+    // own wait counters
+    const __amdgpu_buffer_rsrc_t xch = __builtin_amdgcn_make_buffer_rsrc((void*)a.xch, 0, (int)(2u * G * XS * 16u), 0x00020000);
 
     for (int e = tid; e < K * PS; e += 256) recs[e] = a.records[0][e];
     if (tid == 0) s_gave_up = 0;
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(256) void em_resident_valu_kernel(ResidentArgs a)
     for (uint32_t i = 0; i < a.max_steps; ++i) {
         const int out = (int)((i + 1) % 3);
         const unsigned epoch = i + 1;                              // tag of this iteration's granules (never 0: the buffers start zeroed)
-        gu64* xb = xq + (size_t)(i & 1) * G * XS * 2;
+        const unsigned xb = (i & 1u) * G * XS * 16u;               // byte offset of this iteration's buffer
         stamp(a.profile, i, 0, g, tid);
         // ---- A. E-step + statistics over this workgroup's tiles; the partial block published as tagged granules, write-through
         {
@@ -141,18 +150,15 @@ __global__ __launch_bounds__(256) void em_resident_valu_kernel(ResidentArgs a)
             valu_fold<VP>(acc, ll_acc, wave, lane, fold, red);
             __syncthreads();
             stamp(a.profile, i, 1, g, tid);
-            gu64* o = xb + (size_t)g * XS * 2;
             for (int e = tid; e < XS; e += 256) {
                 const double v = e < TOT ? ((fold[0][e] + fold[1][e]) + fold[2][e]) + fold[3][e] : ((red[0] + red[1]) + red[2]) + red[3];
-                const unsigned long long tag = (unsigned long long)epoch << 32;
-                __hip_atomic_store(o + 2 * e, tag | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(o + 2 * e + 1, tag | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_raw_buffer_store_b128(tagged(v, epoch), xch, xb + 16u * (g * XS + (unsigned)e), 0, kAuxSc1);
             }
         }
         stamp(a.profile, i, 2, g, tid);
         valu_load_tile<D>(a.xt, a.ldx, first_tile, lane, xn);      // the next iteration's first tile: in flight behind the exchange and the closing
         // ---- B. every workgroup's partial block, as soon as it is there, summed in em_reduce_kernel's order (em_mstats.hip)
-        if (!gather_blocks<XS>(xb, G, epoch, tid, vals, give_up)) s_gave_up = 1;
+        if (!gather_blocks<XS>(xch, xb, G, epoch, tid, vals, give_up)) s_gave_up = 1;
         __syncthreads();
         if (s_gave_up) {                                           // (workgroup-uniform) somebody never published: tell the others, leave
             if (tid == 0) __hip_atomic_store(give_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -162,14 +168,29 @@ __global__ __launch_bounds__(256) void em_resident_valu_kernel(ResidentArgs a)
         stamp(a.profile, i, 4, g, tid);
         if (tid < TOT) {
             // sum e: 32 slice sums s_q = 0 + v[q][e] + v[q + 32][e] + ... (blocks ascending), added in ascending q. A block that does
-            // not exist adds +0.0, which leaves a sum -- never -0.0, it starts at +0.0 -- as it is.
+            // not exist adds +0.0, which leaves a sum -- never -0.0, it starts at +0.0 -- as it is. Every read is issued before the
+            // first addition (reads of blocks beyond the grid go to block 0 and are replaced by +0.0).
+            static_assert(kResidentMaxGrid == 2 * kResidentSlices, "two blocks per slice at most");
+            double lo[kResidentSlices], up[kResidentSlices];
+#pragma unroll
+            for (int q = 0; q < kResidentSlices; ++q) lo[q] = vals[((uint32_t)q < G ? q : 0) * XS + tid];
+            if (G > (uint32_t)kResidentSlices) {
+#pragma unroll
+                for (int q = 0; q < kResidentSlices; ++q) up[q] = vals[((uint32_t)(q + kResidentSlices) < G ? q + kResidentSlices : 0) * XS + tid];
+            } else {
+#pragma unroll
+                for (int q = 0; q < kResidentSlices; ++q) up[q] = 0.0;
+            }
             double t = 0.0;
 #pragma unroll
             for (int q = 0; q < kResidentSlices; ++q) {
-                double sq = 0.0;
-#pragma unroll
-                for (int b = q; b < kResidentMaxGrid; b += kResidentSlices) sq += (uint32_t)b < G ? vals[b * XS + tid] : 0.0;
-                t = q == 0 ? sq : t + sq;
+                // (slices q >= G are empty: their +0.0 would change nothing -- t is never -0.0 -- so the chain of additions ends at G)
+                if ((uint32_t)q < G) {
+                    double sq = 0.0;
+                    sq += lo[q];
+                    sq += (uint32_t)(q + kResidentSlices) < G ? up[q] : 0.0;
+                    t = q == 0 ? sq : t + sq;
+                }
             }
             stats[tid] = t;
         }
@@ -194,7 +215,7 @@ __global__ __launch_bounds__(256) void em_resident_valu_kernel(ResidentArgs a)
         stamp(a.profile, i, 5, g, tid);
         // ---- C. closing arithmetic, one wave per component (the four waves take turns): parameters, the next records, flags
         for (int k = wave; k < K; k += 4)
-            closing::close_component<0, D>(stats, K, D, D, a.shift, a.n_global, a.refine_limit, o_mixing, o_means, o_covs, recs, PS,
+            closing::close_component<0, D, true>(stats, K, D, D, a.shift, a.n_global, a.refine_limit, o_mixing, o_means, o_covs, recs, PS,
                                            o_info, k, lane, scratch[wave], StampProbe{a.profile, i, g, tid});
         __syncthreads();
         stamp(a.profile, i, 6, g, tid);

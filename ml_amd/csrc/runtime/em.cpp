@@ -156,7 +156,7 @@ void collect_stats(mlhip_data* dt, int K, size_t count)
     ctx->sync();
     if (ctx->reduce_fn && !ctx->reduce_on_device) {
         if (ctx->reduce_fn(ctx->reduce_user, dt->stats_host.as<double>(), count, 0, ctx->stream) != 0)
-            throw std::runtime_error("all-reduce hook failed");
+            throw hook_failure();
     }
 }
 
@@ -308,12 +308,12 @@ void refine_component(mlhip_data* dt, int k, double* mean_k, double* cov_k)
     std::vector<double> s((size_t)F);
     if (ctx->reduce_fn && ctx->reduce_on_device) {
         if (ctx->reduce_fn(ctx->reduce_user, dt->refine_stats.as<double>(), (size_t)F, 1, ctx->stream) != 0)
-            throw std::runtime_error("all-reduce hook failed");
+            throw hook_failure();
     }
     HIP_CHECK(hipMemcpyAsync(s.data(), dt->refine_stats.p, sizeof(double) * F, hipMemcpyDeviceToHost, ctx->stream));
     ctx->sync();
     if (ctx->reduce_fn && !ctx->reduce_on_device) {
-        if (ctx->reduce_fn(ctx->reduce_user, s.data(), (size_t)F, 0, ctx->stream) != 0) throw std::runtime_error("all-reduce hook failed");
+        if (ctx->reduce_fn(ctx->reduce_user, s.data(), (size_t)F, 0, ctx->stream) != 0) throw hook_failure();
     }
     const double s0 = s[stats_index(d, d)];
     std::vector<double> m(d);
@@ -422,7 +422,7 @@ void allreduce_stats_dev(mlhip_data* dt, size_t count)
     HIP_CHECK(hipMemcpyAsync(dt->stats_host.p, dt->stats_dev.p, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
     ctx->sync();
     if (ctx->reduce_fn(ctx->reduce_user, dt->stats_host.as<double>(), count, 0, ctx->stream) != 0)
-        throw std::runtime_error("all-reduce hook failed");
+        throw hook_failure();
     HIP_CHECK(hipMemcpyAsync(dt->stats_dev.p, dt->stats_host.p, sizeof(double) * count, hipMemcpyHostToDevice, ctx->stream));
 }
 

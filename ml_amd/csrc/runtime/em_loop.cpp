@@ -222,7 +222,7 @@ struct EmLoop {
             const Span spans[] = {{"pass", 0, 1}, {"  densities", 0, 8}, {"  exp+log+1/s", 8, 9}, {"  statistics", 9, 10}, {"  lane fold+barrier", 11, 1},
                                   {"publish", 1, 2}, {"exchange (wait + gather)", 2, 4}, {"sums", 4, 5}, {"closing", 5, 6},
                                   {"  statistics->cov", 5, 12}, {"  factorization", 12, 13}, {"  inverse", 13, 14}, {"  store L, W", 14, 15},
-                                  {"  log det", 15, 16}, {"  c, info", 16, 17}, {"  records+barrier", 17, 6}, {"outputs", 6, 7}};
+                                  {"  logarithms", 15, 16}, {"  flags, log det, c", 16, 17}, {"  records+barrier", 17, 6}, {"outputs", 6, 7}};
             std::string line;
             char buf[96];
             const double us = 0.01 / (evaluated - 1);                     // 100 MHz stamps; iteration 0 (cold loads) left out

@@ -10,162 +10,102 @@
 //     the other shards' slots, and sums all slots in shard order with the same kernel: bit-identical on every shard, reproducible from
 //     run to run, no library involved (slots on other GPUs are read through peer access over xGMI).
 #include "internal.hpp"
-
-#include <climits>
-
-namespace mlhip_rt {
-namespace {
-
-struct GroupAborted : std::runtime_error {
-    GroupAborted() : std::runtime_error("another shard of the device group failed") {}
-};
-
-/// Barrier of the shard threads that can be torn down: a shard that fails (an exception on its way out of the task) aborts it, and
-/// the shards waiting in it -- or arriving later -- fail too instead of waiting for ever. Arrivals spin briefly before they sleep:
-/// the barrier sits inside every all-reduce of an iteration that may take tens of microseconds.
-class Barrier {
-public:
-    void reset(int n) { n_ = n; arrived_.store(0); aborted_.store(false); }
-    void abort()
-    {
-        aborted_.store(true);
-        std::lock_guard<std::mutex> lock(m_);
-        cv_.notify_all();
-    }
-    void wait()
-    {
-        if (aborted_.load()) throw GroupAborted();
-        const uint64_t gen = generation_.load();
-        if (arrived_.fetch_add(1) + 1 == n_) {
-            arrived_.store(0);
-            {
-                std::lock_guard<std::mutex> lock(m_);
-                generation_.fetch_add(1);
-            }
-            cv_.notify_all();
-            return;
-        }
-        for (int spin = 0; spin < 4000; ++spin) {
-            if (generation_.load() != gen) return;
-            if (aborted_.load()) throw GroupAborted();
-            __builtin_ia32_pause();
-        }
-        std::unique_lock<std::mutex> lock(m_);
-        cv_.wait(lock, [&] { return generation_.load() != gen || aborted_.load(); });
-        if (generation_.load() == gen) throw GroupAborted();
-    }
-
-private:
-    int n_ = 1;
-    std::atomic<int> arrived_{0};
-    std::atomic<uint64_t> generation_{0};
-    std::atomic<bool> aborted_{false};
-    std::mutex m_;
-    std::condition_variable cv_;
-};
-
-}  // namespace
-}  // namespace mlhip_rt
+#include "shard_team.hpp"
 
 struct mlhip_group {
     int n = 0;
     std::vector<mlhip_ctx*> shard;      // owned: ordinary contexts with world_size = n, rank = shard index
     std::vector<int> devices;
     enum Reduce { kNone, kRccl, kDirect } reduce = kNone;
-    // ---- the shard threads
-    std::vector<std::thread> workers;
-    std::mutex m;
-    std::condition_variable cv_work, cv_done;
-    uint64_t generation = 0;
-    int pending = 0;
-    bool quit = false;
-    const std::function<void(int)>* task = nullptr;
-    std::vector<std::exception_ptr> errors;
-    std::vector<int> error_order;
-    int error_seq = 0;
-    bool dirty = false;                 // the last task failed somewhere: the shards resynchronise before the next one
-    Barrier barrier;
-    // ---- in-process all-reduce (kDirect): two generations of one slot per shard, so that a shard may start filling the slots of
-    // all-reduce i + 1 while others still read those of all-reduce i
+    std::string rccl_error;             // why an automatic choice fell back from RCCL to the in-process sum (empty: it did not)
+    std::string direct_kind_text;       // "group-direct (RCCL unavailable: ...)" for mlhip_ctx_reduce_kind
+    ShardTeam team;                     // the shard threads, their barrier, the failure protocol (shard_team.hpp)
+    std::atomic<bool> dead{false};      // RCCL mode, after a failure: the communicators were aborted, the group can only be closed
+    // ---- in-process all-reduce (kDirect): the protocol is SlotAllreduce (shard_team.hpp); these are the device objects it moves --
+    // two generations of one slot per shard, an event pair per slot
+    struct DeviceOps;
     std::vector<DevBuf> slot[2];
     std::vector<hipEvent_t> ready[2], consumed[2];
-    std::vector<size_t> capacity;       // doubles per slot (the same on every shard)
-    std::vector<uint64_t> sequence;     // all-reduces since the slots were (re)allocated, per shard
+    mlhip_rt::SlotAllreduce<DeviceOps> exchange;
+    // ---- test hooks, read ONCE when the group is created (tests/test_gpu_group.py): MLHIP_GROUP_TEST_PERTURB=s -- shard s's copy of
+    // a statistics sum differs in its last digits (the checksum exchange must fail the fit); MLHIP_GROUP_TEST_FAIL=s:k -- shard s
+    // fails, alone, in its k-th all-reduce (the others must come back with its error instead of waiting for it)
+    int test_perturb_shard = -1, test_fail_shard = -1;
+    uint64_t test_fail_at = 0;
+    std::vector<uint64_t> allreduces;   // per shard, counted for the hook above
 };
 
 namespace mlhip_rt {
 namespace {
 
-void worker_loop(mlhip_group* g, int s)
-{
-    uint64_t seen = 0;
-    for (;;) {
-        const std::function<void(int)>* task = nullptr;
-        {
-            std::unique_lock<std::mutex> lock(g->m);
-            g->cv_work.wait(lock, [&] { return g->quit || g->generation != seen; });
-            if (g->quit) return;
-            seen = g->generation;
-            task = g->task;
-        }
-        std::exception_ptr err;
-        try {
-            (*task)(s);
-        } catch (...) {
-            err = std::current_exception();
-            g->barrier.abort();
-        }
-        {
-            std::lock_guard<std::mutex> lock(g->m);
-            if (err) { g->errors[(size_t)s] = err; g->error_order[(size_t)s] = g->error_seq++; }
-            if (--g->pending == 0) g->cv_done.notify_all();
-        }
-    }
-}
+}  // namespace
+}  // namespace mlhip_rt
 
-/// After a failed task the shards' streams may hold half an all-reduce: drain them and start the slot protocol afresh.
+/// SlotAllreduce's device operations: shard r's stream, the slots' buffers and events. (Slots on other GPUs are read through peer access.)
+struct mlhip_group::DeviceOps {
+    mlhip_group* g;
+    hipStream_t stream(int r) const { return g->shard[(size_t)r]->stream; }
+    void sync_stream(int r) { HIP_CHECK(hipStreamSynchronize(stream(r))); }
+    void reserve_slots(int r, size_t doubles) { for (int p = 0; p < 2; ++p) g->slot[p][(size_t)r].reserve(sizeof(double) * doubles); }
+    void release_slots(int r) { for (int p = 0; p < 2; ++p) g->slot[p][(size_t)r].release(); }
+    void wait_consumed(int r, int p, int q) { HIP_CHECK(hipStreamWaitEvent(stream(r), g->consumed[p][(size_t)q], 0)); }
+    void publish(int r, int p, const double* buf, size_t count)
+    {
+        HIP_CHECK(hipMemcpyAsync(g->slot[p][(size_t)r].p, buf, sizeof(double) * count, hipMemcpyDeviceToDevice, stream(r)));
+        HIP_CHECK(hipEventRecord(g->ready[p][(size_t)r], stream(r)));
+    }
+    void wait_ready(int r, int p, int q) { HIP_CHECK(hipStreamWaitEvent(stream(r), g->ready[p][(size_t)q], 0)); }
+    void sum(int r, int p, double* buf, size_t count)
+    {
+        GroupSumSlots slots{};
+        for (int q = 0; q < g->n; ++q) slots.p[q] = g->slot[p][(size_t)q].as<double>();
+        launch_group_sum(slots, g->n, buf, count, stream(r));
+        HIP_CHECK(hipGetLastError());
+    }
+    void mark_consumed(int r, int p) { HIP_CHECK(hipEventRecord(g->consumed[p][(size_t)r], stream(r))); }
+};
+
+namespace mlhip_rt {
+namespace {
+
+/// After a failed task the shards' streams may hold half an all-reduce and -- when a slot growth was interrupted -- the shards may
+/// disagree on the slots' capacity: SlotAllreduce::recover (every shard drains its stream, all meet, every shard drops its slots,
+/// all meet again).
 void recover_shard(mlhip_group* g, int s)
 {
     mlhip_ctx* c = g->shard[(size_t)s];
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    if (!g->sequence.empty()) g->sequence[(size_t)s] = 0;
-    g->barrier.wait();
+    mlhip_group::DeviceOps ops{g};
+    if (g->exchange.active()) {
+        g->exchange.recover(ops, g->team.barrier, s);
+    } else {
+        (void)hipStreamSynchronize(c->stream);
+        g->team.barrier.wait();
+    }
 }
 
-/// Runs f(shard) on every shard's thread and waits for all of them; the failure that happened FIRST is re-thrown here (the others
-/// are its consequences: shards torn out of the all-reduce barrier).
+/// A shard failed on its own (out of memory, a HIP error): the others may be INSIDE ncclAllReduce + hipStreamSynchronize waiting for
+/// it, where no barrier of ours can reach them. RCCL mode: abort every communicator -- the blocked streams return with an error --
+/// and mark the group dead (aborted communicators cannot be used again; the caller creates a new group).
+void cancel_collectives(mlhip_group* g)
+{
+    if (g->reduce != mlhip_group::kRccl) return;
+    g->dead.store(true);
+    try {
+        const Rccl& r = Rccl::get();
+        if (!r.CommAbort) return;
+        for (mlhip_ctx* c : g->shard)
+            if (c->comm) (void)r.CommAbort(c->comm);
+    } catch (...) {
+    }
+}
+
 void run_on_shards(mlhip_group* g, const std::function<void(int)>& f)
 {
-    const bool recover = g->dirty;
-    g->dirty = false;
-    const std::function<void(int)> task = [&](int s) {
-        if (recover) recover_shard(g, s);
-        f(s);
-    };
-    {
-        std::lock_guard<std::mutex> lock(g->m);
-        g->task = &task;
-        g->errors.assign((size_t)g->n, nullptr);
-        g->error_order.assign((size_t)g->n, INT_MAX);
-        g->error_seq = 0;
-        g->pending = g->n;
-        g->barrier.reset(g->n);
-        ++g->generation;
-    }
-    g->cv_work.notify_all();
-    {
-        std::unique_lock<std::mutex> lock(g->m);
-        g->cv_done.wait(lock, [&] { return g->pending == 0; });
-        g->task = nullptr;
-    }
-    int first = -1;
-    for (int s = 0; s < g->n; ++s)
-        if (g->errors[(size_t)s] && (first < 0 || g->error_order[(size_t)s] < g->error_order[(size_t)first])) first = s;
-    if (first >= 0) {
-        g->dirty = true;
-        std::rethrow_exception(g->errors[(size_t)first]);
-    }
+    if (g->dead.load())
+        throw std::runtime_error("this device group failed inside an RCCL collective and its communicators were aborted: close it "
+                                 "(mlhip_ctx_destroy) and create a new one");
+    g->team.run(f);
 }
 
 /// The all-reduce hook of a shard in kDirect mode (see the head of this file). Every shard calls it with the same count, in the same
@@ -174,49 +114,23 @@ int direct_allreduce_hook(void* user, double* buf, size_t count, int on_device, 
 {
     auto* c = static_cast<mlhip_ctx*>(user);
     mlhip_group* g = c ? c->member_of : nullptr;
-    if (!g || !on_device) return 1;
+    if (!g || !on_device || static_cast<hipStream_t>(stream_) != c->stream) return 1;
     try {
-        const size_t r = (size_t)c->shard;
-        const int n = g->n;
-        hipStream_t stream = static_cast<hipStream_t>(stream_);
-        if (count > g->capacity[r]) {
-            // all shards arrive here together (same count): nobody may still read the slots that are about to be replaced
-            HIP_CHECK(hipStreamSynchronize(stream));
-            g->barrier.wait();
-            const size_t cap = std::max<size_t>(std::max<size_t>(count, 2 * g->capacity[r]), 4096);
-            for (int p = 0; p < 2; ++p) g->slot[p][r].reserve(sizeof(double) * cap);
-            g->capacity[r] = cap;
-            g->sequence[r] = 0;
-        }
-        const int p = (int)(g->sequence[r] & 1);
-        // slot generation p was last read by all-reduce (sequence - 2): those reads were enqueued before the barrier of all-reduce
-        // (sequence - 1), which this thread has passed
-        if (g->sequence[r] >= 2)
-            for (int q = 0; q < n; ++q) HIP_CHECK(hipStreamWaitEvent(stream, g->consumed[p][(size_t)q], 0));
-        HIP_CHECK(hipMemcpyAsync(g->slot[p][r].p, buf, sizeof(double) * count, hipMemcpyDeviceToDevice, stream));
-        HIP_CHECK(hipEventRecord(g->ready[p][r], stream));
-        g->barrier.wait();                                   // every shard has recorded its `ready` event (and published its slot)
-        GroupSumSlots slots{};
-        for (int q = 0; q < n; ++q) {
-            if ((size_t)q != r) HIP_CHECK(hipStreamWaitEvent(stream, g->ready[p][(size_t)q], 0));
-            slots.p[q] = g->slot[p][(size_t)q].as<double>();
-        }
-        launch_group_sum(slots, n, buf, count, stream);
-        HIP_CHECK(hipGetLastError());
-        if (const char* e = std::getenv("MLHIP_GROUP_TEST_PERTURB")) {
-            // (tests only) shard e's copy of a statistics sum is made to differ in its last digits: the end-of-fit checksum
+        const int r = c->shard;
+        if (g->test_fail_shard == r && ++g->allreduces[(size_t)r] == g->test_fail_at)
+            throw std::runtime_error("injected failure of one shard (MLHIP_GROUP_TEST_FAIL)");
+        mlhip_group::DeviceOps ops{g};
+        g->exchange.allreduce(ops, g->team.barrier, r, buf, count);
+        if (g->test_perturb_shard == r && count > 64) {
+            // (tests only) this shard's copy of a statistics sum is made to differ in its last digits: the end-of-fit checksum
             // exchange of the shards must catch it (short vectors -- that exchange itself -- are left alone)
-            if (std::atoi(e) == (int)r && count > 64) {
-                double v = 0;
-                HIP_CHECK(hipMemcpyAsync(&v, buf, sizeof v, hipMemcpyDeviceToHost, stream));
-                HIP_CHECK(hipStreamSynchronize(stream));
-                v *= 1.0 + 1e-12;
-                HIP_CHECK(hipMemcpyAsync(buf, &v, sizeof v, hipMemcpyHostToDevice, stream));
-                HIP_CHECK(hipStreamSynchronize(stream));
-            }
+            double v = 0;
+            HIP_CHECK(hipMemcpyAsync(&v, buf, sizeof v, hipMemcpyDeviceToHost, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            v *= 1.0 + 1e-12;
+            HIP_CHECK(hipMemcpyAsync(buf, &v, sizeof v, hipMemcpyHostToDevice, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
         }
-        HIP_CHECK(hipEventRecord(g->consumed[p][r], stream));
-        ++g->sequence[r];
         return 0;
     } catch (const std::exception& e) {
         g_error = e.what();
@@ -319,7 +233,12 @@ mlhip_ctx* create(int n_shards, const int* device_ids)
                 const ncclResult_t rc = r.CommInitAll(comms.data(), n_shards, g->devices.data());
                 if (rc != ncclSuccess) {
                     if (want == "rccl") r.check(rc, "ncclCommInitAll");
-                    rccl = false;                            // (auto: fall back to the in-process sum)
+                    rccl = false;                            // (auto: fall back to the in-process sum -- and say so, once)
+                    g->rccl_error = std::string("ncclCommInitAll: ") + r.GetErrorString(rc);
+                    g->direct_kind_text = "group-direct (RCCL unavailable: " + g->rccl_error + ")";
+                    std::fprintf(stderr, "[mlhip] device group: RCCL between the %d GPUs is not available (%s); the shards' statistics are "
+                                         "summed in-process over peer access instead (MLHIP_GROUP_REDUCE=rccl makes this an error)\n",
+                                 n_shards, g->rccl_error.c_str());
                 } else {
                     for (int s = 0; s < n_shards; ++s) {
                         mlhip_ctx* c = g->shard[(size_t)s];
@@ -340,8 +259,7 @@ mlhip_ctx* create(int n_shards, const int* device_ids)
                     g->ready[p].assign((size_t)n_shards, nullptr);
                     g->consumed[p].assign((size_t)n_shards, nullptr);
                 }
-                g->capacity.assign((size_t)n_shards, 0);
-                g->sequence.assign((size_t)n_shards, 0);
+                g->exchange.init(n_shards);
                 for (int s = 0; s < n_shards; ++s) {
                     mlhip_ctx* c = g->shard[(size_t)s];
                     c->use();
@@ -361,9 +279,15 @@ mlhip_ctx* create(int n_shards, const int* device_ids)
             }
             host::set_host_ranks(n_shards);                 // the shards' host threads share this machine's cores
         }
-        g->errors.assign((size_t)n_shards, nullptr);
-        g->error_order.assign((size_t)n_shards, INT_MAX);
-        for (int s = 0; s < n_shards; ++s) g->workers.emplace_back(worker_loop, g, s);
+        // (test hooks: read once, here -- never on the path of an all-reduce)
+        if (const char* e = std::getenv("MLHIP_GROUP_TEST_PERTURB")) g->test_perturb_shard = std::atoi(e);
+        if (const char* e = std::getenv("MLHIP_GROUP_TEST_FAIL")) {
+            g->test_fail_shard = std::atoi(e);
+            const char* colon = std::strchr(e, ':');
+            g->test_fail_at = colon ? std::strtoull(colon + 1, nullptr, 10) : 1;
+        }
+        g->allreduces.assign((size_t)n_shards, 0);
+        g->team.start(n_shards, [g](int s) { recover_shard(g, s); }, [g](int) { cancel_collectives(g); });
     } catch (...) {
         destroy(ctx);
         throw;
@@ -376,13 +300,8 @@ void destroy(mlhip_ctx* ctx)
     if (!ctx) return;
     mlhip_group* g = ctx->group;
     if (g) {
-        {
-            std::lock_guard<std::mutex> lock(g->m);
-            g->quit = true;
-        }
-        g->cv_work.notify_all();
-        for (auto& t : g->workers)
-            if (t.joinable()) t.join();
+        g->team.stop();
+        if (g->n > 1) host::set_host_ranks(1);               // (the shards' share of the host cores was a property of this group)
         for (size_t s = 0; s < g->shard.size(); ++s) {
             mlhip_ctx* c = g->shard[s];
             (void)hipSetDevice(c->device);
@@ -422,7 +341,9 @@ const char* reduce_kind(const mlhip_ctx* ctx)
     if (ctx->group) {
         switch (ctx->group->reduce) {
         case mlhip_group::kRccl: return "group-rccl";
-        case mlhip_group::kDirect: return "group-direct";
+        case mlhip_group::kDirect:
+            // (an automatic choice that fell back from RCCL carries the reason: the bench line shows it)
+            return ctx->group->rccl_error.empty() ? "group-direct" : ctx->group->direct_kind_text.c_str();
         default: return "none";
         }
     }

@@ -48,8 +48,16 @@ struct DomainError : std::runtime_error { using std::runtime_error::runtime_erro
             throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr);  \
     } while (0)
 
+/// What a failed all-reduce hook becomes: a library-owned hook (RCCL, a device group's in-process sum) leaves its reason in the
+/// calling thread's error text; a caller's hook only has its return code.
+inline std::runtime_error hook_failure()
+{
+    return std::runtime_error(g_error.empty() ? std::string("all-reduce hook failed") : "all-reduce hook failed: " + g_error);
+}
+
 template <class F> int guarded(F&& f)
 {
+    g_error.clear();                   // (mlhip_last_error speaks of the LAST call; hook_failure reads what a hook left during this one)
     try { f(); return MLHIP_OK; }
     catch (const InvalidArgument& e) { g_error = e.what(); return MLHIP_E_INVALID_ARGUMENT; }
     catch (const DomainError& e) { g_error = e.what(); return MLHIP_E_DOMAIN; }
@@ -169,6 +177,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;      // (only the device group needs it)
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                          // (optional: a device group cancels the collectives of a failed task)
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -191,6 +200,7 @@ struct Rccl {
             x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(sym("ncclCommInitRank"));
             x.CommInitAll = reinterpret_cast<decltype(x.CommInitAll)>(sym("ncclCommInitAll"));
             x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
+            x.CommAbort = reinterpret_cast<decltype(x.CommAbort)>(sym("ncclCommAbort"));
             x.CommCount = reinterpret_cast<decltype(x.CommCount)>(sym("ncclCommCount"));
             x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(sym("ncclAllReduce"));
             x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
@@ -284,8 +294,9 @@ struct mlhip_ctx {
     void reduce_device(double* buf, size_t count)
     {
         int rc = 0;
+        g_error.clear();
         timed("allreduce", [&] { rc = reduce_fn(reduce_user, buf, count, 1, stream); });
-        if (rc != 0) throw std::runtime_error("all-reduce hook failed");
+        if (rc != 0) throw hook_failure();
     }
 
     /// End-of-fit guard of a row-sharded job: parameters are never broadcast -- every rank applies the same closing arithmetic
@@ -324,7 +335,7 @@ struct mlhip_ctx {
             HIP_CHECK(hipMemcpyAsync(v, small_dev.p, count * sizeof(double), hipMemcpyDeviceToHost, stream));
             sync();
         } else {
-            if (reduce_fn(reduce_user, v, count, 0, stream) != 0) throw std::runtime_error("all-reduce hook failed");
+            if (reduce_fn(reduce_user, v, count, 0, stream) != 0) throw hook_failure();
         }
     }
 };

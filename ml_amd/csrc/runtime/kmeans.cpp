@@ -131,7 +131,7 @@ void km_fetch(mlhip_data* dt, size_t count)
     HIP_CHECK(hipMemcpyAsync(ch, dt->km_out.p, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
     ctx->sync();
     if (ctx->reduce_fn && !ctx->reduce_on_device) {
-        if (ctx->reduce_fn(ctx->reduce_user, ch, count, 0, ctx->stream) != 0) throw std::runtime_error("all-reduce hook failed");
+        if (ctx->reduce_fn(ctx->reduce_user, ch, count, 0, ctx->stream) != 0) throw hook_failure();
     }
 }
 

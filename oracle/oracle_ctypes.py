@@ -24,9 +24,10 @@ def build():
 
 
 def _load():
-    if not os.path.exists(_LIB_PATH):
+    path = os.environ.get("MLPP_ORACLE_LIBRARY") or _LIB_PATH      # override: the sanitizer build (`make -C oracle SANITIZE=...`)
+    if path == _LIB_PATH and not os.path.exists(_LIB_PATH):
         build()
-    lib = C.CDLL(_LIB_PATH)
+    lib = C.CDLL(path)
     lib.orc_last_error.restype = C.c_char_p
     for name in ("orc_em_log_likelihood", "orc_km_inertia", "orc_em_time_iterations", "orc_km_time_steps"):
         getattr(lib, name).restype = C.c_double

@@ -195,15 +195,47 @@ def test_group_fits_carry_the_allreduce_timer_and_the_shard_checksum_guard(group
     assert out[0] == 6 and launches >= 6 and ms > 0.0
     assert group3.reduce_kind == "group-direct" and group3.rccl_ranks == 0      # (group-rccl reports ncclCommCount here)
     assert group3.timing_get("em_estep")[1] >= 6
-    monkeypatch.setenv("MLHIP_GROUP_TEST_PERTURB", "1")      # shard 1's sums differ by 1e-12 relative in one entry
-    with pytest.raises(_lib.MlhipError, match="ranks disagree"):
-        g.em_iterate(pi, mu, S, 4)
-    C0 = X[:5].copy()
-    with pytest.raises(_lib.MlhipError, match="ranks disagree"):
-        g.kmeans_iterate(C0, 4)
-    monkeypatch.delenv("MLHIP_GROUP_TEST_PERTURB")
-    assert g.em_iterate(pi, mu, S, 4)[0] == 4                # ... and the group is usable afterwards
     g.close()
+    # a group whose shard 1 returns sums that differ by 1e-12 relative in one entry (the hook is read when the group is created)
+    monkeypatch.setenv("MLHIP_GROUP_TEST_PERTURB", "1")
+    bad = _lib.Context.group(3, device_ids=[0, 0, 0])
+    monkeypatch.delenv("MLHIP_GROUP_TEST_PERTURB")
+    try:
+        gb = _lib.Data(bad, X)
+        with pytest.raises(_lib.MlhipError, match="ranks disagree"):
+            gb.em_iterate(pi, mu, S, 4)
+        C0 = X[:5].copy()
+        with pytest.raises(_lib.MlhipError, match="ranks disagree"):
+            gb.kmeans_iterate(C0, 4)
+        gb.close()
+    finally:
+        bad.close()
+
+
+@pytest.mark.parametrize("fail_at", [1, 2, 7])
+def test_one_shard_failing_alone_fails_the_call_and_the_group_recovers(single, monkeypatch, fail_at):
+    """a shard that fails BY ITSELF (out of memory, a HIP error -- here: injected into its fail_at-th all-reduce; the
+    first one is also the slots' growth) while the others are inside the same all-reduce: the call comes back with that shard's
+    error on the caller's thread instead of hanging, and the next call -- after every shard has drained its stream and dropped its
+    slots -- gives the results of an undisturbed group."""
+    from ml_amd import _lib
+    X, pi, mu, S = _mixture(6, 4, 12000, 5)
+    monkeypatch.setenv("MLHIP_GROUP_TEST_FAIL", f"2:{fail_at}")
+    grp = _lib.Context.group(4, device_ids=[0, 0, 0, 0])
+    monkeypatch.delenv("MLHIP_GROUP_TEST_FAIL")
+    try:
+        with pytest.raises(_lib.MlhipError, match="injected failure"):
+            g = _lib.Data(grp, X)                            # (the upload has all-reduces of its own: fail_at = 1 hits the first of them)
+            for _ in range(4):
+                g.em_iterate(pi, mu, S, 5)
+        g = _lib.Data(grp, X)
+        s = _lib.Data(single, X)
+        a, b = g.em_iterate(pi, mu, S, 6), s.em_iterate(pi, mu, S, 6)
+        assert a[0] == b[0] and relerr(a[6], b[6]) < 1e-12 and relerr(a[4], b[4]) < 1e-11
+        assert np.array_equal(g.em_labels(4), s.em_labels(4))
+        g.close(); s.close()
+    finally:
+        grp.close()
 
 
 def test_group_on_distinct_gpus_when_there_are_two():
