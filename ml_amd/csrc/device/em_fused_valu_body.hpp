@@ -55,6 +55,8 @@ __device__ __forceinline__ void valu_tiles(const double* __restrict__ xt, size_t
                                            double* __restrict__ lse_out, uint32_t block, uint32_t grid, int wave, int lane,
                                            double (&xn)[D], double (&acc)[ValuShape<D, K>::VP], double& ll_acc, const Probe& probe = Probe())
 {
+#pragma clang fp contract(off)     // every fused multiply-add below is written out: the one-pass kernel and the resident loop instantiate
+                                   // this text with different record pointers and must not be contracted differently
     using S = ValuShape<D, K>;
     constexpr int PS = S::PS, DA = S::DA, F = S::F;
     const uint32_t n_tiles = (n + TS - 1) / TS;
@@ -132,6 +134,7 @@ __device__ __forceinline__ void valu_tiles(const double* __restrict__ xt, size_t
 /// workgroup barrier comes next; entry e of the workgroup is then ((fold[0][e] + fold[1][e]) + fold[2][e]) + fold[3][e].
 template <int VP> __device__ __forceinline__ void valu_fold(double (&acc)[VP], double ll_acc, int wave, int lane, double (*fold)[VP], double* red)
 {
+#pragma clang fp contract(off)
 #pragma unroll
     for (int e = 0; e < VP / 2; ++e) acc[e] = halves_fold<true>(acc[e], acc[e + VP / 2]);
 #pragma unroll

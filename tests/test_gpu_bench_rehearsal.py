@@ -26,14 +26,16 @@ def _bench(*args):
 def test_two_rank_em_line_matches_the_single_rank_run():
     one = _bench("--samples", "400000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
     two = _bench("--gpus", "2", "--allreduce", "gloo", "--n", "400000", "--steps", "3", "--warmup", "1")
-    assert two["n_gpus"] == 2 and two["n_local"] == [200000, 200000] and two["steps"] == 3
+    # two ranks on the ONE GPU of this box: `n_gpus` counts physical GPUs, `units` the ranks; the line says it is a rehearsal
+    assert two["n_gpus"] == 1 and two["units"] == 2 and "rehearsal" in two
+    assert two["n_local"] == [200000, 200000] and two["steps"] == 3
     a, b = one["config"]["final_mean_log_likelihood"], two["config"]["final_mean_log_likelihood"]
     assert abs(a - b) <= 1e-12 * abs(a)
     assert "roofline" in two and two["roofline"]["kernel_ms"]["em_estep"] > 0
     # the fields a first multi-GPU run is diagnosed with: every line has them, a single rank reports no all-reduce time
     for line in (one, two):
         assert line["ms_per_step_min"] <= line["ms_per_step_max"] <= line["ms_per_step"] * 1.5 + 1.0
-        assert len(line["allreduce_ms_per_rank"]) == line["n_gpus"]
+        assert len(line["allreduce_ms_per_rank"]) == line["units"]
     assert one["allreduce_ms"] == 0
     assert one["roofline"]["exp_runs_in"].startswith("em_mstats")        # d = 32, K = 64: self-normalising statistics kernel
 
