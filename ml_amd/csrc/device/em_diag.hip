@@ -15,6 +15,7 @@
 // running sum folded once at the end. No atomics; per-workgroup partials are combined in fixed order by em_reduce_kernel.
 // Bound: ~3d VALU + one exp per (sample, component) against 8d bytes per sample -- VALU/latency-bound at d = K = 16, not HBM.
 #include <cstdlib>
+#include "parts.hpp"
 #include <type_traits>
 
 #include "em_mstats_common.hpp"
@@ -329,7 +330,8 @@ template <bool BIT5> __device__ __forceinline__ void lane_partners(double v, dou
         b = __hiloint2double((int)h[1], (int)l[1]);
     }
 }
-__device__ __forceinline__ double quad_max(double v)
+#ifdef MLHIP_EXPERIMENTS   // (superseded by em_diag_mixed_kernel below; `make EXPERIMENTS=1` keeps it for A/B runs, MLHIP_DIAG_MIXED=0 selects it)
+[[maybe_unused]] __device__ __forceinline__ double quad_max(double v)
 {
     double a, b;
     lane_partners<false>(v, a, b);
@@ -338,7 +340,7 @@ __device__ __forceinline__ double quad_max(double v)
     asm("v_max_f64 %0, %1, %2" : "=v"(v) : "v"(a), "v"(b));
     return v;
 }
-__device__ __forceinline__ double quad_sum(double v)
+[[maybe_unused]] __device__ __forceinline__ double quad_sum(double v)
 {
     double a, b;
     lane_partners<false>(v, a, b);
@@ -634,6 +636,7 @@ __global__ __launch_bounds__(256, D <= 8 ? 4 : 3) void em_diag_sgpr_kernel(
     __syncthreads();
     if (tid == 0) ll_partials[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
+#endif  // MLHIP_EXPERIMENTS
 
 /// K <= 16, d <= 16 (BASELINE.json configs[1]): the two-operation density form
 ///     t = fma(a, x~, b) ;  q = fma(t, t, q)        a = 1 / sigma, b = -(mu - shift) / sigma
@@ -885,21 +888,25 @@ __global__ __launch_bounds__(256, 2) void em_diag_mixed_kernel(
     if (tid == 0) ll_partials[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
-/// MLHIP_DIAG_MIXED=0: em_diag_sgpr_kernel (the exact scalar-fed form; with MLHIP_DIAG_GEMM=1 its matrix-core density path) instead of
-/// this kernel (A/B runs).
-inline bool diag_mixed_applies(int d, int K)
+/// Shapes em_diag_mixed_kernel serves: one row block of components, d <= 16. In a `make EXPERIMENTS=1` build MLHIP_DIAG_MIXED=0 /
+/// MLHIP_DIAG_GEMM=1 select em_diag_sgpr_kernel (the exact scalar-fed form / its matrix-core density path) and MLHIP_DIAG_SGPR=0 the
+/// LDS-fed general kernel instead (A/B runs).
+[[maybe_unused]] inline bool diag_sgpr_applies(int d, int K)
 {
+#ifdef MLHIP_EXPERIMENTS
+    const char* e = std::getenv("MLHIP_DIAG_SGPR");
+    if (e && e[0] == '0') return false;
+#endif
+    return K <= 16 && padded_dim(d) <= 16;
+}
+[[maybe_unused]] inline bool diag_mixed_applies(int d, int K)
+{
+#ifdef MLHIP_EXPERIMENTS
     const char* e = std::getenv("MLHIP_DIAG_MIXED");
     const char* g = std::getenv("MLHIP_DIAG_GEMM");
-    return !(e && e[0] == '0') && !(g && g[0] == '1') && K <= 16 && padded_dim(d) <= 16;
-}
-
-/// Shapes the scalar-fed kernel serves: one row block of components, coordinates + densities within 128 registers.
-/// MLHIP_DIAG_SGPR=0: off (A/B runs).
-inline bool diag_sgpr_applies(int d, int K)
-{
-    const char* e = std::getenv("MLHIP_DIAG_SGPR");
-    return !(e && e[0] == '0') && K <= 16 && padded_dim(d) <= 16;
+    if ((e && e[0] == '0') || (g && g[0] == '1')) return false;
+#endif
+    return K <= 16 && padded_dim(d) <= 16;
 }
 
 constexpr int rbw_of(int RBT) { return RBT >= 2 ? 2 : 1; }
@@ -911,13 +918,15 @@ inline double diag_ab_limit()
     return e && e[0] == '0' ? -1.0 : kDiagAbLimit;
 }
 
+#ifdef MLHIP_EXPERIMENTS
 /// Largest B2 = sum_j ((mu_j - shift_j) / sigma_j)^2 of a component for which the expanded form runs on the matrix cores
 /// (layout.hpp kDiagExpandLimit; MLHIP_DIAG_EXPAND_LIMIT overrides it -- tests, error measurements).
-inline double diag_expand_limit()
+[[maybe_unused]] inline double diag_expand_limit()
 {
     const char* e = std::getenv("MLHIP_DIAG_EXPAND_LIMIT");   // (read per launch: tests switch it inside one process)
     return e && *e ? std::atof(e) : kDiagExpandLimit;
 }
+#endif
 
 /// Samples per lane: 2 while coordinates + densities of both fit the registers of 2 waves per SIMD, else 1.
 constexpr int samples_per_lane(int D, int RBT) { return (D <= 16 && RBT == 1) || (D <= 8 && RBT == 2) ? 2 : 1; }
@@ -934,6 +943,7 @@ int launch_t(const DiagArgs& a, int grid, hipStream_t stream)
                                (a.two_op && diag_ab_limit() > 0) ? 1 : 0);
             return grid;
         }
+#ifdef MLHIP_EXPERIMENTS
         if (diag_sgpr_applies(a.d, a.K)) {
             const char* e = std::getenv("MLHIP_DIAG_GEMM");        // 1: log-densities on the matrix cores while the guard allows (A/B runs)
             const bool gemm = e && e[0] == '1';
@@ -948,11 +958,17 @@ int launch_t(const DiagArgs& a, int grid, hipStream_t stream)
             return grid;
         }
     }
-    const size_t smem = sizeof(double) * (4 * ((size_t)TS * XSS + (size_t)TS * RSS) + (size_t)16 * RBT * PS);
-    hipLaunchKernelGGL((em_diag_kernel<D, RBT, RBW, CB, S>), dim3(grid, RBT / RBW), dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d,
-                       a.shift, a.params, a.K, a.lse, a.partials, em_diag_partial_rows(a.K), em_diag_partial_cols(a.d),
-                       a.ll_partials, diag_ab_limit());
-    return grid;
+    {
+#else
+        return -1;                                                 // (one row block, d <= 16: always the kernel above in the default build)
+    } else {
+#endif
+        const size_t smem = sizeof(double) * (4 * ((size_t)TS * XSS + (size_t)TS * RSS) + (size_t)16 * RBT * PS);
+        hipLaunchKernelGGL((em_diag_kernel<D, RBT, RBW, CB, S>), dim3(grid, RBT / RBW), dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d,
+                           a.shift, a.params, a.K, a.lse, a.partials, em_diag_partial_rows(a.K), em_diag_partial_cols(a.d),
+                           a.ll_partials, diag_ab_limit());
+        return grid;
+    }
 }
 
 template <int D>
@@ -966,6 +982,40 @@ int launch_d(const DiagArgs& a, int grid, hipStream_t stream)
 }
 
 }  // namespace
+
+// ---- compiled in six parts by padded dimension (parts.hpp): 1: D = 1, 2; 2: 3, 4; 3: 6, 8; 4: 12, 16; 5: 20, 24; 6: 28, 32
+int MLHIP_PART_FN(launch_em_diag)(const DiagArgs& a, int grid, hipStream_t stream)
+{
+    switch (padded_dim(a.d)) {
+#if MLHIP_PART == 1
+    case 1: return launch_d<1>(a, grid, stream);
+    case 2: return launch_d<2>(a, grid, stream);
+#elif MLHIP_PART == 2
+    case 3: return launch_d<3>(a, grid, stream);
+    case 4: return launch_d<4>(a, grid, stream);
+#elif MLHIP_PART == 3
+    case 6: return launch_d<6>(a, grid, stream);
+    case 8: return launch_d<8>(a, grid, stream);
+#elif MLHIP_PART == 4
+    case 12: return launch_d<12>(a, grid, stream);
+    case 16: return launch_d<16>(a, grid, stream);
+#elif MLHIP_PART == 5
+    case 20: return launch_d<20>(a, grid, stream);
+    case 24: return launch_d<24>(a, grid, stream);
+#elif MLHIP_PART == 6
+    case 28: return launch_d<28>(a, grid, stream);
+    case 32: return launch_d<32>(a, grid, stream);
+#endif
+    default: return -1;
+    }
+}
+
+#if MLHIP_PART == 1
+int launch_em_diag_part2(const DiagArgs&, int, hipStream_t);
+int launch_em_diag_part3(const DiagArgs&, int, hipStream_t);
+int launch_em_diag_part4(const DiagArgs&, int, hipStream_t);
+int launch_em_diag_part5(const DiagArgs&, int, hipStream_t);
+int launch_em_diag_part6(const DiagArgs&, int, hipStream_t);
 
 bool em_diag_supported(int d, int K) { return d >= 1 && d <= kRegDim && K >= 1 && K <= 64; }
 int em_diag_partial_rows(int K) { const int RB = (K + 15) / 16; return (RB == 1 ? 1 : RB == 2 ? 2 : 4) * 16; }
@@ -995,22 +1045,15 @@ int launch_em_diag(const DiagArgs& a, int num_cus, hipStream_t stream)
     const size_t block = (size_t)em_diag_partial_rows(a.K) * em_diag_partial_cols(a.d);
     if ((size_t)grid * block > a.partials_capacity) grid = (int)(a.partials_capacity / block);
     if (grid < 1) return -2;
-    switch (padded_dim(a.d)) {
-    case 1: return launch_d<1>(a, grid, stream);
-    case 2: return launch_d<2>(a, grid, stream);
-    case 3: return launch_d<3>(a, grid, stream);
-    case 4: return launch_d<4>(a, grid, stream);
-    case 6: return launch_d<6>(a, grid, stream);
-    case 8: return launch_d<8>(a, grid, stream);
-    case 12: return launch_d<12>(a, grid, stream);
-    case 16: return launch_d<16>(a, grid, stream);
-    case 20: return launch_d<20>(a, grid, stream);
-    case 24: return launch_d<24>(a, grid, stream);
-    case 28: return launch_d<28>(a, grid, stream);
-    case 32: return launch_d<32>(a, grid, stream);
-    default: return -1;
-    }
+    const int D = padded_dim(a.d);
+    if (D <= 2) return launch_em_diag_part1(a, grid, stream);
+    if (D <= 4) return launch_em_diag_part2(a, grid, stream);
+    if (D <= 8) return launch_em_diag_part3(a, grid, stream);
+    if (D <= 16) return launch_em_diag_part4(a, grid, stream);
+    if (D <= 24) return launch_em_diag_part5(a, grid, stream);
+    return launch_em_diag_part6(a, grid, stream);
 }
+#endif
 
 }  // namespace mstats
 }  // namespace mlhip

@@ -16,6 +16,7 @@
 // HBM traffic per iteration: X once, LSE once. The log-responsibility block is produced on demand (labels /
 // responsibilities after the fit) by the ordinary E-step kernel from the same parameter records.
 #include "em_fused_valu_body.hpp"
+#include "parts.hpp"
 
 namespace mlhip {
 namespace mstats {
@@ -296,7 +297,7 @@ int launch_d(const FusedArgs& a, int grid, hipStream_t stream)
 
 /// Workgroups the vector-unit form is launched with before the cut to what a CU's registers hold (launch_valu_k): one per four
 /// tiles, at most 8 per CU, the capacity of the partial-block scratch.
-int valu_grid_uncut(const FusedArgs& a, int num_cus)
+[[maybe_unused]] int valu_grid_uncut(const FusedArgs& a, int num_cus)
 {
     const uint32_t n_tiles = (a.n + TS - 1) / TS;
     int grid = 8 * num_cus;
@@ -343,7 +344,7 @@ template <int D> int launch_valu(const FusedArgs& a, int num_cus, hipStream_t st
 /// samples on, where it still wins by 6 - 36 % (below that the matrix-core form is up to 4 us faster).
 /// MLHIP_FUSED_VALU=0: the matrix-core form instead; =2: the vector-unit form at every N for all shapes it is built for (A/B runs,
 /// tests; read per call).
-bool valu_form_applies(const FusedArgs& a)
+[[maybe_unused]] bool valu_form_applies(const FusedArgs& a)
 {
     const char* e = std::getenv("MLHIP_FUSED_VALU");
     if (e && e[0] == '0') return false;
@@ -354,6 +355,7 @@ bool valu_form_applies(const FusedArgs& a)
 
 }  // namespace
 
+#if MLHIP_PART == 1
 /// Shapes the fused kernel is used for: d <= 8 with K <= 32, d <= 4 with K <= 64 (the K densities and the
 /// accumulator tiles must fit the register file).
 bool em_fused_supported(int d, int K)
@@ -365,6 +367,37 @@ bool em_fused_supported(int d, int K)
 
 int em_fused_partial_rows(int K) { const int RB = (K + 15) / 16; return (RB == 1 ? 1 : RB == 2 ? 2 : 4) * 16; }
 int em_fused_partial_cols(int d) { return ((stats_count(d) + 15) / 16) * 16; }
+#endif
+
+// ---- compiled in six parts by padded dimension (parts.hpp): part 1 .. 6 = D 1, 2, 3, 4, 6, 8
+constexpr int kPartDim = MLHIP_PART <= 4 ? MLHIP_PART : (MLHIP_PART == 5 ? 6 : 8);
+
+/// Returns the number of per-workgroup partial blocks written (stats and log-likelihood alike), or < 0.
+int MLHIP_PART_FN(launch_em_fused_small)(const FusedArgs& a, int num_cus, hipStream_t stream)
+{
+    constexpr int D = kPartDim, CB = D <= 4 ? 1 : (D == 6 ? 2 : 3);
+    if (padded_dim(a.d) != D) return -1;
+    if constexpr (valu_max_k(D) > 0) {
+        if (valu_form_applies(a)) return launch_valu<D>(a, num_cus, stream);
+    }
+    const uint32_t n_tiles = (a.n + TS - 1) / TS;
+    const int RB = (a.K + 15) / 16;
+    int grid = (D <= 4 && RB <= 2 ? 3 : 2) * num_cus;   // resident workgroups per CU of the instance
+    if ((uint32_t)grid * 4 > n_tiles) grid = (int)((n_tiles + 3) / 4);
+    if (grid < 1) grid = 1;
+    if (grid > a.n_ll_partials) grid = a.n_ll_partials;
+    const size_t block = (size_t)em_fused_partial_rows(a.K) * em_fused_partial_cols(a.d);
+    if ((size_t)grid * block > a.partials_capacity) grid = (int)(a.partials_capacity / block);
+    if (grid < 1) return -2;
+    return launch_d<D, CB>(a, grid, stream);
+}
+
+#if MLHIP_PART == 1
+int launch_em_fused_small_part2(const FusedArgs&, int, hipStream_t);
+int launch_em_fused_small_part3(const FusedArgs&, int, hipStream_t);
+int launch_em_fused_small_part4(const FusedArgs&, int, hipStream_t);
+int launch_em_fused_small_part5(const FusedArgs&, int, hipStream_t);
+int launch_em_fused_small_part6(const FusedArgs&, int, hipStream_t);
 
 /// The grid the vector-unit form would be launched with for these arguments when that is at most one workgroup per CU (no
 /// register cut applies then); 0 when the shape takes another form or a larger grid. What the device-resident loop
@@ -376,39 +409,20 @@ int em_fused_valu_small_grid(const FusedArgs& a, int num_cus)
     return grid >= 1 && grid <= num_cus ? grid : 0;
 }
 
-/// Returns the number of per-workgroup partial blocks written (stats and log-likelihood alike), or < 0.
 int launch_em_fused_small(const FusedArgs& a, int num_cus, hipStream_t stream)
 {
     if (!em_fused_supported(a.d, a.K)) return -1;
-    if (valu_form_applies(a)) {
-        switch (a.d) {
-        case 1: return launch_valu<1>(a, num_cus, stream);
-        case 2: return launch_valu<2>(a, num_cus, stream);
-        case 3: return launch_valu<3>(a, num_cus, stream);
-        case 4: return launch_valu<4>(a, num_cus, stream);
-        case 6: return launch_valu<6>(a, num_cus, stream);
-        default: break;
-        }
-    }
-    const uint32_t n_tiles = (a.n + TS - 1) / TS;
-    const int RB = (a.K + 15) / 16;
-    int grid = (padded_dim(a.d) <= 4 && RB <= 2 ? 3 : 2) * num_cus;   // resident workgroups per CU of the instance
-    if ((uint32_t)grid * 4 > n_tiles) grid = (int)((n_tiles + 3) / 4);
-    if (grid < 1) grid = 1;
-    if (grid > a.n_ll_partials) grid = a.n_ll_partials;
-    const size_t block = (size_t)em_fused_partial_rows(a.K) * em_fused_partial_cols(a.d);
-    if ((size_t)grid * block > a.partials_capacity) grid = (int)(a.partials_capacity / block);
-    if (grid < 1) return -2;
     switch (padded_dim(a.d)) {
-    case 1: return launch_d<1, 1>(a, grid, stream);
-    case 2: return launch_d<2, 1>(a, grid, stream);
-    case 3: return launch_d<3, 1>(a, grid, stream);
-    case 4: return launch_d<4, 1>(a, grid, stream);
-    case 6: return launch_d<6, 2>(a, grid, stream);
-    case 8: return launch_d<8, 3>(a, grid, stream);
+    case 1: return launch_em_fused_small_part1(a, num_cus, stream);
+    case 2: return launch_em_fused_small_part2(a, num_cus, stream);
+    case 3: return launch_em_fused_small_part3(a, num_cus, stream);
+    case 4: return launch_em_fused_small_part4(a, num_cus, stream);
+    case 6: return launch_em_fused_small_part5(a, num_cus, stream);
+    case 8: return launch_em_fused_small_part6(a, num_cus, stream);
     default: return -1;
     }
 }
+#endif
 
 }  // namespace mstats
 }  // namespace mlhip

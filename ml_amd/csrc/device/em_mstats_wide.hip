@@ -19,6 +19,7 @@
 //     its exponentials, which a small follow-up kernel (em_lse_finish_kernel, em_mstats.hip) turns into lse and the log-
 //     likelihood partials. Needs all K components in this workgroup (a single row-block group, K <= 64).
 #include <type_traits>
+#include "parts.hpp"
 
 #include "em_mstats_common.hpp"
 #include "exp_nonpos.hpp"
@@ -386,42 +387,73 @@ void launch_t(const MstatsArgs& a, const Plan& p, int grid_x, hipStream_t stream
 
 }  // namespace
 
-int launch_wide(const MstatsArgs& a, const Plan& p, int grid_x, hipStream_t stream)
+// ---- one code object per (row blocks per workgroup, dimension class): the Makefile compiles this file eight times with
+// -DMLHIP_PART=1..8 (parts 1-4: d <= 32 with RBW = part; 5-8: 32 < d <= 128 with RBW = part - 4). A fit uses one K and one d, so it
+// touches one or two of them (the sample covariance is a K = 1 call: RBW = 1) and the first use of a shape loads ~0.3 MB of
+// kernels instead of the 2.1 MB of all 147 instantiations (round 5: the first call of a shape was dominated by that load).
+int MLHIP_PART_FN(launch_wide)(const MstatsArgs& a, const Plan& p, int grid_x, hipStream_t stream)
 {
-    if (a.d > kRegDim) {
-        // 32 < d <= 128: 38..525 column blocks in column groups of 8 waves x (3, 4 or 5) blocks
-#define MLHIP_BIG(R, C) \
-    if (p.RBW == R && p.CBW == C) { \
+    constexpr int R = (MLHIP_PART - 1) % 4 + 1;
+    if (p.RBW != R) return -1;
+#if MLHIP_PART > 4
+    // 32 < d <= 128: 38..525 column blocks in column groups of 8 waves x (3, 4 or 5) blocks
+#define MLHIP_BIG(C) \
+    if (p.CBW == C) { \
         if (a.d <= kMidDim) launch_t<R, C, kMidDim>(a, p, grid_x, stream); else launch_t<R, C, kMaxDim>(a, p, grid_x, stream); \
     } else
-        MLHIP_BIG(1, 3) MLHIP_BIG(1, 4) MLHIP_BIG(1, 5) MLHIP_BIG(2, 3) MLHIP_BIG(2, 4) MLHIP_BIG(2, 5)
-        MLHIP_BIG(3, 3) MLHIP_BIG(3, 4) MLHIP_BIG(3, 5) MLHIP_BIG(4, 3) MLHIP_BIG(4, 4) MLHIP_BIG(4, 5)
-        { return -1; }
+    MLHIP_BIG(3) MLHIP_BIG(4) MLHIP_BIG(5)
+    { return -1; }
 #undef MLHIP_BIG
-        return grid_x;
-    }
+    return grid_x;
+#else
     // balanced dealing of (column block, row block) units where whole column blocks leave the waves unevenly loaded
     // (MLHIP_MSTATS_BALANCED=0: off)
     static const bool balanced = [] { const char* e = std::getenv("MLHIP_MSTATS_BALANCED"); return !(e && e[0] == '0'); }();
     if (balanced && p.n_rbg == 1 && p.n_cbg == 1) {
-        if (p.RBW == 4 && p.CB == 6) { launch_t<4, 1, kRegDim, 6>(a, p, grid_x, stream); return grid_x; }      // d = 12
-        if (p.RBW == 4 && p.CB == 10) { launch_t<4, 2, kRegDim, 10>(a, p, grid_x, stream); return grid_x; }    // d = 16
-        if (p.RBW == 3 && p.CB == 10) { launch_t<3, 2, kRegDim, 10>(a, p, grid_x, stream); return grid_x; }
+        if constexpr (R == 4) {
+            if (p.CB == 6) { launch_t<4, 1, kRegDim, 6>(a, p, grid_x, stream); return grid_x; }      // d = 12
+            if (p.CB == 10) { launch_t<4, 2, kRegDim, 10>(a, p, grid_x, stream); return grid_x; }    // d = 16
+        }
+        if constexpr (R == 3) {
+            if (p.CB == 10) { launch_t<3, 2, kRegDim, 10>(a, p, grid_x, stream); return grid_x; }
+            if (p.CB == 6) { launch_t<3, 1, kRegDim, 6>(a, p, grid_x, stream); return grid_x; }
+        }
         // (K <= 32 at d = 16: the plain form with two workgroups per CU -- the balanced one needs 130 registers -- unless the plan
         //  kept one workgroup per CU)
-        if (p.RBW == 2 && p.CB == 10 && p.wg_per_cu == 1) { launch_t<2, 2, kRegDim, 10>(a, p, grid_x, stream); return grid_x; }
-        if (p.RBW == 3 && p.CB == 6) { launch_t<3, 1, kRegDim, 6>(a, p, grid_x, stream); return grid_x; }
+        if constexpr (R == 2) {
+            if (p.CB == 10 && p.wg_per_cu == 1) { launch_t<2, 2, kRegDim, 10>(a, p, grid_x, stream); return grid_x; }
+        }
     }
-#define MLHIP_CASE(R, C) \
-    if (p.RBW == R && p.CBW == C) { launch_t<R, C>(a, p, grid_x, stream); } else
-    MLHIP_CASE(1, 1) MLHIP_CASE(1, 2) MLHIP_CASE(1, 3) MLHIP_CASE(1, 4) MLHIP_CASE(1, 5)
-    MLHIP_CASE(2, 1) MLHIP_CASE(2, 2) MLHIP_CASE(2, 3) MLHIP_CASE(2, 4) MLHIP_CASE(2, 5)
-    MLHIP_CASE(3, 1) MLHIP_CASE(3, 2) MLHIP_CASE(3, 3) MLHIP_CASE(3, 4) MLHIP_CASE(3, 5)
-    MLHIP_CASE(4, 1) MLHIP_CASE(4, 2) MLHIP_CASE(4, 3) MLHIP_CASE(4, 4) MLHIP_CASE(4, 5)
+#define MLHIP_CASE(C) \
+    if (p.CBW == C) { launch_t<R, C>(a, p, grid_x, stream); } else
+    MLHIP_CASE(1) MLHIP_CASE(2) MLHIP_CASE(3) MLHIP_CASE(4) MLHIP_CASE(5)
     { return -1; }
 #undef MLHIP_CASE
     return grid_x;
+#endif
 }
+
+#if MLHIP_PART == 1
+int launch_wide_part2(const MstatsArgs&, const Plan&, int, hipStream_t);
+int launch_wide_part3(const MstatsArgs&, const Plan&, int, hipStream_t);
+int launch_wide_part4(const MstatsArgs&, const Plan&, int, hipStream_t);
+int launch_wide_part5(const MstatsArgs&, const Plan&, int, hipStream_t);
+int launch_wide_part6(const MstatsArgs&, const Plan&, int, hipStream_t);
+int launch_wide_part7(const MstatsArgs&, const Plan&, int, hipStream_t);
+int launch_wide_part8(const MstatsArgs&, const Plan&, int, hipStream_t);
+
+int launch_wide(const MstatsArgs& a, const Plan& p, int grid_x, hipStream_t stream)
+{
+    const bool big = a.d > kRegDim;
+    switch (p.RBW) {
+    case 1: return big ? launch_wide_part5(a, p, grid_x, stream) : launch_wide_part1(a, p, grid_x, stream);
+    case 2: return big ? launch_wide_part6(a, p, grid_x, stream) : launch_wide_part2(a, p, grid_x, stream);
+    case 3: return big ? launch_wide_part7(a, p, grid_x, stream) : launch_wide_part3(a, p, grid_x, stream);
+    case 4: return big ? launch_wide_part8(a, p, grid_x, stream) : launch_wide_part4(a, p, grid_x, stream);
+    default: return -1;
+    }
+}
+#endif
 
 }  // namespace mstats
 }  // namespace mlhip

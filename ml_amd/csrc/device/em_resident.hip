@@ -27,6 +27,7 @@
 // would get), same summation order, same closing arithmetic (tests/test_gpu_resident.py).
 #include "em_close_body.hpp"
 #include "em_fused_valu_body.hpp"
+#include "parts.hpp"
 
 namespace mlhip {
 namespace mstats {
@@ -268,9 +269,25 @@ template <int D, int K> bool launch_k(const ResidentArgs& a, int grid, hipStream
 
 /// Largest K at dimension D the resident loop is built for: the shapes the vector-unit form takes at EVERY sample count
 /// (K F <= 64 accumulators per lane, valu_form_applies in em_fused_small.hip).
-constexpr int resident_max_k(int D) { return 64 / ((D + 1) * (D + 2) / 2); }
+/// ... and at most 16 components: the four waves of a workgroup close them in turns of ~2.5 us each, so beyond four turns the
+/// serial closing costs more than the dispatches it saves (N = 16 384, d = 1, K = 21: 21.0 against 18.0 us per iteration with
+/// three launches, profiles/r05_resident_phases.txt).
+constexpr int resident_max_k(int D) { return 64 / ((D + 1) * (D + 2) / 2) < 16 ? 64 / ((D + 1) * (D + 2) / 2) : 16; }
 
 }  // namespace
+
+// ---- compiled in five parts by dimension (parts.hpp): part 1 .. 5 = d 1, 2, 3, 4, 6
+bool MLHIP_PART_FN(launch_em_resident)(const ResidentArgs& a, hipStream_t stream)
+{
+    constexpr int D = MLHIP_PART <= 4 ? MLHIP_PART : 6;
+    return a.d == D && launch_k<D, resident_max_k(D)>(a, a.vgrid, stream);   // one resident workgroup per partial block (<= one per CU)
+}
+
+#if MLHIP_PART == 1
+bool launch_em_resident_part2(const ResidentArgs&, hipStream_t);
+bool launch_em_resident_part3(const ResidentArgs&, hipStream_t);
+bool launch_em_resident_part4(const ResidentArgs&, hipStream_t);
+bool launch_em_resident_part5(const ResidentArgs&, hipStream_t);
 
 /// Two alternating buffers of vgrid blocks of K F + 1 values, two 8-byte granules {tag, half} per value.
 size_t em_resident_exchange_doubles(int d, int K, int vgrid) { return 2 * (size_t)vgrid * ((size_t)K * stats_count(d) + 1) * 2; }
@@ -290,16 +307,16 @@ bool em_resident_supported(int d, int K, int vgrid, int num_cus)
 
 bool launch_em_resident(const ResidentArgs& a, hipStream_t stream)
 {
-    const int grid = a.vgrid;                                      // one resident workgroup per partial block (<= one per CU)
     switch (a.d) {
-    case 1: return launch_k<1, resident_max_k(1)>(a, grid, stream);
-    case 2: return launch_k<2, resident_max_k(2)>(a, grid, stream);
-    case 3: return launch_k<3, resident_max_k(3)>(a, grid, stream);
-    case 4: return launch_k<4, resident_max_k(4)>(a, grid, stream);
-    case 6: return launch_k<6, resident_max_k(6)>(a, grid, stream);
+    case 1: return launch_em_resident_part1(a, stream);
+    case 2: return launch_em_resident_part2(a, stream);
+    case 3: return launch_em_resident_part3(a, stream);
+    case 4: return launch_em_resident_part4(a, stream);
+    case 6: return launch_em_resident_part5(a, stream);
     default: return false;
     }
 }
+#endif
 
 }  // namespace mstats
 }  // namespace mlhip

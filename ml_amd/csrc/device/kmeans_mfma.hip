@@ -24,6 +24,7 @@
 //
 // Update statistics: exact fixed-point limb sums with integer atomics, exactly as in kmeans.hip.
 #include "device.hpp"
+#include "parts.hpp"
 #include "exact_sum.hpp"
 
 namespace mlhip {
@@ -63,7 +64,7 @@ __device__ __forceinline__ void track_top2(double& best, double& second, double 
 /// fewer. The key keeps 20 mantissa bits: the exact phase turns (best, runner-up) back into a lower / upper bound of the two
 /// scores and demands their distance to exceed the rounding margin; the winner's quad (4 clusters) is then settled by exact
 /// direct-form distances, everything else falls back to the full scan.
-__device__ __forceinline__ void track_quad_keys(int& best, int& second, int& block, d4 acc, int this_block)
+[[maybe_unused]] __device__ __forceinline__ void track_quad_keys(int& best, int& second, int& block, d4 acc, int this_block)
 {
     const int k0 = __double2hiint(acc[0]), k1 = __double2hiint(acc[1]), k2 = __double2hiint(acc[2]), k3 = __double2hiint(acc[3]);
     const int m = max(max(k0, k1), max(k2, k3));
@@ -521,6 +522,48 @@ int launch_t(const KmeansArgs& a, int num_cus, size_t pstride, hipStream_t strea
 
 }  // namespace
 
+// ---- compiled in six parts by dimension (parts.hpp): 1: D = 4, 8; 2: 12, 16; 3: 20 .. 32; 4: 40 .. 64; 5: 72 .. 96; 6: 104 .. 128
+int MLHIP_PART_FN(launch_kmeans_mfma)(const KmeansArgs& a, int num_cus, size_t pstride, hipStream_t stream)
+{
+    switch (a.D) {
+#if MLHIP_PART == 1
+    case 4: return launch_t<4>(a, num_cus, pstride, stream);
+    case 8: return launch_t<8>(a, num_cus, pstride, stream);
+#elif MLHIP_PART == 2
+    case 12: return launch_t<12>(a, num_cus, pstride, stream);
+    case 16: return launch_t<16>(a, num_cus, pstride, stream);
+#elif MLHIP_PART == 3
+    case 20: return launch_t<20>(a, num_cus, pstride, stream);
+    case 24: return launch_t<24>(a, num_cus, pstride, stream);
+    case 28: return launch_t<28>(a, num_cus, pstride, stream);
+    case 32: return launch_t<32>(a, num_cus, pstride, stream);
+#elif MLHIP_PART == 4
+    case 40: return launch_t<40>(a, num_cus, pstride, stream);
+    case 48: return launch_t<48>(a, num_cus, pstride, stream);
+    case 56: return launch_t<56>(a, num_cus, pstride, stream);
+    case 64: return launch_t<64>(a, num_cus, pstride, stream);
+#elif MLHIP_PART == 5
+    case 72: return launch_t<72>(a, num_cus, pstride, stream);
+    case 80: return launch_t<80>(a, num_cus, pstride, stream);
+    case 88: return launch_t<88>(a, num_cus, pstride, stream);
+    case 96: return launch_t<96>(a, num_cus, pstride, stream);
+#elif MLHIP_PART == 6
+    case 104: return launch_t<104>(a, num_cus, pstride, stream);
+    case 112: return launch_t<112>(a, num_cus, pstride, stream);
+    case 120: return launch_t<120>(a, num_cus, pstride, stream);
+    case 128: return launch_t<128>(a, num_cus, pstride, stream);
+#endif
+    default: return -1;
+    }
+}
+
+#if MLHIP_PART == 1
+int launch_kmeans_mfma_part2(const KmeansArgs&, int, size_t, hipStream_t);
+int launch_kmeans_mfma_part3(const KmeansArgs&, int, size_t, hipStream_t);
+int launch_kmeans_mfma_part4(const KmeansArgs&, int, size_t, hipStream_t);
+int launch_kmeans_mfma_part5(const KmeansArgs&, int, size_t, hipStream_t);
+int launch_kmeans_mfma_part6(const KmeansArgs&, int, size_t, hipStream_t);
+
 /// The matrix-core kernel handles D = 4, 8, ..., 32, 40, ..., 128 and any K (tables beyond the LDS budget are streamed in chunks).
 bool kmeans_mfma_supported(int D, int K)
 {
@@ -531,29 +574,13 @@ bool kmeans_mfma_supported(int D, int K)
 int launch_kmeans_mfma(const KmeansArgs& a, int num_cus, hipStream_t stream)
 {
     const size_t pstride = 2 + (size_t)a.K * (3 * a.d + 1);
-    switch (a.D) {
-    case 4: return launch_t<4>(a, num_cus, pstride, stream);
-    case 8: return launch_t<8>(a, num_cus, pstride, stream);
-    case 12: return launch_t<12>(a, num_cus, pstride, stream);
-    case 16: return launch_t<16>(a, num_cus, pstride, stream);
-    case 20: return launch_t<20>(a, num_cus, pstride, stream);
-    case 24: return launch_t<24>(a, num_cus, pstride, stream);
-    case 28: return launch_t<28>(a, num_cus, pstride, stream);
-    case 32: return launch_t<32>(a, num_cus, pstride, stream);
-    case 40: return launch_t<40>(a, num_cus, pstride, stream);
-    case 48: return launch_t<48>(a, num_cus, pstride, stream);
-    case 56: return launch_t<56>(a, num_cus, pstride, stream);
-    case 64: return launch_t<64>(a, num_cus, pstride, stream);
-    case 72: return launch_t<72>(a, num_cus, pstride, stream);
-    case 80: return launch_t<80>(a, num_cus, pstride, stream);
-    case 88: return launch_t<88>(a, num_cus, pstride, stream);
-    case 96: return launch_t<96>(a, num_cus, pstride, stream);
-    case 104: return launch_t<104>(a, num_cus, pstride, stream);
-    case 112: return launch_t<112>(a, num_cus, pstride, stream);
-    case 120: return launch_t<120>(a, num_cus, pstride, stream);
-    case 128: return launch_t<128>(a, num_cus, pstride, stream);
-    default: return -1;
-    }
+    if (a.D <= 8) return launch_kmeans_mfma_part1(a, num_cus, pstride, stream);
+    if (a.D <= 16) return launch_kmeans_mfma_part2(a, num_cus, pstride, stream);
+    if (a.D <= 32) return launch_kmeans_mfma_part3(a, num_cus, pstride, stream);
+    if (a.D <= 64) return launch_kmeans_mfma_part4(a, num_cus, pstride, stream);
+    if (a.D <= 96) return launch_kmeans_mfma_part5(a, num_cus, pstride, stream);
+    return launch_kmeans_mfma_part6(a, num_cus, pstride, stream);
 }
+#endif
 
 }  // namespace mlhip

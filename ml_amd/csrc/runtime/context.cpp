@@ -82,6 +82,18 @@ mlhip_ctx* create_single_context(int device_id)
         HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
         ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        // The first host-to-device copy of a process sets up the runtime's copy path (8.4 ms on the MI355X box, rocprofv3 --hip-trace of
+        // tools/first_call.py: inside the first fit's upload). Every fit uploads its samples and reads results back, so the two
+        // directions are touched here, once per context, next to the ~150 ms the device initialisation takes anyway.
+        {
+            DevBuf probe;
+            probe.reserve(64);
+            double word[8] = {0};
+            HIP_CHECK(hipMemcpyAsync(probe.p, word, sizeof word, hipMemcpyHostToDevice, ctx->stream));
+            HIP_CHECK(hipMemcpyAsync(word, probe.p, sizeof word, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            probe.release();
+        }
     } catch (...) {
         delete ctx;
         throw;

@@ -255,9 +255,15 @@ def test_two_operation_density_form_and_its_guard(ctx, oracle, d, K, n, monkeypa
     assert c[0] == e[0] and np.array_equal(c[1], e[1]) and np.array_equal(c[2], e[2]) and np.array_equal(c[3], e[3])
 
 
+def _experiments_build():
+    from ml_amd import _lib
+    return os.path.basename(_lib.LIB_PATH) == "libmlhip_exp.so"
+
+
+@pytest.mark.skipif(not _experiments_build(), reason="em_diag_sgpr_kernel is an A/B variant: `make -C ml_amd/csrc EXPERIMENTS=1`, MLHIP_LIBRARY=.../libmlhip_exp.so")
 @pytest.mark.parametrize("d,K,n", [(16, 16, 20000), (12, 7, 9000), (6, 16, 9000), (3, 4, 5000)])
 def test_matrix_core_density_form_and_its_guard(ctx, oracle, d, K, n, monkeypatch):
-    """MLHIP_DIAG_GEMM=1 (an A/B variant, off by default): the log-densities as ONE product [K x 2d] . [x~^2 ; x~] on the matrix
+    """MLHIP_DIAG_GEMM=1 (an A/B variant, in `make EXPERIMENTS=1` builds only): the log-densities as ONE product [K x 2d] . [x~^2 ; x~] on the matrix
     cores -- the expanded form, whose cancellation costs about 4 eps B2 in a log-responsibility, B2_k = |(mu_k - shift) / sigma_k|^2.
     Overlapping components whose PAIRS sit far from the global mean (B2 of several hundred, responsibilities strictly between 0
     and 1): within the usual tolerances of the oracle while every B2 is below the limit; beyond it the kernel takes the exact
