@@ -668,11 +668,40 @@ __global__ __launch_bounds__(256, 2) void em_diag_mixed_kernel(
     double* bl = smem + 4 * (TS * XSS + TS * RSS);            // [D][KMAX] pairs (a, b): the records' trailer, interleaved
     constexpr int ONE = D, ZERO = D + 1;                      // LDS row: [x~_0 .. x~_(D-1) | 1 | 0]
     const double* __restrict__ aT = params + (size_t)KMAX * PS;
-    for (int e = tid; e < KMAX * D; e += 256) { bl[2 * e] = aT[e]; bl[2 * e + 1] = aT[KMAX * D + e]; }
-    // every record must allow the two-operation form (wave-uniform: scalar loads and compares)
-    bool ab = allow_two_op != 0;
+    const uint32_t n_tiles = (n + TW - 1) / TW;
+    const uint32_t stride = gridDim.x * 4;
+    // The samples of the wave's FIRST tile are requested before anything else, so the HBM round trip runs under the staging of the
+    // records; every later tile loads its samples at its head, the other wave of the SIMD covering for the round trip. (Round 5 also
+    // measured the next tile's samples requested slot by slot during the statistics phase: 2 - 3 us SLOWER -- the 32 coordinate
+    // registers stay live through the matrix phase and the loads queue behind its LDS traffic; profiles/r05_diag_skeleton.txt.
+    // The timing build keeps that placement as bit 128.)
+    double x[S][D];
+    {
+        const uint32_t t0 = blockIdx.x * 4 + wave;
+        const uint32_t i0 = (t0 < n_tiles ? t0 : 0) * TW + lane;
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) ab = ab && params[(size_t)k * PS + 2 * D + 1] <= kDiagAbLimit * kDiagAbLimit;   // (B2: layout.hpp; a NaN fails)
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int j = 0; j < D; ++j) x[s][j] = xt[(size_t)j * ldx + i0 + TS * s];
+    }
+    // Timing builds (`make EXPERIMENTS=1`, MLHIP_DIAG_KO=mask, tools/diag_knockout.py; profiles/r05_diag_skeleton.txt): phases of the
+    // kernel switched off at run time by wave-uniform branches -- the results are WRONG by construction. 1: density loop, 2: exponentials,
+    // 4: statistics phase, 8: sample loads after a wave's first tile, 16: lse store, 32: prologue, 64: partial-block flush, 128: the next
+    // tile's samples requested during the statistics phase instead of at the head of the tile. The default build has no such branches.
+#ifdef MLHIP_EXPERIMENTS
+    const int ko = __builtin_amdgcn_readfirstlane(allow_two_op >> 8);
+#define MLHIP_KO(bit) ((ko & (bit)) != 0)
+#else
+#define MLHIP_KO(bit) false
+#endif
+    if (!MLHIP_KO(32))
+        for (int e = tid; e < KMAX * D; e += 256) { bl[2 * e] = aT[e]; bl[2 * e + 1] = aT[KMAX * D + e]; }
+    // every record must allow the two-operation form (wave-uniform: scalar loads and compares)
+    bool ab = (allow_two_op & 1) != 0;
+    if (!MLHIP_KO(32)) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) ab = ab && params[(size_t)k * PS + 2 * D + 1] <= kDiagAbLimit * kDiagAbLimit;   // (B2: layout.hpp; a NaN fails)
+    }
     __syncthreads();
 
     int offa[CB], offb[CB];
@@ -687,8 +716,6 @@ __global__ __launch_bounds__(256, 2) void em_diag_mixed_kernel(
 #pragma unroll
     for (int c = 0; c < CB; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
 
-    const uint32_t n_tiles = (n + TW - 1) / TW;
-    const uint32_t stride = gridDim.x * 4;
     const double* xbase = Xw + 16 * (lane >> 4) * XSS;
     lds_cdouble* pa[CB];
     lds_cdouble* pb[CB];
@@ -707,11 +734,12 @@ __global__ __launch_bounds__(256, 2) void em_diag_mixed_kernel(
         lds_cd2* blv = (lds_cd2*)bl;                          // ONE base register: every b read is `ds_read_b128 base offset:imm`
         asm volatile("" : "+v"(blv));
         const uint32_t i0 = tile * TW + lane;                 // sample of slot s: i0 + 64 s (< n_pad: a multiple of 256)
-        double x[S][D];
+        if (!MLHIP_KO(128) && !MLHIP_KO(8) && tile != blockIdx.x * 4 + wave) {
 #pragma unroll
-        for (int s = 0; s < S; ++s)
+            for (int s = 0; s < S; ++s)
 #pragma unroll
-            for (int j = 0; j < D; ++j) x[s][j] = xt[(size_t)j * ldx + i0 + TS * s];
+                for (int j = 0; j < D; ++j) x[s][j] = xt[(size_t)j * ldx + i0 + TS * s];
+        }
 
         // ---- 1. log-densities of all 16 component slots (records k >= K are neutral: a = b = 0, coef = -inf)
         double lwv[S][KMAX];
@@ -736,6 +764,7 @@ __global__ __launch_bounds__(256, 2) void em_diag_mixed_kernel(
             // v_fma_f64 right behind its producer stalls.
             constexpr int KH = KMAX / 2;
                 d2 pv[2][KH];
+            if (!MLHIP_KO(1)) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -762,6 +791,7 @@ __global__ __launch_bounds__(256, 2) void em_diag_mixed_kernel(
                         }
                     }
                 }
+            }
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) {
                 const double coef = params[(size_t)k * PS + 2 * D];
@@ -816,7 +846,7 @@ __global__ __launch_bounds__(256, 2) void em_diag_mixed_kernel(
                 double e[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) e[u] = lwv[s][k8 + u] - m[s];
-                exp_nonpos_n<8>(e);                                              // exp(-inf) = 0 for the neutral tail
+                if (!MLHIP_KO(2)) exp_nonpos_n<8>(e);                            // exp(-inf) = 0 for the neutral tail
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     lwv[s][k8 + u] = e[u];
@@ -825,12 +855,13 @@ __global__ __launch_bounds__(256, 2) void em_diag_mixed_kernel(
             }
             const double lse = m[s] + log(sum);
             const bool live = i0 + TS * s < n;
-            lse_out[i0 + TS * s] = lse;
+            if (!MLHIP_KO(16)) lse_out[i0 + TS * s] = lse;
             if (live) ll_acc += lse;
             inv[s] = live ? 1.0 / sum : 0.0;                     // padding samples contribute nothing
         }
 
         // ---- 3. per 64-sample slot: tiles -> LDS, statistics on the matrix cores
+        if (!MLHIP_KO(4))
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             __builtin_amdgcn_wave_barrier();
@@ -842,6 +873,13 @@ __global__ __launch_bounds__(256, 2) void em_diag_mixed_kernel(
             for (int it = 0; it < 16; ++it) Rw[lane * RSS + it] = lwv[s][it] * inv[s];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+#ifdef MLHIP_EXPERIMENTS
+            if (tile + stride < n_tiles && !MLHIP_KO(8) && MLHIP_KO(128)) {   // (timing builds) slot s of the NEXT tile: in flight during the matrix phase
+                const uint32_t inext = (tile + stride) * TW + lane;
+#pragma unroll
+                for (int j = 0; j < D; ++j) x[s][j] = xt[(size_t)j * ldx + inext + TS * s];
+            }
+#endif
             __builtin_amdgcn_s_setprio(kMatrixPhasePriority);
 #pragma unroll 4
             for (int sg = 0; sg < TS / 4; ++sg) {
@@ -857,35 +895,39 @@ __global__ __launch_bounds__(256, 2) void em_diag_mixed_kernel(
         }
     }
 
-    // ---- epilogue: fold the 4 waves' accumulators, S0 sums and log-likelihood sums in fixed order
+    // ---- epilogue: the 4 waves' accumulators and S0 sums folded in fixed order  (((0 + w0) + w1) + w2) + w3  -- through LDS (every
+    // wave parks its values in its own, now idle, tile region; one barrier; one store per output). Round 4 chained the waves through
+    // global memory, a read-modify-write and a barrier per wave: 4.5 us of a 77 us kernel.
     s0 += __shfl_xor(s0, 16, 64);
     s0 += __shfl_xor(s0, 32, 64);
+    constexpr int WREG = TS * XSS + TS * RSS;                  // doubles per wave region (>= 64 (4 CB + 1))
+    static_assert(64 * (4 * CB + 1) <= WREG, "the parked accumulators must fit a wave's tile region");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Xw[(c * 4 + g) * 64 + lane] = acc[c][g];
+    Xw[4 * CB * 64 + lane] = s0;
+    __syncthreads();
     double* out = partials + (size_t)blockIdx.x * KP * FP;
-    for (int w = 0; w < 4; ++w) {
-        if (w == wave) {
-#pragma unroll
-            for (int c = 0; c < CB; ++c)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int k = (lane >> 4) + 4 * g;
-                    const int f = c * 16 + (lane & 15);
-                    if (f < 2 * d) {
-                        double* p = out + (size_t)k * FP + f;
-                        *p = (w == 0 ? 0.0 : *p) + acc[c][g];
-                    }
-                }
-            if (lane < 16) {
-                double* p = out + (size_t)lane * FP + 2 * d;
-                *p = (w == 0 ? 0.0 : *p) + s0;
-            }
+    if (!MLHIP_KO(64)) {
+        for (int e = tid; e < 4 * CB * 64; e += 256) {
+            const int l = e & 63, g = (e >> 6) & 3, c = e >> 8;
+            const int k = (l >> 4) + 4 * g, f = c * 16 + (l & 15);
+            if (f < 2 * d)
+                out[(size_t)k * FP + f] = (((0.0 + smem[e]) + smem[WREG + e]) + smem[2 * WREG + e]) + smem[3 * WREG + e];
         }
-        __syncthreads();
+        if (tid < 16) {
+            const int e = 4 * CB * 64 + tid;
+            out[(size_t)tid * FP + 2 * d] = (((0.0 + smem[e]) + smem[WREG + e]) + smem[2 * WREG + e]) + smem[3 * WREG + e];
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ll_acc += __shfl_down(ll_acc, off, 64);
     if (lane == 0) red[wave] = ll_acc;
     __syncthreads();
     if (tid == 0) ll_partials[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+#undef MLHIP_KO
 }
 
 /// Shapes em_diag_mixed_kernel serves: one row block of components, d <= 16. In a `make EXPERIMENTS=1` build MLHIP_DIAG_MIXED=0 /
@@ -907,6 +949,17 @@ __global__ __launch_bounds__(256, 2) void em_diag_mixed_kernel(
     if ((e && e[0] == '0') || (g && g[0] == '1')) return false;
 #endif
     return K <= 16 && padded_dim(d) <= 16;
+}
+
+/// Timing builds only (em_diag_mixed_kernel): MLHIP_DIAG_KO=mask in a `make EXPERIMENTS=1` build; 0 otherwise.
+[[maybe_unused]] inline int diag_knockouts()
+{
+#ifdef MLHIP_EXPERIMENTS
+    const char* e = std::getenv("MLHIP_DIAG_KO");
+    return e && *e ? (std::atoi(e) << 8) : 0;
+#else
+    return 0;
+#endif
 }
 
 constexpr int rbw_of(int RBT) { return RBT >= 2 ? 2 : 1; }
@@ -940,7 +993,7 @@ int launch_t(const DiagArgs& a, int grid, hipStream_t stream)
             const size_t smem = sizeof(double) * (4 * ((size_t)TS * XSS + (size_t)TS * RSS) + (size_t)32 * D);
             hipLaunchKernelGGL((em_diag_mixed_kernel<D, CB, 2>), dim3(grid), dim3(256), smem, stream, a.xt, a.ldx, a.n, a.d, a.shift,
                                a.params, a.K, a.lse, a.partials, em_diag_partial_rows(a.K), em_diag_partial_cols(a.d), a.ll_partials,
-                               (a.two_op && diag_ab_limit() > 0) ? 1 : 0);
+                               ((a.two_op && diag_ab_limit() > 0) ? 1 : 0) | diag_knockouts());
             return grid;
         }
 #ifdef MLHIP_EXPERIMENTS

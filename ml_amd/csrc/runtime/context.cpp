@@ -82,17 +82,19 @@ mlhip_ctx* create_single_context(int device_id)
         HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
         ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        // The first host-to-device copy of a process sets up the runtime's copy path (8.4 ms on the MI355X box, rocprofv3 --hip-trace of
-        // tools/first_call.py: inside the first fit's upload). Every fit uploads its samples and reads results back, so the two
-        // directions are touched here, once per context, next to the ~150 ms the device initialisation takes anyway.
+        // The first copy between PINNED host memory and the device sets up the runtime's DMA path (8.4 ms on the MI355X box, rocprofv3
+        // --hip-trace of tools/first_call.py: inside the first fit's upload; a copy from pageable memory does not take that path).
+        // Every fit uploads its samples through the pinned staging pair and reads results back the same way, so both directions
+        // are touched here, once per context, next to the ~150 ms the device initialisation takes anyway; the two small blocks
+        // stay with the context as the first staging pair.
         {
-            DevBuf probe;
-            probe.reserve(64);
-            double word[8] = {0};
-            HIP_CHECK(hipMemcpyAsync(probe.p, word, sizeof word, hipMemcpyHostToDevice, ctx->stream));
-            HIP_CHECK(hipMemcpyAsync(word, probe.p, sizeof word, hipMemcpyDeviceToHost, ctx->stream));
+            const size_t probe = 64 * 1024;
+            ctx->up_pin[0].reserve(probe);
+            ctx->up_stage[0].reserve(probe);
+            std::memset(ctx->up_pin[0].p, 0, probe);
+            HIP_CHECK(hipMemcpyAsync(ctx->up_stage[0].p, ctx->up_pin[0].p, probe, hipMemcpyHostToDevice, ctx->stream));
+            HIP_CHECK(hipMemcpyAsync(ctx->up_pin[0].p, ctx->up_stage[0].p, probe, hipMemcpyDeviceToHost, ctx->stream));
             HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            probe.release();
         }
     } catch (...) {
         delete ctx;
