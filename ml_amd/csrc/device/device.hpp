@@ -170,9 +170,15 @@ struct CloseArgs {
     double* mixing; double* means; double* covs;             // out (device): [K], [K*d], [K*d*d] (diagonal: [K*d] variances)
     double* records;                                         // out (device): the next E-step's K records
     double* info;                                            // out (device): [ll_sum | refine flag (K) | max |W (mu - shift)| (K)]
+    double* work;                                            // d > 64: em_close_work_doubles(d, K) doubles of device scratch
 };
 size_t em_close_info_doubles(int K);
-bool em_close_supported(int d);                              // d <= 64 (two d x d matrices in LDS)
+bool em_close_supported(int d);                              // d <= 64: one wave per component, the matrices in LDS (em_close.hip);
+                                                             // 64 < d <= 1024: panelled, the matrices in global memory (em_close_big.hip)
+size_t em_close_work_doubles(int d, int K);                  // 0 for d <= 64
+bool em_close_big_supported(int d);
+size_t em_close_big_work_doubles(int d, int K);
+void launch_em_close_big(const CloseArgs& a, hipStream_t stream);
 void launch_em_close(const CloseArgs& a, hipStream_t stream);
 void launch_em_close_diag(const CloseArgs& a, hipStream_t stream);
 /// Fixed-order combination of `n_partials` blocks [KP][FP] (and of the log-likelihood partials) into stats[K*F (+1)].

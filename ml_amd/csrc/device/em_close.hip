@@ -92,11 +92,13 @@ __global__ __launch_bounds__(64) void em_close_diag_kernel(const double* __restr
 }  // namespace
 
 size_t em_close_info_doubles(int K) { return 1 + 2 * (size_t)K; }
-bool em_close_supported(int d) { return d >= 1 && d <= kMidDim; }
+bool em_close_supported(int d) { return (d >= 1 && d <= kMidDim) || em_close_big_supported(d); }
+size_t em_close_work_doubles(int d, int K) { return em_close_big_supported(d) ? em_close_big_work_doubles(d, K) : 0; }
 
 void launch_em_close(const CloseArgs& a, hipStream_t stream)
 {
     const int d = a.d;
+    if (d > kMidDim) { launch_em_close_big(a, stream); return; }
     const size_t smem = sizeof(double) * closing::scratch_doubles(d);
 #define MLHIP_CLOSE(LAYOUT, DT, PS) \
     hipLaunchKernelGGL((em_close_kernel<LAYOUT, DT>), dim3(a.K), dim3(NT), smem, stream, a.stats, a.K, d, a.D, a.shift, a.n_global, \

@@ -1,0 +1,346 @@
+// Closing arithmetic of the M-step on the device for 64 < d <= 1024 -- what em_close.hip does for d <= 64 with one wave per component
+// and both d x d matrices in LDS (reference ML/EM.cpp:242, 250-257, 274-287: new mixing weight, mean, covariance, its Cholesky factor L,
+// W = L^-1, sum log L_jj, the next E-step's record). Here the matrices live in global memory (a component's pair is 16 MB at d = 1024;
+// they stay in L2) and the factorization runs as a short sequence of launches over column PANELS of 32:
+//
+//   prepare      statistics -> mean, covariance (-> the caller's pack and the workspace), refinement codes; W starts as the identity
+//   per panel    chol_diag  : ONE wave per component factors the 32 x 32 diagonal block in registers (lane = row, partners by v_readlane)
+//   (of L)       chol_rows  : every row below the block, one thread per row: the panel's own columns against the diagonal block
+//                chol_trail : RIGHT-looking -- the panel's 32 terms go to every entry of the trailing matrix at once (one thread per
+//                             row and 32 columns, the partner rows' values by scalar loads): all the parallelism of the factorization
+//   per panel    whiten_solve : the panel's 32 rows of W = L^-1 against the diagonal block, one thread per column of W
+//   (of W)       whiten_trail : their terms to every later row at once
+//   finish       sum log L_jj, c = W (mean - shift), flags, the record in the E-step's layout, the info block
+// A first form walked the earlier columns per panel (left-looking: one launch per panel and long chains per thread: 25 ms at d = 1024,
+// K = 4); with the trailing updates every launch is short and wide (3 + 2 launches per panel).
+//
+// Until round 4 these dimensions closed on the host (K factorizations on a thread team: 1.7 ms of a 24 ms iteration at d = 128,
+// K = 32; 60 of 70 ms at d = 1024, K = 4).
+//
+// Every VALUE is formed by the host's operations on the host's operands in the host's order (host/em_math.cpp finalize_mstep,
+// cholesky_lower, whitening_matrix, the record builders): an entry of L or W receives its terms in ascending l, one product and one
+// subtraction at a time (contraction off), then one division -- whichever thread evaluates it and however the loops are blocked. So
+// the parameters agree with the host path bit for bit except through log() (one ulp of the library function), exactly as for d <= 64,
+// and all ranks of a row-sharded job hold bit-identical parameters.
+#include "device.hpp"
+
+#pragma clang fp contract(off)     // the host's closing arithmetic, statement by statement (see above)
+
+namespace mlhip {
+namespace {
+
+constexpr int PB = 32;             // panel width (columns of L / rows of W handled per step)
+
+__device__ __forceinline__ int sidx(int a, int b) { return a * (a + 1) / 2 + b; }   // stats_index
+
+/// Workspace of one component (doubles): L (d x d column-major: L[l * d + i] = L(i, l); starts as the covariance), Wt (d x d:
+/// Wt[i * d + c] = W(i, c)), mean (d), c = W (mean - shift) (d), log L_jj (d), refinement codes (d).
+__host__ __device__ inline size_t big_stride(int d) { return 2 * (size_t)d * d + 4 * (size_t)d; }
+
+struct BigView {
+    double *L, *Wt, *mean, *c, *logs, *codes;
+    __device__ BigView(double* work, int k, int d)
+    {
+        L = work + (size_t)k * big_stride(d);
+        Wt = L + (size_t)d * d;
+        mean = Wt + (size_t)d * d;
+        c = mean + d;
+        logs = c + d;
+        codes = logs + d;
+    }
+};
+
+__device__ __forceinline__ double lane_value(double v, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
+/// Covariance entries (one thread each), means, mixing weight, refinement codes (em_close_body.hpp's first part, from global memory).
+__global__ __launch_bounds__(256) void close_big_prepare_kernel(const double* __restrict__ stats, int K, int d, const double* __restrict__ shift,
+                                                                 double n_global, double refine_limit, double* __restrict__ mixing,
+                                                                 double* __restrict__ means, double* __restrict__ covs, double* __restrict__ work)
+{
+    const int k = blockIdx.x;
+    const int F = (d + 1) * (d + 2) / 2;
+    const double* __restrict__ s = stats + (size_t)k * F;
+    BigView v(work, k, d);
+    const double s0 = s[sidx(d, d)];
+    const size_t e = (size_t)blockIdx.y * 256 + threadIdx.x;
+    if (e < (size_t)d * d) {
+        const int a = (int)(e % d), b = (int)(e / d);                                // element (a, b), column-major
+        const int hi = a > b ? a : b, lo = a > b ? b : a;
+        const double mlo = s[sidx(d, lo)] / s0;
+        double x = (s[sidx(hi, lo)] - s[sidx(d, hi)] * mlo) / s0;
+        if (a == b) x += 1e-15;                                                      // ML/EM.cpp:252
+        v.L[e] = x;
+        v.Wt[e] = a == b ? 1.0 : 0.0;
+        covs[(size_t)k * d * d + e] = x;
+        if (a == b) {
+            const double mean = shift[a] + mlo;
+            const double off = mean - shift[a];
+            v.mean[a] = mean;
+            means[(size_t)k * d + a] = mean;
+            v.codes[a] = (!isfinite(off) || !isfinite(x)) ? 2.0 : ((refine_limit > 0 && off * off > refine_limit * x) ? 1.0 : 0.0);
+        }
+    }
+    if (e == 0) mixing[k] = s0 / n_global;                                           // ML/EM.cpp:257
+}
+
+/// The panel's 32 x 32 diagonal block (rows j0 .. j0 + 31, lane = row; the terms of all columns l < j0 are in: chol_trail_kernel),
+/// factored in registers as em_close_body.hpp factors a whole d <= 32 matrix. One wave per component.
+__global__ __launch_bounds__(64) void chol_diag_kernel(double* __restrict__ work, int d, int j0)
+{
+    const int k = blockIdx.x, r = threadIdx.x;
+    BigView v(work, k, d);
+    const int nb = d - j0 < PB ? d - j0 : PB;
+    const bool row = r < nb;
+    const int i = j0 + (row ? r : 0);
+    double t[PB];
+#pragma unroll
+    for (int c = 0; c < PB; ++c) t[c] = (row && c < nb) ? v.L[(size_t)(j0 + c) * d + i] : 0.0;
+#pragma unroll
+    for (int jj = 0; jj < PB; ++jj) {
+        if (jj < nb) {                                                               // (uniform)
+            double tt = t[jj];
+#pragma unroll
+            for (int l = 0; l < jj; ++l) tt -= t[l] * lane_value(t[l], jj);          // L(i, j0 + l) * L(j0 + jj, j0 + l)
+            const double ljj = sqrt(lane_value(tt, jj));
+            t[jj] = r == jj ? ljj : tt / ljj;                                        // (rows above the diagonal: unused)
+        }
+    }
+    if (row) {
+#pragma unroll
+        for (int c = 0; c < PB; ++c)
+            if (c <= r && c < nb) v.L[(size_t)(j0 + c) * d + i] = t[c];
+    }
+}
+
+/// Rows below the panel's diagonal block, one thread per row: the panel's own columns against the diagonal block (final:
+/// chol_diag_kernel ran before). `work_ro` is the same workspace, read-only here for everything this kernel reads through it (the
+/// diagonal rows: other rows than the ones it writes) -- uniform addresses, scalar loads.
+__global__ __launch_bounds__(64) void chol_rows_kernel(double* __restrict__ work, const double* __restrict__ work_ro, int d, int j0)
+{
+    const int k = blockIdx.x;
+    BigView v(work, k, d);
+    const double* __restrict__ Lro = work_ro + (size_t)k * big_stride(d);
+    const int nb = d - j0 < PB ? d - j0 : PB;
+    const int i_raw = j0 + PB + blockIdx.y * 64 + threadIdx.x;
+    const bool row = i_raw < d;
+    const int i = row ? i_raw : d - 1;
+    double t[PB];
+#pragma unroll
+    for (int c = 0; c < PB; ++c) t[c] = c < nb ? v.L[(size_t)(j0 + c) * d + i] : 0.0;
+#pragma unroll
+    for (int c = 0; c < PB; ++c) {
+        if (c < nb) {                                                                // (uniform)
+#pragma unroll
+            for (int c2 = 0; c2 < c; ++c2) t[c] -= t[c2] * Lro[(size_t)(j0 + c2) * d + j0 + c];
+            t[c] = t[c] / Lro[(size_t)(j0 + c) * d + j0 + c];
+        }
+    }
+    if (row) {
+#pragma unroll
+        for (int c = 0; c < PB; ++c)
+            if (c < nb) v.L[(size_t)(j0 + c) * d + i] = t[c];
+    }
+}
+
+/// Right-looking step of the factorization: the terms l = j0 .. j0 + 31 of the panel just finished go to the entries (i, jb + c),
+/// c = 0 .. 31, of one later column block -- one thread per row i >= jb, 32 accumulators, the partner values L(jb + c, l) by scalar
+/// loads. Every entry receives its terms in ascending l: panels in order, l in order inside a panel.
+__global__ __launch_bounds__(64) void chol_trail_kernel(double* __restrict__ work, const double* __restrict__ work_ro, int d, int j0)
+{
+    const int k = blockIdx.x;
+    BigView v(work, k, d);
+    const double* __restrict__ Lro = work_ro + (size_t)k * big_stride(d);
+    const int jb = j0 + PB + (int)blockIdx.z * PB;                                   // first column of the block
+    const int nbc = d - jb < PB ? d - jb : PB;
+    const int i_raw = jb + blockIdx.y * 64 + threadIdx.x;
+    if (jb + (int)blockIdx.y * 64 >= d) return;                                       // (uniform: no row of this block exists)
+    const bool row = i_raw < d;
+    const int i = row ? i_raw : d - 1;
+    double t[PB];
+#pragma unroll
+    for (int c = 0; c < PB; ++c) t[c] = c < nbc ? v.L[(size_t)(jb + c) * d + i] : 0.0;
+#pragma unroll 4
+    for (int l = j0; l < j0 + PB; ++l) {
+        const double xl = v.L[(size_t)l * d + i];                                    // L(i, l)
+        const double* __restrict__ cl = Lro + (size_t)l * d + jb;                    // L(jb + c, l), c = 0 .. 31 (uniform)
+#pragma unroll
+        for (int c = 0; c < PB; ++c) t[c] -= xl * cl[c];
+    }
+    if (row) {
+#pragma unroll
+        for (int c = 0; c < PB; ++c)
+            if (c < nbc) v.L[(size_t)(jb + c) * d + i] = t[c];
+    }
+}
+
+/// W = L^-1 (host/em_math.cpp whitening_matrix): entry (i, c) starts from (i == c), receives L(i, l) W(l, c) for l = c .. i - 1 in
+/// ascending order and is divided by L(i, i); for l < c the factor W(l, c) is an exact zero (stored as such: t - L * 0 == t), and the
+/// entries above the diagonal are set to zero as the host sets them. Stored transposed (Wt[i * d + c]: the threads of a wave -- one
+/// per column c -- touch neighbouring words). This kernel: the 32 rows i0 .. of one panel against the diagonal block of L, the terms of
+/// all rows l < i0 being in (whiten_trail_kernel).
+__global__ __launch_bounds__(64) void whiten_solve_kernel(double* __restrict__ work, const double* __restrict__ work_ro, int d, int i0)
+{
+    const int k = blockIdx.x;
+    BigView v(work, k, d);
+    const double* __restrict__ Lro = work_ro + (size_t)k * big_stride(d);
+    const int nb = d - i0 < PB ? d - i0 : PB;
+    const int c_raw = blockIdx.y * 64 + threadIdx.x;
+    const bool col = c_raw < i0 + nb;                                                // (columns right of the panel: zeros already)
+    const int c = col ? c_raw : 0;
+    double acc[PB];
+#pragma unroll
+    for (int r = 0; r < PB; ++r) acc[r] = r < nb ? v.Wt[(size_t)(i0 + r) * d + c] : 0.0;
+#pragma unroll
+    for (int r = 0; r < PB; ++r) {
+        if (r < nb) {                                                                // (uniform)
+            const int i = i0 + r;
+#pragma unroll
+            for (int r2 = 0; r2 < r; ++r2) acc[r] -= Lro[(size_t)(i0 + r2) * d + i] * acc[r2];
+            acc[r] = i < c ? 0.0 : acc[r] / Lro[(size_t)i * d + i];
+        }
+    }
+    if (col) {
+#pragma unroll
+        for (int r = 0; r < PB; ++r)
+            if (r < nb) v.Wt[(size_t)(i0 + r) * d + c] = acc[r];
+    }
+}
+
+/// The finished rows l = i0 .. i0 + 31 of W go to the 32 later rows ib .. of one row block: (i, c) -= L(i, l) W(l, c), ascending l.
+/// Only the columns c < i0 + 32 can hold anything but zero.
+__global__ __launch_bounds__(64) void whiten_trail_kernel(double* __restrict__ work, const double* __restrict__ work_ro, int d, int i0)
+{
+    const int k = blockIdx.x;
+    BigView v(work, k, d);
+    const double* __restrict__ Lro = work_ro + (size_t)k * big_stride(d);
+    const int ib = i0 + PB + (int)blockIdx.z * PB;                                   // first row of the block
+    const int nbr = d - ib < PB ? d - ib : PB;
+    const int c_raw = blockIdx.y * 64 + threadIdx.x;
+    const bool col = c_raw < i0 + PB;
+    const int c = col ? c_raw : 0;
+    double acc[PB];
+#pragma unroll
+    for (int r = 0; r < PB; ++r) acc[r] = r < nbr ? v.Wt[(size_t)(ib + r) * d + c] : 0.0;
+#pragma unroll 4
+    for (int l = i0; l < i0 + PB; ++l) {
+        const double wl = v.Wt[(size_t)l * d + c];                                   // W(l, c)
+        const double* __restrict__ cl = Lro + (size_t)l * d + ib;                    // L(ib + r, l), r = 0 .. 31 (uniform)
+#pragma unroll
+        for (int r = 0; r < PB; ++r) acc[r] -= cl[r] * wl;
+    }
+    if (col) {
+#pragma unroll
+        for (int r = 0; r < PB; ++r)
+            if (r < nbr) v.Wt[(size_t)(ib + r) * d + c] = acc[r];
+    }
+}
+
+/// sum log L_jj, c = W (mean - shift), the refinement flag, the next E-step's record, the info block (em_close_body.hpp's last part,
+/// from global memory). One workgroup per component.
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void close_big_finish_kernel(const double* __restrict__ stats, int K, int d, int D,
+                                                                const double* __restrict__ shift, const double* __restrict__ mixing,
+                                                                double* __restrict__ work, double* __restrict__ records, int PS,
+                                                                double* __restrict__ info)
+{
+    __shared__ double red[256];
+    __shared__ double s_coef;
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const int F = (d + 1) * (d + 2) / 2;
+    BigView v(work, k, d);
+    const double mix = mixing[k];
+    for (int j = tid; j < d; j += 256) v.logs[j] = log(v.L[(size_t)j * d + j]);
+    double reach = 0.0;
+    for (int i = tid; i < d; i += 256) {
+        double acc = 0.0;
+        for (int col = 0; col <= i; ++col) acc += v.Wt[(size_t)i * d + col] * (v.mean[col] - shift[col]);
+        v.c[i] = acc;
+        const double m = isfinite(acc) ? fabs(acc) : __builtin_inf();
+        reach = m > reach ? m : reach;
+    }
+    red[tid] = reach;
+    __syncthreads();
+    if (tid == 0) {
+        int flag = 0;                                                                // scanned in order, a non-finite entry ends the scan
+        if (mix > 0 && isfinite(mix))
+            for (int a = 0; a < d; ++a) {
+                if (v.codes[a] == 2.0) break;
+                if (v.codes[a] == 1.0) { flag = 1; break; }
+            }
+        info[1 + k] = flag;
+        double ldh = 0.0;
+        for (int j = 0; j < d; ++j) ldh += v.logs[j];                                // the host's order
+        s_coef = log(mix) - ldh;
+        double m = 0.0;
+        for (int t = 0; t < 256; ++t) m = red[t] > m ? red[t] : m;
+        info[1 + K + k] = m;
+        if (k == 0) info[0] = stats[(size_t)K * F];                                  // the log-likelihood sum rides along
+    }
+    __syncthreads();
+    double* __restrict__ rec = records + (size_t)k * PS;
+    if constexpr (LAYOUT == 2) {
+        const int Q = D / 4, NB = Q * (Q + 1) / 2;
+        for (int e = tid; e < NB * 16; e += 256) {
+            const int t = e / 16, kk = (e % 16) / 4, i = e % 4;
+            int C = 0;
+            while (C + 1 < Q && (C + 1) * Q - (C + 1) * C / 2 <= t) ++C;             // column-quad-major block order
+            const int R = C + (t - (C * Q - C * (C - 1) / 2));
+            const int row = 4 * R + i, colm = 4 * C + kk;
+            rec[e] = (row < d && colm <= row) ? v.Wt[(size_t)row * d + colm] : 0.0;
+        }
+        for (int j = tid; j < D; j += 256) {
+            rec[NB * 16 + j] = j < d ? v.mean[j] : 0.0;
+            rec[NB * 16 + D + j] = j < d ? -v.c[j] : 0.0;
+        }
+        if (tid == 0) rec[NB * 16 + 2 * D] = s_coef;
+    } else {
+        for (int j = tid; j < D; j += 256) rec[j] = j < d ? v.mean[j] : 0.0;
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int j = wave; j < D; j += 4) {                                          // packed lower triangle, row by row
+            double* __restrict__ out = rec + D + (size_t)j * (j + 1) / 2;
+            for (int l = lane; l <= j; l += 64) out[l] = j < d ? v.Wt[(size_t)j * d + l] : 0.0;
+        }
+        if (tid == 0) rec[PS - 1] = s_coef;
+    }
+}
+
+}  // namespace
+
+bool em_close_big_supported(int d) { return d > kMidDim && d <= 1024; }
+size_t em_close_big_work_doubles(int d, int K) { return (size_t)K * big_stride(d); }
+
+void launch_em_close_big(const CloseArgs& a, hipStream_t stream)
+{
+    const int d = a.d, K = a.K;
+    hipLaunchKernelGGL(close_big_prepare_kernel, dim3(K, (unsigned)(((size_t)d * d + 255) / 256)), dim3(256), 0, stream, a.stats, K, d, a.shift,
+                       a.n_global, a.refine_limit, a.mixing, a.means, a.covs, a.work);
+    for (int j0 = 0; j0 < d; j0 += PB) {
+        hipLaunchKernelGGL(chol_diag_kernel, dim3(K), dim3(64), 0, stream, a.work, d, j0);
+        const int below = d - (j0 + PB);                                             // rows / columns behind the panel
+        if (below > 0) {
+            hipLaunchKernelGGL(chol_rows_kernel, dim3(K, (below + 63) / 64), dim3(64), 0, stream, a.work, a.work, d, j0);
+            hipLaunchKernelGGL(chol_trail_kernel, dim3(K, (below + 63) / 64, (below + PB - 1) / PB), dim3(64), 0, stream, a.work, a.work, d, j0);
+        }
+    }
+    for (int i0 = 0; i0 < d; i0 += PB) {
+        const int cols = i0 + PB < d ? i0 + PB : d;                                  // columns that hold anything but zero so far
+        hipLaunchKernelGGL(whiten_solve_kernel, dim3(K, (cols + 63) / 64), dim3(64), 0, stream, a.work, a.work, d, i0);
+        const int below = d - (i0 + PB);
+        if (below > 0)
+            hipLaunchKernelGGL(whiten_trail_kernel, dim3(K, (cols + 63) / 64, (below + PB - 1) / PB), dim3(64), 0, stream, a.work, a.work, d, i0);
+    }
+    if (a.layout == 2) {
+        const int PS = estep_mfma4_param_stride(a.D);
+        hipLaunchKernelGGL(close_big_finish_kernel<2>, dim3(K), dim3(256), 0, stream, a.stats, K, d, a.D, a.shift, a.mixing, a.work, a.records,
+                           PS, a.info);
+    } else {
+        const int PS = estep_param_stride(a.D);
+        hipLaunchKernelGGL(close_big_finish_kernel<0>, dim3(K), dim3(256), 0, stream, a.stats, K, d, a.D, a.shift, a.mixing, a.work, a.records,
+                           PS, a.info);
+    }
+}
+
+}  // namespace mlhip

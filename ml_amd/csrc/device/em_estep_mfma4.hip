@@ -109,10 +109,16 @@ __global__ __launch_bounds__(64 * NW, D <= 32 ? 8 / SB : 2) void em_estep_mfma4_
         const uint32_t base = grp * GS;
         // coordinates in B-operand layout: xb[C][sb] = x[dim 4C + g][sample base + 16sb + s]
         double xb[Q][SB];
+        {
+            // (The row pointer is made opaque per tile: left to itself the compiler hoists all Q x SB 64-bit load addresses out of the
+            // tile loop and carries them in registers -- 64 to 128 of them at d > 64, spilled to scratch around every tile in round 4.)
+            const double* row = xt + (size_t)g * ldx + base + s;
+            asm volatile("" : "+v"(row));
 #pragma unroll
-        for (int C = 0; C < Q; ++C)
+            for (int C = 0; C < Q; ++C)
 #pragma unroll
-            for (int sb = 0; sb < SB; ++sb) xb[C][sb] = xt[(size_t)(4 * C + g) * ldx + base + 16 * sb + s];
+                for (int sb = 0; sb < SB; ++sb) xb[C][sb] = row[(size_t)(4 * C) * ldx + 16 * sb];
+        }
         if constexpr (FOLD) {
 #pragma unroll
             for (int C = 0; C < Q; ++C) {
@@ -309,6 +315,8 @@ int launch_t(const EstepArgs& a, int num_cus, hipStream_t stream)
 {
     // 64 < d: one sample block per wave (16 samples): 2D doubles per lane; 32 < d <= 64: two (D coordinate + D accumulator
     // doubles per lane pair do not fit otherwise); d <= 32: four (64 samples per wave)
+    // (Round 5 measured TWO blocks per wave at one wave per SIMD for 64 < d <= 128 -- 512 registers, half the LDS reads of W per matrix
+    // instruction: no faster, E-step 10.77 against 10.58 ms at N = 1M, d = 128, K = 32, 6.09 / 5.95 at d = 96, 3.70 / 3.60 at d = 72; not kept.)
     if constexpr (D > 64) return launch_v<D, 1>(a, num_cus, stream);
     else if constexpr (D > 32) return launch_v<D, 2>(a, num_cus, stream);
     else return launch_v<D, 4>(a, num_cus, stream);

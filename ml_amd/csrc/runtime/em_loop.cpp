@@ -9,7 +9,7 @@
 //   * the loop policies        -- run_synchronous (launch, wait, test: every shape), run_lagged (iteration i + 1 is launched before
 //                                 the host looks at iteration i: short iterations), run_resident (the WHOLE loop in one launch of
 //                                 resident workgroups, em_resident.hip: fits whose iteration is a few microseconds),
-//                                 host_closing_loop (d > 64, MLHIP_DEVICE_CLOSE=0);
+//                                 host_closing_loop (d > 1024, MLHIP_DEVICE_CLOSE=0);
 //   * close_on_host(i)         -- the one iteration a refinement flag (far, tight component) sends through the per-step arithmetic.
 // finish() leaves the device state as the per-step entry points expect it (records of the LAST E-step in params_dev).
 #include "internal.hpp"
@@ -97,6 +97,7 @@ struct EmLoop {
             data->it_info_slot[s].reserve(sizeof(double) * n_pack);
             if (!data->it_event[s]) HIP_CHECK(hipEventCreateWithFlags(&data->it_event[s], hipEventDisableTiming));
         }
+        if (const size_t w = em_close_work_doubles(d, K); w > 0 && !diag) data->close_work.reserve(sizeof(double) * w);
         rec[0] = &data->params_dev; rec[1] = &data->params_next; rec[2] = &data->params_prev;
         if (diag) {
             for (DevBuf* r : rec) upload_diag_records(data, K, mixing, means, covs, *r);   // (the neutral padding records live in all)
@@ -147,6 +148,7 @@ struct EmLoop {
         ca.mixing = pack_mixing(out); ca.means = pack_means(out); ca.covs = pack_covs(out);
         ca.records = rec[out]->as<double>();
         ca.info = info_pinned ? data->it_info_slot[out].as<double>() : pack_base(out);
+        ca.work = data->close_work.as<double>();
         ctx->timed("em_close", [&] { if (diag) launch_em_close_diag(ca, ctx->stream); else launch_em_close(ca, ctx->stream); });
         HIP_CHECK(hipGetLastError());
         if (!info_pinned && !pack_pinned)
@@ -416,7 +418,7 @@ struct EmLoop {
     }
 };
 
-/// d > 64 (no device closing), MLHIP_DEVICE_CLOSE=0, experimental record layouts: the loop over the per-step functions.
+/// d > 1024 (no device closing), MLHIP_DEVICE_CLOSE=0, experimental record layouts: the loop over the per-step functions.
 void host_closing_loop(mlhip_data* data, int K, bool diag, double* mixing, double* means, double* covs, uint32_t max_steps,
                        ConvergenceTest& test)
 {

@@ -371,6 +371,7 @@ struct mlhip_data {
     // (i + 1) % 3; it_pack: [info (1 + 2K) | mixing (K) | means (K d) | covariances]; one pinned read-back slot and event per pack
     DevBuf params_next, params_prev, it_pack[3];
     DevBuf it_sync, it_xch;       // device-resident loop (em_resident.hip): arrival counter / give-up flag, exchange blocks
+    DevBuf close_work;            // closing arithmetic at d > 64 (em_close_big.hip): the components' L and W
     PinnedBuf it_info_slot[3], it_history;   // it_history: [result words | log-likelihood history] of the resident loop
     hipEvent_t it_event[3] = {nullptr, nullptr, nullptr};
     // source of the last statistics pass (for the per-component refinement pass)
@@ -391,7 +392,7 @@ struct mlhip_data {
     {
         for (DevBuf* b : {&xt, &shift_dev, &lw, &lse, &esum, &ll_partials, &params_dev, &partials, &stats_dev, &resp_dev,
                           &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_cent_next, &km_partials, &km_out, &km_mind, &km_probe, &km_scale, &km_cnorm, &km_xt_pad, &kpp_w, &kpp_scr,
-                          &refine_shift, &refine_stats, &params_next, &params_prev, &it_pack[0], &it_pack[1], &it_pack[2], &it_sync, &it_xch})
+                          &refine_shift, &refine_stats, &params_next, &params_prev, &it_pack[0], &it_pack[1], &it_pack[2], &it_sync, &it_xch, &close_work})
             b->pool = pool;
         for (PinnedBuf* b : {&params_host, &stats_host, &km_host, &it_info_slot[0], &it_info_slot[1], &it_info_slot[2], &it_history}) b->pool = pool;
     }
@@ -401,7 +402,7 @@ struct mlhip_data {
         for (mlhip_data* p : parts) mlhip_data_free(p);
         for (DevBuf* b : {&xt, &shift_dev, &lw, &lse, &esum, &ll_partials, &params_dev, &partials, &stats_dev, &resp_dev,
                           &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_cent_next, &km_partials, &km_out, &km_mind, &km_probe, &km_scale, &km_cnorm, &km_xt_pad, &kpp_w, &kpp_scr,
-                          &refine_shift, &refine_stats, &params_next, &params_prev, &it_pack[0], &it_pack[1], &it_pack[2], &it_sync, &it_xch})
+                          &refine_shift, &refine_stats, &params_next, &params_prev, &it_pack[0], &it_pack[1], &it_pack[2], &it_sync, &it_xch, &close_work})
             b->release();
         for (auto& sl : it_info_slot) sl.release();
         for (auto& e : it_event) if (e) (void)hipEventDestroy(e);
