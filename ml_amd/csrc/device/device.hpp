@@ -179,6 +179,9 @@ size_t em_close_work_doubles(int d, int K);                  // 0 for d <= 64
 bool em_close_big_supported(int d);
 size_t em_close_big_work_doubles(int d, int K);
 void launch_em_close_big(const CloseArgs& a, hipStream_t stream);
+double* em_close_big_param_area(double* work, int d, int K);   // K (d d + d + 1) + 2 K + 1 doubles behind the matrices
+/// Records of GIVEN parameters (a fit's first E-step): a.mixing / a.means / a.covs are device inputs, a.stats unused.
+void launch_em_records_big(const CloseArgs& a, hipStream_t stream);
 void launch_em_close(const CloseArgs& a, hipStream_t stream);
 void launch_em_close_diag(const CloseArgs& a, hipStream_t stream);
 /// Fixed-order combination of `n_partials` blocks [KP][FP] (and of the log-likelihood partials) into stats[K*F (+1)].

@@ -86,6 +86,25 @@ __global__ __launch_bounds__(256) void close_big_prepare_kernel(const double* __
     if (e == 0) mixing[k] = s0 / n_global;                                           // ML/EM.cpp:257
 }
 
+/// The same start from GIVEN parameters (the records of a fit's first E-step: EM::fit's initial covariances, ML/EM.cpp:143-150 --
+/// host/em_math.cpp build_estep_params*): the covariance goes into the workspace as it is, no statistics, no refinement codes.
+__global__ __launch_bounds__(256) void close_big_from_params_kernel(const double* __restrict__ means, const double* __restrict__ covs, int d,
+                                                                     double* __restrict__ work)
+{
+    const int k = blockIdx.x;
+    BigView v(work, k, d);
+    const size_t e = (size_t)blockIdx.y * 256 + threadIdx.x;
+    if (e < (size_t)d * d) {
+        const int a = (int)(e % d), b = (int)(e / d);
+        v.L[e] = covs[(size_t)k * d * d + e];
+        v.Wt[e] = a == b ? 1.0 : 0.0;
+    }
+    if (e < (size_t)d) {
+        v.mean[e] = means[(size_t)k * d + e];
+        v.codes[e] = 0.0;
+    }
+}
+
 /// The panel's 32 x 32 diagonal block (rows j0 .. j0 + 31, lane = row; the terms of all columns l < j0 are in: chol_trail_kernel),
 /// factored in registers as em_close_body.hpp factors a whole d <= 32 matrix. One wave per component.
 __global__ __launch_bounds__(64) void chol_diag_kernel(double* __restrict__ work, int d, int j0)
@@ -277,7 +296,7 @@ __global__ __launch_bounds__(256) void close_big_finish_kernel(const double* __r
         double m = 0.0;
         for (int t = 0; t < 256; ++t) m = red[t] > m ? red[t] : m;
         info[1 + K + k] = m;
-        if (k == 0) info[0] = stats[(size_t)K * F];                                  // the log-likelihood sum rides along
+        if (k == 0 && stats) info[0] = stats[(size_t)K * F];                         // the log-likelihood sum rides along
     }
     __syncthreads();
     double* __restrict__ rec = records + (size_t)k * PS;
@@ -307,16 +326,10 @@ __global__ __launch_bounds__(256) void close_big_finish_kernel(const double* __r
     }
 }
 
-}  // namespace
-
-bool em_close_big_supported(int d) { return d > kMidDim && d <= 1024; }
-size_t em_close_big_work_doubles(int d, int K) { return (size_t)K * big_stride(d); }
-
-void launch_em_close_big(const CloseArgs& a, hipStream_t stream)
+/// L and W = L^-1 of the K matrices in the workspace, then the records / info block.
+void factor_and_finish(const double* stats, const double* mixing, const CloseArgs& a, hipStream_t stream)
 {
     const int d = a.d, K = a.K;
-    hipLaunchKernelGGL(close_big_prepare_kernel, dim3(K, (unsigned)(((size_t)d * d + 255) / 256)), dim3(256), 0, stream, a.stats, K, d, a.shift,
-                       a.n_global, a.refine_limit, a.mixing, a.means, a.covs, a.work);
     for (int j0 = 0; j0 < d; j0 += PB) {
         hipLaunchKernelGGL(chol_diag_kernel, dim3(K), dim3(64), 0, stream, a.work, d, j0);
         const int below = d - (j0 + PB);                                             // rows / columns behind the panel
@@ -334,13 +347,37 @@ void launch_em_close_big(const CloseArgs& a, hipStream_t stream)
     }
     if (a.layout == 2) {
         const int PS = estep_mfma4_param_stride(a.D);
-        hipLaunchKernelGGL(close_big_finish_kernel<2>, dim3(K), dim3(256), 0, stream, a.stats, K, d, a.D, a.shift, a.mixing, a.work, a.records,
-                           PS, a.info);
+        hipLaunchKernelGGL(close_big_finish_kernel<2>, dim3(K), dim3(256), 0, stream, stats, K, d, a.D, a.shift, mixing, a.work, a.records, PS,
+                           a.info);
     } else {
         const int PS = estep_param_stride(a.D);
-        hipLaunchKernelGGL(close_big_finish_kernel<0>, dim3(K), dim3(256), 0, stream, a.stats, K, d, a.D, a.shift, a.mixing, a.work, a.records,
-                           PS, a.info);
+        hipLaunchKernelGGL(close_big_finish_kernel<0>, dim3(K), dim3(256), 0, stream, stats, K, d, a.D, a.shift, mixing, a.work, a.records, PS,
+                           a.info);
     }
+}
+
+}  // namespace
+
+bool em_close_big_supported(int d) { return d > kMidDim && d <= 1024; }
+/// The components' matrices, then room for one parameter set (mixing, means, covariances) and an info block (launch_em_records_big).
+size_t em_close_big_work_doubles(int d, int K) { return (size_t)K * big_stride(d) + (size_t)K * ((size_t)d * d + d + 1) + 2 * (size_t)K + 8; }
+double* em_close_big_param_area(double* work, int d, int K) { return work + (size_t)K * big_stride(d); }
+
+void launch_em_close_big(const CloseArgs& a, hipStream_t stream)
+{
+    const int d = a.d, K = a.K;
+    hipLaunchKernelGGL(close_big_prepare_kernel, dim3(K, (unsigned)(((size_t)d * d + 255) / 256)), dim3(256), 0, stream, a.stats, K, d, a.shift,
+                       a.n_global, a.refine_limit, a.mixing, a.means, a.covs, a.work);
+    factor_and_finish(a.stats, a.mixing, a, stream);
+}
+
+/// Records of GIVEN parameters: a.mixing / a.means / a.covs are device INPUTS here; a.info receives flags (none) and reach.
+void launch_em_records_big(const CloseArgs& a, hipStream_t stream)
+{
+    const int d = a.d, K = a.K;
+    hipLaunchKernelGGL(close_big_from_params_kernel, dim3(K, (unsigned)(((size_t)d * d + 255) / 256)), dim3(256), 0, stream, a.means, a.covs, d,
+                       a.work);
+    factor_and_finish(nullptr, a.mixing, a, stream);
 }
 
 }  // namespace mlhip

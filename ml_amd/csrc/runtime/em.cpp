@@ -57,7 +57,37 @@ void prepare_estep(mlhip_data* dt, int K, const double* mixing, const double* me
         }
     }
     dt->estep_fold = false;
-    if (use_mfma4) {
+    // d > 64: the K factorizations on the device (em_close_big.hip launch_em_records_big -- the closing arithmetic's kernels, started
+    // from the given covariances; the host's operations in the host's order, so the records are the host builders' except through
+    // log()). On the host they were 60 ms at d = 1024, K = 4 -- once per fit, but a short fit is a few iterations. MLHIP_DEVICE_CLOSE=0
+    // (or MLHIP_DEVICE_RECORDS=0 for this step alone): the host builders.
+    const bool records_on_device = [] {                  // (read per call: tests switch it; MLHIP_DEVICE_RECORDS=0/1 decides for the records alone)
+        const char* r = std::getenv("MLHIP_DEVICE_RECORDS");
+        const char* e = r && *r ? r : std::getenv("MLHIP_DEVICE_CLOSE");
+        return !(e && e[0] == '0');
+    }();
+    if (records_on_device && em_close_big_supported(dt->d) && !use_mfma) {
+        const int d = dt->d;
+        const size_t n_par = (size_t)K * ((size_t)d * d + d + 1);
+        dt->close_work.reserve(sizeof(double) * em_close_work_doubles(d, K));
+        dt->params_host.reserve(sizeof(double) * n_par);
+        double* stage = dt->params_host.as<double>();
+        std::memcpy(stage, mixing, sizeof(double) * K);
+        std::memcpy(stage + K, means, sizeof(double) * K * d);
+        std::memcpy(stage + K + (size_t)K * d, covs, sizeof(double) * K * d * d);
+        double* area = em_close_big_param_area(dt->close_work.as<double>(), d, K);
+        HIP_CHECK(hipMemcpyAsync(area, stage, sizeof(double) * n_par, hipMemcpyHostToDevice, ctx->stream));
+        CloseArgs ca{};
+        ca.K = K; ca.d = d; ca.D = dt->D; ca.shift = dt->shift_dev.as<double>();
+        ca.layout = use_mfma4 ? 2 : 0;
+        ca.mixing = area; ca.means = area + K; ca.covs = area + K + (size_t)K * d;
+        ca.records = target->as<double>();
+        ca.info = area + n_par;
+        ca.work = dt->close_work.as<double>();
+        launch_em_records_big(ca, ctx->stream);
+        HIP_CHECK(hipGetLastError());
+        ctx->sync();                                     // (params_host may be rewritten by the caller's next upload)
+    } else if (use_mfma4) {
         // FOLD form (no per-component mean subtraction in the kernel) while every |W_k (mu_k - shift)| is small enough for
         // the parity tolerances; the exact form otherwise. Every rank decides from the same parameters. MLHIP_ESTEP_FOLD=0: off.
         static const bool fold_allowed = [] { const char* e = std::getenv("MLHIP_ESTEP_FOLD"); return !(e && e[0] == '0'); }();

@@ -97,7 +97,7 @@ struct EmLoop {
             data->it_info_slot[s].reserve(sizeof(double) * n_pack);
             if (!data->it_event[s]) HIP_CHECK(hipEventCreateWithFlags(&data->it_event[s], hipEventDisableTiming));
         }
-        if (const size_t w = em_close_work_doubles(d, K); w > 0 && !diag) data->close_work.reserve(sizeof(double) * w);
+        if (const size_t w = em_close_work_doubles(d, K); w > 0 && !diag) data->close_work.reserve(sizeof(double) * w);   // (before prepare_estep: it uses the same block)
         rec[0] = &data->params_dev; rec[1] = &data->params_next; rec[2] = &data->params_prev;
         if (diag) {
             for (DevBuf* r : rec) upload_diag_records(data, K, mixing, means, covs, *r);   // (the neutral padding records live in all)

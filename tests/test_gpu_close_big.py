@@ -31,16 +31,21 @@ def _problem(d, K, n, seed):
     return np.ascontiguousarray(X), mu0
 
 
-def _iterate(dt, pi0, mu0, S0, steps, device_close):
-    old = os.environ.get("MLHIP_DEVICE_CLOSE")
+def _iterate(dt, pi0, mu0, S0, steps, device_close, device_records=None):
+    """em_iterate with the closing arithmetic on the device or on the host; `device_records`: where the records of the FIRST E-step
+    are factored (default: where the closing runs)."""
+    keep = {k: os.environ.get(k) for k in ("MLHIP_DEVICE_CLOSE", "MLHIP_DEVICE_RECORDS")}
     os.environ["MLHIP_DEVICE_CLOSE"] = "1" if device_close else "0"
+    if device_records is not None:
+        os.environ["MLHIP_DEVICE_RECORDS"] = "1" if device_records else "0"
     try:
         return dt.em_iterate(pi0, mu0, S0, steps, 0.0, 0.0, False)
     finally:
-        if old is None:
-            del os.environ["MLHIP_DEVICE_CLOSE"]
-        else:
-            os.environ["MLHIP_DEVICE_CLOSE"] = old
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 @pytest.mark.parametrize("d,K,n", [
@@ -61,11 +66,15 @@ def test_device_closing_equals_host_closing(ctx, d, K, n):
     dt = _lib.Data(ctx, X)
     _, cov = dt.sample_covariance()
     S0, pi0 = np.stack([cov] * K), np.full(K, 1.0 / K)
-    # one iteration: the new parameters involve no library function -- the same bits
-    _, _, ll_h, pi_h, mu_h, S_h, _ = _iterate(dt, pi0, mu0, S0, 1, False)
-    _, _, ll_d, pi_d, mu_d, S_d, _ = _iterate(dt, pi0, mu0, S0, 1, True)
+    # one iteration from the SAME first records (the host's): the new parameters involve no library function -- the same bits
+    _, _, ll_h, pi_h, mu_h, S_h, _ = _iterate(dt, pi0, mu0, S0, 1, False, device_records=False)
+    _, _, ll_d, pi_d, mu_d, S_d, _ = _iterate(dt, pi0, mu0, S0, 1, True, device_records=False)
     assert ll_d == ll_h
     assert np.array_equal(pi_d, pi_h) and np.array_equal(mu_d, mu_h) and np.array_equal(S_d, S_h)
+    # the first records factored on the device (launch_em_records_big) against the host builders: the first log-likelihood sees W and
+    # sum log L_jj of the GIVEN covariances
+    _, _, ll_r, *_ = _iterate(dt, pi0, mu0, S0, 1, True, device_records=True)
+    assert abs(ll_r - ll_h) <= 1e-14 * abs(ll_h)
     # three iterations: the records built on the device (W = L^-1, sum log L_jj, the mean) drive the second and third E-step
     _, _, _, pi_h, mu_h, S_h, hist_h = _iterate(dt, pi0, mu0, S0, 3, False)
     _, _, _, pi_d, mu_d, S_d, hist_d = _iterate(dt, pi0, mu0, S0, 3, True)
