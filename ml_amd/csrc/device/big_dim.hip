@@ -135,10 +135,150 @@ __global__ __launch_bounds__(256) void em_estep_big_kernel(const double* __restr
     if (tid == 0) ll_partials[blockIdx.x] = ll_acc;
 }
 
+// ---- E-step, tiled as a matrix product (round 5) ------------------------------------------------------------------------
+// The kernel above keeps ONE centred tile of 16 samples per workgroup (all D rows of it: 128 KB at D = 1024) and streams the whole of W
+// past it: every element of W is fetched again for every 16 samples -- 4 flop per byte from L2, which is what it ran at (15.8 TFLOP/s
+// at d = 1024: 52 GB through L2 per launch). Here a workgroup owns a tile of 128 rows of Y = W (X - mu) x 128 samples in registers (each
+// of four waves 64 x 64: 16 accumulator blocks) and walks the columns l of W in chunks of 16: 128 x 16 of W and 16 x 128 of the centred
+// samples go through LDS, double-buffered, the next chunk in flight during the matrix phase: 16 flop per byte. Only chunks on or left
+// of the tile's diagonal exist; a wave skips the 16-row blocks that lie wholly right of it. The squares of a finished tile are folded
+// into the samples' q on the spot; log-sum-exp over the components is a separate pass over lw (em_lse_rows_kernel), so a unit of work
+// is (sample tile, component) and the units are dealt to persistent workgroups round-robin.
+constexpr int GR = 128, GS = 128, GC = 16;      // rows, samples, columns per chunk
+constexpr int GWS = GC + 1, GZS = GS + 1;       // LDS row strides (odd)
+
+__global__ __launch_bounds__(256, 2) void em_estep_gemm_kernel(const double* __restrict__ xt, size_t ldx, uint32_t n_pad, int D,
+                                                                const double* __restrict__ params, int K, double* __restrict__ lw_out,
+                                                                size_t ldr)
+{
+    __shared__ double Wc[2][GR * GWS];
+    __shared__ double Zc[2][GC * GZS];
+    __shared__ double qs[2][GS];
+    const int tid = threadIdx.x, lane = tid & 63, i_r = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave >> 1, wb = wave & 1;                           // the wave's 64 rows x 64 samples of the tile
+    const size_t PS = (size_t)D + (size_t)D * (D + 1) / 2 + 1;
+    const int n_rb = (D + GR - 1) / GR;
+    const uint32_t n_tiles = n_pad / GS, n_units = n_tiles * (uint32_t)K;
+    // staging roles: W chunk -- row w_r, columns 8 w_h .. + 7; Z chunk -- column (of W) z_j, samples 8 z_g .. + 7
+    const int w_r = tid >> 1, w_h = tid & 1, z_j = tid >> 4, z_g = tid & 15;
+    for (uint32_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        const uint32_t tile = unit / (uint32_t)K;
+        const int k = (int)(unit - tile * (uint32_t)K);
+        const uint32_t i0 = tile * GS;
+        const double* __restrict__ p = params + (size_t)k * PS;
+        const double* __restrict__ w = p + D;
+        double qacc[4] = {0.0, 0.0, 0.0, 0.0};
+        double wv[8], zv[8], mu = 0.0;
+        // chunk (rb, c): rows rb * 128 .., columns 16 c ..; requested into registers one chunk ahead
+        auto prefetch = [&](int rb, int c) {
+            size_t ldx_ = ldx;
+            asm volatile("" : "+s"(ldx_));                              // (addresses formed per call, not carried through the matrix phase)
+            const int row = rb * GR + w_r, l0 = c * GC + 8 * w_h;
+            const int rowc = row < D ? row : D - 1;
+            const double* __restrict__ wr = w + (size_t)rowc * (rowc + 1) / 2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wv[j] = wr[l0 + j <= rowc ? l0 + j : rowc];
+            const int l = c * GC + z_j, lc = l < D ? l : D - 1;
+            const double* __restrict__ xr = xt + (size_t)lc * ldx_ + i0 + 8 * z_g;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) zv[j] = xr[j];
+            mu = p[lc];
+        };
+        auto stage = [&](int rb, int c, int buf) {
+            const int row = rb * GR + w_r, l0 = c * GC + 8 * w_h;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Wc[buf][w_r * GWS + 8 * w_h + j] = (row < D && l0 + j <= row) ? wv[j] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Zc[buf][z_j * GZS + 8 * z_g + j] = zv[j] - mu;
+        };
+        int buf = 0;
+        prefetch(0, 0);
+        for (int rb = 0; rb < n_rb; ++rb) {
+            const int row0 = rb * GR;
+            const int l_end = row0 + GR < D ? row0 + GR : D;             // columns 0 .. l_end - 1
+            const int n_c = (l_end + GC - 1) / GC;
+            d4 acc[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] = d4{0.0, 0.0, 0.0, 0.0};
+            for (int c = 0; c < n_c; ++c, buf ^= 1) {
+                stage(rb, c, buf);
+                __syncthreads();
+                if (c + 1 < n_c) prefetch(rb, c + 1);
+                else if (rb + 1 < n_rb) prefetch(rb + 1, 0);
+                const double* Wb = Wc[buf] + (wa * 64 + i_r) * GWS + kq;
+                const double* Zb = Zc[buf] + kq * GZS + wb * 64 + i_r;
+                const int first_row = row0 + wa * 64;                   // block u of this wave: rows first_row + 16 u .. + 15
+#pragma unroll
+                for (int ks = 0; ks < GC / 4; ++ks) {
+                    const int l_lo = c * GC + 4 * ks;                   // columns l_lo .. l_lo + 3
+                    double bv[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) bv[v] = Zb[4 * ks * GZS + 16 * v];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (l_lo <= first_row + 16 * u + 15 && first_row + 16 * u < D) {   // (wave-uniform: blocks wholly right of the diagonal or below row D - 1 hold zeros)
+                            const double av = Wb[16 * u * GWS + 4 * ks];
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[v], acc[u][v], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            // the finished tile's squares: lane (i_r, kq) holds rows kq + 4 g + 16 u of sample 16 v + i_r
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) qacc[v] = __builtin_fma(acc[u][v][g], acc[u][v][g], qacc[v]);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const double q = quad_total(qacc[v]);
+            if (kq == 0) qs[wa][wb * 64 + 16 * v + i_r] = q;
+        }
+        __syncthreads();
+        if (tid < GS) lw_out[(size_t)k * ldr + i0 + tid] = __builtin_fma(-0.5, qs[0][tid] + qs[1][tid], p[PS - 1]);
+        __syncthreads();                                               // (qs and the LDS buffers are reused by the next unit)
+    }
+}
+
+/// lse_i = log sum_k exp(lw_ki) (the online form of em_estep.hip, k ascending) and the per-workgroup sums of lse over the live samples.
+__global__ __launch_bounds__(256) void em_lse_rows_kernel(const double* __restrict__ lw, size_t ldr, uint32_t n, uint32_t n_pad, int K,
+                                                           double* __restrict__ lse_out, double* __restrict__ ll_partials)
+{
+    __shared__ double red[4];
+    double ll_acc = 0.0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_pad; i += gridDim.x * 256u) {
+        double m = -__builtin_inf(), s = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const double v = lw[(size_t)k * ldr + i];
+            const double e = exp_nonpos(v == -HUGE_VAL ? -HUGE_VAL : -fabs(v - m));
+            const bool up = v > m;
+            s = up ? __builtin_fma(s, e, 1.0) : s + e;
+            m = up ? v : m;
+        }
+        const double lse = m + log(s);
+        lse_out[i] = lse;
+        if (i < n) ll_acc += lse;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ll_acc += __shfl_down(ll_acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ll_acc;
+    __syncthreads();
+    if (threadIdx.x == 0) ll_partials[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
 // ---- statistics ----------------------------------------------------------------------------------------------------------
 constexpr int MT = 64;        // macro tile: 64 x 64 entries of S_k
 constexpr int SC = 32;        // samples per panel
-constexpr int XS = 34;        // LDS row stride of a panel (== 2 mod 32: the 16 rows x 2 sample columns of a half wave hit 32 banks)
+constexpr int XS = 33;        // LDS row stride of a panel: ODD. The compiler pairs the reads of two sample groups into ds_read2_b64, which is
+                              // served in 16-lane groups over 32 banks of 4 bytes: the 16 rows of a group must start on 16 different even
+                              // banks (round 4's 34 suited ds_read_b64's 32-lane halves over 64 banks and cost 28 % of the LDS cycles in
+                              // conflicts: SQ_LDS_BANK_CONFLICT 3.96e7 of SQ_LDS_IDX_ACTIVE 1.41e8 at N = 100k, d = 256, K = 8)
 
 /// grid: (macro tile pair t, group of KC components, sample range s). Tile pair t = (ta, tb), tb <= ta, row-major over the lower
 /// triangle. The panels of X are the same for every component -- only the responsibilities differ -- so ONE pair of panels in LDS
@@ -147,7 +287,13 @@ constexpr int XS = 34;        // LDS row stride of a panel (== 2 mod 32: the 16 
 /// what bound the first form of this kernel at 4.4 ms.)
 constexpr int KC = 4;
 
-__global__ __launch_bounds__(256) void em_mstats_big_kernel(const double* __restrict__ xt, size_t ldx, uint32_t n, int d,
+/// Macro tiles along one edge of S_k. When d is a multiple of 64 the row of the constant 1 (the S1 sums and S0) would open a tile row
+/// of its own -- 15 tile pairs instead of 10 at d = 256, 10 instead of 6 at d = 192, all of it padding but one row: that row is then
+/// formed by em_mstats_big_lastrow_kernel and the tiles cover the d coordinates only (round 5).
+__host__ __device__ inline bool big_ones_row_apart(int d) { return d % MT == 0; }
+__host__ __device__ inline int big_tiles(int d) { return big_ones_row_apart(d) ? d / MT : (d + 1 + MT - 1) / MT; }
+
+__global__ __launch_bounds__(256, 2) void em_mstats_big_kernel(const double* __restrict__ xt, size_t ldx, uint32_t n, int d,
                                                              const double* __restrict__ shift, const double* __restrict__ lw,
                                                              size_t ldr, const double* __restrict__ lse, int mode,
                                                              double* __restrict__ partials, int K, int F, uint32_t chunks_per_split)
@@ -175,24 +321,57 @@ __global__ __launch_bounds__(256) void em_mstats_big_kernel(const double* __rest
     uint32_t c_end = c_begin + chunks_per_split;
     if (c_end > n_chunks) c_end = n_chunks;
     const int i_r = lane & 15, kq = lane >> 4;
+    // Software pipeline (round 5): the NEXT chunk's panel entries and responsibilities are requested right behind the barrier and are in
+    // flight during the matrix phase of this chunk; they go to LDS at the top of the next trip. (Round 4 loaded global -> LDS between
+    // the two barriers: every chunk exposed a memory round trip, the matrix pipe was 43 % busy.)
+    // thread -> (row = e / 32, sample = e % 32), e = tid + 256 t: 256-byte runs along a row of X
+    constexpr int NP = MT * SC / 256;
+    double va[NP], vb[NP], vr = 0.0, vl = 0.0;
+    const int p_s = tid & (SC - 1), p_r = tid / SC;                     // sample column, first row (rows p_r + 8 t)
+    const int r_c = tid / SC;                                           // (tid < KC * SC) component of the group
+    auto prefetch = [&](uint32_t ch) {
+        const uint32_t i = ch * SC + p_s;                               // < n_pad (the allocation is padded to the tile)
+        // (the row stride is made opaque per call: the compiler would otherwise form the 16 row offsets once, outside the chunk loop, and
+        // carry them through the matrix phase -- 32 registers, which it then spills together with the values in flight)
+        size_t ldx_ = ldx;
+        asm volatile("" : "+s"(ldx_));
+        const int ar = a_base + p_r, br = b_base + p_r;                 // rows beyond d - 1 re-read row d - 1 (discarded at the LDS write)
+#pragma unroll
+        for (int t = 0; t < NP; ++t) {
+            va[t] = xt[(size_t)(ar + 8 * t < d ? ar + 8 * t : d - 1) * ldx_ + i];
+            vb[t] = xt[(size_t)(br + 8 * t < d ? br + 8 * t : d - 1) * ldx_ + i];
+        }
+        if (tid < KC * SC) {
+            const int k = k0 + r_c;
+            vr = lw[(size_t)(k < K ? k : 0) * ldr + i];
+            if (mode != kFromResp) vl = lse[i];
+        }
+    };
+    if (c_begin < c_end) prefetch(c_begin);
     for (uint32_t ch = c_begin; ch < c_end; ++ch) {
         const uint32_t i0 = ch * SC;
         __syncthreads();                                               // the previous panels have been consumed
         if (tid < KC * SC) {                                           // responsibilities of the group's components for the 32 samples
-            const int c = tid / SC, sidx = tid - c * SC;
-            const uint32_t i = i0 + sidx;
-            const int k = k0 + c;
-            rr[tid] = (k < K && i < n) ? (mode == kFromResp ? lw[(size_t)k * ldr + i] : exp_nonpos(lw[(size_t)k * ldr + i] - lse[i])) : 0.0;
+            const int k = k0 + r_c;
+            rr[tid] = (k < K && i0 + p_s < n) ? (mode == kFromResp ? vr : exp_nonpos(vr - vl)) : 0.0;
         }
-        // panels: 64 rows x 32 samples each; thread -> (row = e / 32, sample = e % 32): 256-byte runs along a row of X
-        for (int e = tid; e < MT * SC; e += 256) {
-            const int r = e / SC, sidx = e - r * SC;
-            const uint32_t i = i0 + sidx;                                // < n_pad (the allocation is padded to the tile)
-            const int a = a_base + r, b = b_base + r;
-            pa[r * XS + sidx] = a < d ? xt[(size_t)a * ldx + i] - shift[a] : (a == d ? 1.0 : 0.0);
-            pb[r * XS + sidx] = b < d ? xt[(size_t)b * ldx + i] - shift[b] : (b == d ? 1.0 : 0.0);
+        {
+            // (an opaque zero in the row index: the 16 shift entries and the row tests are otherwise formed once, outside the chunk loop,
+            // and held in 40 registers next to 128 of accumulators)
+            int zero = 0;
+            asm volatile("" : "+v"(zero));
+#pragma unroll
+            for (int t = 0; t < NP; ++t) {
+                const int r = p_r + 8 * t;
+                const int a = a_base + r + zero, b = b_base + r + zero;
+                const double sa = shift[a < d ? a : d - 1], sb = shift[b < d ? b : d - 1];
+                const double xa = va[t] - sa, xb = vb[t] - sb;
+                pa[r * XS + p_s] = a < d ? xa : (a == d ? 1.0 : 0.0);
+                pb[r * XS + p_s] = b < d ? xb : (b == d ? 1.0 : 0.0);
+            }
         }
         __syncthreads();
+        if (ch + 1 < c_end) prefetch(ch + 1);
         if (!idle) {
 #pragma unroll
             for (int ks = 0; ks < SC / 4; ++ks) {
@@ -228,9 +407,50 @@ __global__ __launch_bounds__(256) void em_mstats_big_kernel(const double* __rest
                 for (int g = 0; g < 4; ++g) {
                     const int a = a_base + wa * 32 + u * 16 + kq + 4 * g;   // output row: kq + 4 g of the block; column: lane & 15
                     const int b = b_base + wb * 32 + v * 16 + i_r;
-                    if (a <= d && b <= a) out[(size_t)a * (a + 1) / 2 + b] = acc[c][u][v][g];
+                    if (a <= d && b <= a && !(big_ones_row_apart(d) && a == d)) out[(size_t)a * (a + 1) / 2 + b] = acc[c][u][v][g];
                 }
     }
+}
+
+/// The row of the constant 1 when the tiles leave it out (d a multiple of 64): S1_kb = sum_i r_ik x~_ib (b < d) and S0_k = sum_i r_ik,
+/// entries d (d + 1) / 2 + b of the packed block. grid: (64-column block of b, group of KC components, sample range) -- the sample
+/// ranges of em_mstats_big_kernel, so that every partial block is complete. A panel of 64 columns x 32 samples goes through LDS as
+/// there; thread (column, component) walks its 32 samples in order.
+__global__ __launch_bounds__(256) void em_mstats_big_lastrow_kernel(const double* __restrict__ xt, size_t ldx, uint32_t n, int d,
+                                                                     const double* __restrict__ shift, const double* __restrict__ lw,
+                                                                     size_t ldr, const double* __restrict__ lse, int mode,
+                                                                     double* __restrict__ partials, int K, int F, uint32_t chunks_per_split)
+{
+    __shared__ double pa[MT * XS];
+    __shared__ double rr[KC * SC];
+    const int tid = threadIdx.x;
+    const int b_base = blockIdx.x * MT, k0 = blockIdx.y * KC;
+    const uint32_t n_chunks = (n + SC - 1) / SC;
+    const uint32_t c_begin = blockIdx.z * chunks_per_split;
+    uint32_t c_end = c_begin + chunks_per_split;
+    if (c_end > n_chunks) c_end = n_chunks;
+    const int col = tid & (MT - 1), comp = tid / MT;                    // this thread's output: (component k0 + comp, column b_base + col)
+    double acc = 0.0;
+    for (uint32_t ch = c_begin; ch < c_end; ++ch) {
+        const uint32_t i0 = ch * SC;
+        __syncthreads();
+        if (tid < KC * SC) {
+            const int c = tid / SC, sidx = tid - c * SC;
+            const uint32_t i = i0 + sidx;
+            const int k = k0 + c;
+            rr[tid] = (k < K && i < n) ? (mode == kFromResp ? lw[(size_t)k * ldr + i] : exp_nonpos(lw[(size_t)k * ldr + i] - lse[i])) : 0.0;
+        }
+        for (int e = tid; e < MT * SC; e += 256) {
+            const int r = e / SC, sidx = e - r * SC;
+            const int b = b_base + r;
+            pa[r * XS + sidx] = b < d ? xt[(size_t)b * ldx + i0 + sidx] - shift[b] : (b == d ? 1.0 : 0.0);
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int sidx = 0; sidx < SC; ++sidx) acc = __builtin_fma(rr[comp * SC + sidx], pa[col * XS + sidx], acc);
+    }
+    const int k = k0 + comp, b = b_base + col;
+    if (k < K && b <= d) partials[((size_t)blockIdx.z * K + k) * F + (size_t)d * (d + 1) / 2 + b] = acc;
 }
 
 // ---- K-means assignment -----------------------------------------------------------------------------------------------
@@ -330,18 +550,47 @@ bool big_dim_applies(int d) { return d > kMaxDim && d <= kBigMaxDim && big_dim_e
 /// The K-means assignment kernel of this file has no upper limit on d (no tile in LDS).
 bool big_dim_kmeans_applies(int d) { return d > kMaxDim && big_dim_enabled(); }
 
-/// Sample ranges a statistics tile is cut into (= partial blocks written): enough workgroups to fill the chip, at most 32.
+/// Sample ranges a statistics tile is cut into (= partial blocks written), at most 32: the count whose workgroups fill whole rounds of
+/// the chip's 2 x CUs resident slots best (round 4 took ceil(3 CUs / units): 20 units x 32 = 640 workgroups on 512 slots at d = 256,
+/// K = 8 -- a second round a quarter full), the smallest such count within 3 % of the best.
 int big_dim_splits(int d, int K, int num_cus)
 {
-    const int T = (d + 1 + MT - 1) / MT;
+    const int T = big_tiles(d);
     const int units = T * (T + 1) / 2 * ((K + KC - 1) / KC);            // (tile pair, component group)
-    int s = (3 * num_cus + units - 1) / units;
-    return s < 1 ? 1 : (s > 32 ? 32 : s);
+    const int slots = 2 * num_cus;
+    double best = 0.0;
+    for (int s = 1; s <= 32; ++s) {
+        const int wgs = units * s, rounds = (wgs + slots - 1) / slots;
+        const double eff = (double)wgs / ((double)rounds * slots);
+        if (eff > best) best = eff;
+    }
+    for (int s = 1; s <= 32; ++s) {
+        const int wgs = units * s, rounds = (wgs + slots - 1) / slots;
+        if ((double)wgs / ((double)rounds * slots) >= best - 0.03 && wgs >= slots) return s;
+    }
+    for (int s = 1; s <= 32; ++s) {                                     // (fewer workgroups than slots whatever the count: the fullest)
+        const int wgs = units * s, rounds = (wgs + slots - 1) / slots;
+        if ((double)wgs / ((double)rounds * slots) >= best - 1e-9) return s;
+    }
+    return 1;
 }
 
 int launch_em_estep_big(const EstepArgs& a, int num_cus, hipStream_t stream)
 {
     const uint32_t n_pad = padded_samples(a.n);
+    static const bool tiled = [] { const char* e = std::getenv("MLHIP_ESTEP_BIG"); return !(e && e[0] == 't'); }();   // "tile": round 4's kernel (A/B)
+    if (tiled) {
+        static_assert(kSampleTile % GS == 0, "a sample tile of the product must divide the padding granule of N");
+        const uint32_t units = n_pad / GS * (uint32_t)a.K;
+        uint32_t grid = 2u * (uint32_t)num_cus;
+        if (grid > units) grid = units;
+        hipLaunchKernelGGL(em_estep_gemm_kernel, dim3(grid), dim3(256), 0, stream, a.xt, a.ldx, n_pad, a.D, a.params, a.K, a.lw, a.ldr);
+        uint32_t lgrid = (n_pad + 255) / 256;
+        if (lgrid > (uint32_t)a.n_ll_partials) lgrid = (uint32_t)a.n_ll_partials;
+        if (lgrid > 4u * (uint32_t)num_cus) lgrid = 4u * (uint32_t)num_cus;
+        hipLaunchKernelGGL(em_lse_rows_kernel, dim3(lgrid), dim3(256), 0, stream, a.lw, a.ldr, a.n, n_pad, a.K, a.lse, a.ll_partials);
+        return (int)lgrid;
+    }
     const size_t smem = sizeof(double) * ((size_t)a.D * 16 + 64);     // 64.5 KB at D = 512, 128.5 KB at D = 1024
     if (smem > 64 * 1024 &&                                           // (per device: asked for on every such launch)
         hipFuncSetAttribute(reinterpret_cast<const void*>(em_estep_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess)
@@ -368,9 +617,12 @@ int launch_em_mstats_big(const MstatsArgs& a, int num_cus, hipStream_t stream)
     if ((size_t)splits * a.K * F > a.partials_capacity) splits = (int)(a.partials_capacity / ((size_t)a.K * F));
     if (splits < 1) return -2;
     const uint32_t per = (n_chunks + splits - 1) / splits;
-    const int T = (a.d + 1 + MT - 1) / MT;
+    const int T = big_tiles(a.d);
     hipLaunchKernelGGL(em_mstats_big_kernel, dim3(T * (T + 1) / 2, (a.K + KC - 1) / KC, splits), dim3(256), 0, stream, a.xt, a.ldx, a.n, a.d, a.shift, a.lw,
                        a.ldr, a.lse, a.mode, a.partials, a.K, F, per);
+    if (big_ones_row_apart(a.d))
+        hipLaunchKernelGGL(em_mstats_big_lastrow_kernel, dim3((a.d + 1 + MT - 1) / MT, (a.K + KC - 1) / KC, splits), dim3(256), 0, stream, a.xt, a.ldx,
+                           a.n, a.d, a.shift, a.lw, a.ldr, a.lse, a.mode, a.partials, a.K, F, per);
     return splits;
 }
 

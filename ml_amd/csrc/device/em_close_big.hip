@@ -149,12 +149,16 @@ __global__ __launch_bounds__(64) void chol_rows_kernel(double* __restrict__ work
     double t[PB];
 #pragma unroll
     for (int c = 0; c < PB; ++c) t[c] = c < nb ? v.L[(size_t)(j0 + c) * d + i] : 0.0;
+    // (column by column of the diagonal block: entry c is final once the terms of the columns before it are in, and its own term goes
+    // to every later entry at once -- each entry still receives its terms in ascending order, and the partners L(j0 + c2, j0 + c),
+    // c2 > c, are CONTIGUOUS: a few wide scalar loads per column instead of one per term)
 #pragma unroll
     for (int c = 0; c < PB; ++c) {
         if (c < nb) {                                                                // (uniform)
+            const double* __restrict__ lc = Lro + (size_t)(j0 + c) * d + j0;         // column j0 + c of the diagonal block
+            t[c] = t[c] / lc[c];
 #pragma unroll
-            for (int c2 = 0; c2 < c; ++c2) t[c] -= t[c2] * Lro[(size_t)(j0 + c2) * d + j0 + c];
-            t[c] = t[c] / Lro[(size_t)(j0 + c) * d + j0 + c];
+            for (int c2 = c + 1; c2 < PB; ++c2) t[c2] -= t[c] * lc[c2];
         }
     }
     if (row) {
@@ -213,12 +217,13 @@ __global__ __launch_bounds__(64) void whiten_solve_kernel(double* __restrict__ w
 #pragma unroll
     for (int r = 0; r < PB; ++r) acc[r] = r < nb ? v.Wt[(size_t)(i0 + r) * d + c] : 0.0;
 #pragma unroll
-    for (int r = 0; r < PB; ++r) {
+    for (int r = 0; r < PB; ++r) {                                                   // (column by column of the diagonal block, as chol_rows_kernel)
         if (r < nb) {                                                                // (uniform)
             const int i = i0 + r;
+            const double* __restrict__ lc = Lro + (size_t)i * d + i0;                // column i of L, rows i0 ..
+            acc[r] = i < c ? 0.0 : acc[r] / lc[r];
 #pragma unroll
-            for (int r2 = 0; r2 < r; ++r2) acc[r] -= Lro[(size_t)(i0 + r2) * d + i] * acc[r2];
-            acc[r] = i < c ? 0.0 : acc[r] / Lro[(size_t)i * d + i];
+            for (int r2 = r + 1; r2 < PB; ++r2) acc[r2] -= lc[r2] * acc[r];
         }
     }
     if (col) {
@@ -257,6 +262,30 @@ __global__ __launch_bounds__(64) void whiten_trail_kernel(double* __restrict__ w
     }
 }
 
+/// c = W (mean - shift): row i's sum over col = 0 .. i in ascending order, one product and one addition at a time (the host's loop).
+/// One thread per row; the rows of W are read as 64 x 64 tiles through LDS (a thread walking its own row of Wt directly touches one
+/// cache line per load and lane: 1.25 ms at d = 1024).
+__global__ __launch_bounds__(64) void close_big_cvec_kernel(const double* __restrict__ shift, double* __restrict__ work, int d)
+{
+    __shared__ double tile[64][65];
+    __shared__ double diff[64];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    BigView v(work, k, d);
+    const int r0 = blockIdx.y * 64;
+    const int i = r0 + tid;
+    double acc = 0.0;
+    for (int c0 = 0; c0 <= r0; c0 += 64) {
+        __syncthreads();
+        const int col = c0 + tid;
+        diff[tid] = col < d ? v.mean[col] - shift[col] : 0.0;
+        for (int r = 0; r < 64; ++r) tile[r][tid] = (r0 + r < d && col < d) ? v.Wt[(size_t)(r0 + r) * d + col] : 0.0;
+        __syncthreads();
+        const int n_cols = i - c0 + 1 < 64 ? i - c0 + 1 : 64;                        // columns c0 .. min(i, c0 + 63)
+        for (int cc = 0; cc < n_cols; ++cc) acc += tile[tid][cc] * diff[cc];
+    }
+    if (i < d) v.c[i] = acc;
+}
+
 /// sum log L_jj, c = W (mean - shift), the refinement flag, the next E-step's record, the info block (em_close_body.hpp's last part,
 /// from global memory). One workgroup per component.
 template <int LAYOUT>
@@ -274,9 +303,7 @@ __global__ __launch_bounds__(256) void close_big_finish_kernel(const double* __r
     for (int j = tid; j < d; j += 256) v.logs[j] = log(v.L[(size_t)j * d + j]);
     double reach = 0.0;
     for (int i = tid; i < d; i += 256) {
-        double acc = 0.0;
-        for (int col = 0; col <= i; ++col) acc += v.Wt[(size_t)i * d + col] * (v.mean[col] - shift[col]);
-        v.c[i] = acc;
+        const double acc = v.c[i];                                                   // (close_big_cvec_kernel)
         const double m = isfinite(acc) ? fabs(acc) : __builtin_inf();
         reach = m > reach ? m : reach;
     }
@@ -345,6 +372,7 @@ void factor_and_finish(const double* stats, const double* mixing, const CloseArg
         if (below > 0)
             hipLaunchKernelGGL(whiten_trail_kernel, dim3(K, (cols + 63) / 64, (below + PB - 1) / PB), dim3(64), 0, stream, a.work, a.work, d, i0);
     }
+    hipLaunchKernelGGL(close_big_cvec_kernel, dim3(K, (d + 63) / 64), dim3(64), 0, stream, a.shift, a.work, d);
     if (a.layout == 2) {
         const int PS = estep_mfma4_param_stride(a.D);
         hipLaunchKernelGGL(close_big_finish_kernel<2>, dim3(K), dim3(256), 0, stream, stats, K, d, a.D, a.shift, mixing, a.work, a.records, PS,

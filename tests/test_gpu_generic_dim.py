@@ -28,7 +28,7 @@ def _problem(d, K, n, seed):
 
 
 @pytest.mark.parametrize("tier", ["matrix-core", "plain"])
-@pytest.mark.parametrize("d,K,n", [(129, 3, 1500), (160, 5, 2100), (200, 2, 1111), (256, 4, 1800), (333, 2, 900), (191, 19, 4001),
+@pytest.mark.parametrize("d,K,n", [(129, 3, 1500), (160, 5, 2100), (200, 2, 1111), (256, 4, 1800), (333, 2, 900), (191, 19, 4001), (192, 6, 1500), (320, 2, 1000),
                                    (512, 3, 1300), (600, 2, 700)])
 def test_one_iteration_labels_covariance_and_kmeans_step_match_the_oracle(oracle, d, K, n, tier, monkeypatch):
     from ml_amd import _lib
