@@ -578,7 +578,7 @@ int big_dim_splits(int d, int K, int num_cus)
 int launch_em_estep_big(const EstepArgs& a, int num_cus, hipStream_t stream)
 {
     const uint32_t n_pad = padded_samples(a.n);
-    static const bool tiled = [] { const char* e = std::getenv("MLHIP_ESTEP_BIG"); return !(e && e[0] == 't'); }();   // "tile": round 4's kernel (A/B)
+    static const bool tiled = [] { const char* e = ab_env("MLHIP_ESTEP_BIG"); return !(e && e[0] == 't'); }();   // "tile": round 4's kernel (A/B)
     if (tiled) {
         static_assert(kSampleTile % GS == 0, "a sample tile of the product must divide the padding granule of N");
         const uint32_t units = n_pad / GS * (uint32_t)a.K;

@@ -53,6 +53,7 @@ struct EstepArgs {
     const double* shift;                                    // device, D doubles (zero-padded): the fold's centre
     int fold;                                               // records carry -W (mu - shift) instead of the mean (d <= 32)
     int with_lse;                                           // 0: write lw only (the statistics kernel normalises)
+    int num_cus;                                            // compute units of the context's device (0: ask the current device)
 };
 /// Returns the grid size used (= number of ll partials written), or <0 if D is not instantiated.
 int launch_em_estep(const EstepArgs& a, hipStream_t stream);
@@ -230,5 +231,9 @@ void launch_kmeans_reduce(const KmeansArgs& a, int n_partials, hipStream_t strea
 /// from the same kernel -- the host then only waits for the stream; a separate hipMemcpyAsync of these 2 + K (d + 1) doubles goes
 /// through a copy engine and costs more than the kernel itself.
 void launch_kmeans_close(double* out, int K, int d, int D, double* next, double* mirror, hipStream_t stream);
+/// launch_kmeans_reduce + launch_kmeans_close in one launch (no all-reduce in between). `ticket`: one unsigned of device memory, zeroed once;
+/// `ticket_base`: the tickets drawn from it so far -- the return value (this launch's workgroups) is added to it by the caller.
+unsigned launch_kmeans_reduce_close(const KmeansArgs& a, int n_partials, int D, double* next, double* mirror, unsigned* ticket,
+                                    unsigned ticket_base, hipStream_t stream);
 
 }  // namespace mlhip

@@ -116,11 +116,11 @@ int launch_em_estep(const EstepArgs& a, hipStream_t stream)
     default:
         if (a.D <= kMaxDim) return -1;
         if (big_dim_applies(a.D)) {
-            static const int cus = [] {
-                int dev = 0, n = 0;
-                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
-                return n;
-            }();
+            int cus = a.num_cus;                              // (per context: a device group may span different devices -- ADVICE r4)
+            if (cus < 1) {
+                int dev = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+            }
             return launch_em_estep_big(a, cus, stream);
         }
         return launch_em_estep_generic(a, stream);

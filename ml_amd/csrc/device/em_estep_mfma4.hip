@@ -287,7 +287,7 @@ int launch_sb(const EstepArgs& a, int num_cus, hipStream_t stream)
         static const int fit = [] {
             int blocks = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, em_estep_mfma4_kernel<D, SB, FOLD, LSE, NW>, NT, sizeof(double) * 2 * NLD * NT) != hipSuccess) blocks = 2;
-            const char* e = std::getenv("MLHIP_ESTEP_WGS");
+            const char* e = ab_env("MLHIP_ESTEP_WGS");
             const int want = e ? std::atoi(e) : 4;
             return blocks < 2 ? 2 : (blocks > want ? want : blocks);
         }();

@@ -152,7 +152,7 @@ Plan make_plan(int d, int K, int num_cus)
         // shorter than the latency of the next tile's loads, and one workgroup per CU waits for memory most of the time. These
         // instantiations need <= 128 registers and <= 70 KB of LDS: TWO workgroups per CU [r3] (N = 1M, d = 16, K = 16: 202 ->
         // 160 us; N = 5M, d = 24, K = 32: 2.31 -> 1.97 ms; profiles/r03_mstats_wg2.txt). MLHIP_MSTATS_WG2=0: one.
-        static const bool wg2_allowed = [] { const char* e = std::getenv("MLHIP_MSTATS_WG2"); return !(e && e[0] == '0'); }();
+        static const bool wg2_allowed = [] { const char* e = ab_env("MLHIP_MSTATS_WG2"); return !(e && e[0] == '0'); }();
         if (wg2_allowed && d <= kRegDim && p.n_rbg == 1 && p.n_cbg == 1 && (p.RBW == 1 || (p.RBW == 2 && p.CBW <= 3))) {
             p.wg_per_cu = 2;                                       // (three, where registers and LDS allow: no faster, slower at d >= 20)
             p.grid_x = p.wg_per_cu * num_cus;

@@ -193,58 +193,79 @@ __global__ __launch_bounds__(BSU) void kmeans_update_kernel(
     }
 }
 
-/// out = [inertia, n_changed, counts(K), sums(K*d)]: one wave per output element, the lanes stride over the per-workgroup
-/// partials. inertia / changed: lane-strided partial sums combined by a shuffle tree (a fixed order for a given number of
-/// partials); counts and coordinate sums: exact integer sums of the limb words (order-free), converted to double once.
-__global__ __launch_bounds__(256) void kmeans_reduce_kernel(const double* __restrict__ partials, int n_blocks, size_t pstride,
-                                                             int K, int d, int accumulate, const double* __restrict__ scale,
-                                                             double* __restrict__ out)
+/// One output element of [inertia, n_changed, counts(K), sums(K*d)] by one wave, the lanes striding over the per-workgroup partial blocks
+/// four at a time (round 5: the loads of a trip in flight together -- 11.8 -> ... us at K = 256, d = 8 over 512 blocks). inertia / changed:
+/// lane-strided partial sums combined by a shuffle tree (a fixed order for a given number of partials); counts and coordinate sums:
+/// exact integer sums of the limb words (order-free), converted to double once.
+__device__ __forceinline__ void kmeans_reduce_element(const double* __restrict__ partials, int n_blocks, size_t pstride, int K, int d,
+                                                      const double* __restrict__ scale, double* out, int e, int total, int lane)
 {
-    const int W = 3 * d + 1;
-    const int total = 2 + (accumulate ? K * (d + 1) : 0);
-    const int lane = threadIdx.x & 63;
-    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);        // wave-uniform
-    if (e >= total) return;
-    if (e < 2) {
-        double v = 0.0;
-        for (int b = lane; b < n_blocks; b += 64) v += partials[(size_t)b * pstride + e];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) out[e] = v;
-        return;
-    }
-    const int k = (e - 2) / (d + 1), j = (e - 2) - k * (d + 1);
-    const u64* words = reinterpret_cast<const u64*>(partials + 2) + (size_t)k * W;
-    const size_t wstride = pstride;   // doubles and words are both 8 bytes
     auto wave_sum = [](u64 v) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         return v;
     };
-    if (j == d) {
-        u64 c = 0;
-        for (int b = lane; b < n_blocks; b += 64) c += words[(size_t)b * wstride + 3 * d];
-        c = wave_sum(c);
-        if (lane == 0) out[2 + k] = (double)c;
-    } else {
-        u64 w0 = 0, w1 = 0, w2 = 0;
-        for (int b = lane; b < n_blocks; b += 64) {
-            const u64* p = words + (size_t)b * wstride + 3 * j;
-            w0 += p[0];
-            w1 += p[1];
-            w2 += p[2];
-        }
-        w0 = wave_sum(w0); w1 = wave_sum(w1); w2 = wave_sum(w2);
-        if (lane == 0) {
-            // value = (w2 * 2^64 + w1 * 2^32 + w0) / scale; propagate carries so that the top word carries the sign and
-            // the lower words are < 2^32, then combine from the small end (at most ~1.5 ulp from the exact sum).
-            w1 += w0 >> 32;  w0 &= 0xffffffffull;
-            const long long top = (long long)w2 + (long long)(w1 >> 32);
-            w1 &= 0xffffffffull;
-            const double v = __builtin_fma((double)top, 0x1p64, __builtin_fma((double)w1, 0x1p32, (double)w0));
-            out[2 + K + (size_t)k * d + j] = v / scale[j];
+    const int W = 3 * d + 1;
+    if (e < 2) {
+        double v = 0.0;
+        for (int b = lane; b < n_blocks; b += 64) v += partials[(size_t)b * pstride + e];   // (the order of kmeans_reduce_kernel: same bits)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) out[e] = v;
+    } else if (e < total) {
+        const int k = (e - 2) / (d + 1), j = (e - 2) - k * (d + 1);
+        const u64* words = reinterpret_cast<const u64*>(partials + 2) + (size_t)k * W;
+        if (j == d) {
+            u64 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            int b = lane;
+            for (; b + 192 < n_blocks; b += 256) {
+                c0 += words[(size_t)b * pstride + 3 * d];
+                c1 += words[(size_t)(b + 64) * pstride + 3 * d];
+                c2 += words[(size_t)(b + 128) * pstride + 3 * d];
+                c3 += words[(size_t)(b + 192) * pstride + 3 * d];
+            }
+            for (; b < n_blocks; b += 64) c0 += words[(size_t)b * pstride + 3 * d];
+            const u64 c = wave_sum((c0 + c1) + (c2 + c3));                                    // (integer sums: order-free)
+            if (lane == 0) out[2 + k] = (double)c;
+        } else {
+            u64 w0 = 0, w1 = 0, w2 = 0;
+            int b = lane;
+            for (; b + 192 < n_blocks; b += 256) {
+                const u64* p0 = words + (size_t)b * pstride + 3 * j;
+                const u64* p1 = p0 + 64 * pstride;
+                const u64* p2 = p1 + 64 * pstride;
+                const u64* p3 = p2 + 64 * pstride;
+                const u64 a0 = p0[0], a1 = p0[1], a2 = p0[2], b0 = p1[0], b1 = p1[1], b2 = p1[2];
+                const u64 c0 = p2[0], c1 = p2[1], c2 = p2[2], d0 = p3[0], d1 = p3[1], d2 = p3[2];
+                w0 += (a0 + b0) + (c0 + d0);
+                w1 += (a1 + b1) + (c1 + d1);
+                w2 += (a2 + b2) + (c2 + d2);
+            }
+            for (; b < n_blocks; b += 64) {
+                const u64* p = words + (size_t)b * pstride + 3 * j;
+                w0 += p[0];
+                w1 += p[1];
+                w2 += p[2];
+            }
+            w0 = wave_sum(w0); w1 = wave_sum(w1); w2 = wave_sum(w2);
+            if (lane == 0) {                                                                  // (the conversion of kmeans_reduce_kernel)
+                w1 += w0 >> 32;  w0 &= 0xffffffffull;
+                const long long top = (long long)w2 + (long long)(w1 >> 32);
+                w1 &= 0xffffffffull;
+                const double v = __builtin_fma((double)top, 0x1p64, __builtin_fma((double)w1, 0x1p32, (double)w0));
+                out[2 + K + (size_t)k * d + j] = v / scale[j];
+            }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void kmeans_reduce_kernel(const double* __restrict__ partials, int n_blocks, size_t pstride,
+                                                             int K, int d, int accumulate, const double* __restrict__ scale,
+                                                             double* __restrict__ out)
+{
+    const int total = 2 + (accumulate ? K * (d + 1) : 0);
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);        // wave-uniform
+    kmeans_reduce_element(partials, n_blocks, pstride, K, d, scale, out, e, total, threadIdx.x & 63);
 }
 
 template <int D>
@@ -378,6 +399,69 @@ __global__ __launch_bounds__(256) void kmeans_close_kernel(double* __restrict__ 
     next[e] = v;
 }
 }  // namespace
+
+#ifdef MLHIP_EXPERIMENTS
+namespace {
+/// kmeans_reduce_kernel and kmeans_close_kernel in ONE launch (single rank: no all-reduce between the two; round 5): every workgroup
+/// reduces its four output elements as before, takes a ticket, and the workgroup that draws the last one -- every element of `out` is
+/// then written and, behind the fences, visible -- forms the means, the next centroid table and the pinned mirror. One dependent
+/// dispatch less per step -- and measured SLOWER: 32.2 us for the one launch against 11.8 + 4.2 us for the two (K = 256, d = 8, 512
+/// partial blocks: the last workgroup closes 2 048 entries and writes the 18 KB mirror alone, behind the slowest of 577 reductions),
+/// 1.094 against 1.074 ms per step at N = 12.5M. `make EXPERIMENTS=1` + MLHIP_KMEANS_FUSED=1 only (profiles/r05_kmeans_step.txt).
+__global__ __launch_bounds__(256) void kmeans_reduce_close_kernel(const double* __restrict__ partials, int n_blocks, size_t pstride, int K, int d,
+                                                                   int D, const double* __restrict__ scale, double* out, double* __restrict__ next,
+                                                                   double* __restrict__ mirror, unsigned* __restrict__ ticket, unsigned ticket_base)
+{
+    __shared__ int is_last;
+    const int total = 2 + K * (d + 1);
+    kmeans_reduce_element(partials, n_blocks, pstride, K, d, scale, out, blockIdx.x * 4 + (threadIdx.x >> 6), total, threadIdx.x & 63);
+    // The in-launch combine of the gfx950 guide (counter form of its hand-off): every wave's stores drained, ONE agent-scope release
+    // and ONE relaxed ticket per workgroup; the workgroup that draws the launch's last ticket acquires once and reads with plain loads.
+    // The counter is never reset: launch number m of a handle owns the tickets ticket_base .. ticket_base + gridDim.x - 1.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = t - ticket_base == gridDim.x - 1 ? 1 : 0;
+        if (is_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (!is_last) return;
+    const int threads = K * D > K + 2 ? K * D : K + 2;
+    for (int t = threadIdx.x; t < threads; t += 256) {        // kmeans_close_kernel's body
+        if (mirror && t < 2 + K) mirror[t] = out[t];
+        if (t >= K * D) continue;
+        const int k = t / D, j = t - k * D;
+        double v = 0.0;
+        if (j < d) {
+            const double c = out[2 + k];
+            double* sum = out + 2 + K + (size_t)k * d + j;
+            v = c > 0 ? *sum / c : 0.0;
+            *sum = v;
+            if (mirror) mirror[2 + K + (size_t)k * d + j] = v;
+        }
+        next[t] = v;
+    }
+}
+}  // namespace
+
+unsigned launch_kmeans_reduce_close(const KmeansArgs& a, int n_partials, int D, double* next, double* mirror, unsigned* ticket,
+                                    unsigned ticket_base, hipStream_t stream)
+{
+    const size_t pstride = 2 + (size_t)a.K * (3 * a.d + 1);
+    const int total = 2 + a.K * (a.d + 1);
+    const unsigned grid = (unsigned)((total + 3) / 4);
+    hipLaunchKernelGGL(kmeans_reduce_close_kernel, dim3(grid), dim3(256), 0, stream, a.partials, n_partials, pstride, a.K, a.d, D, a.scale, a.out,
+                       next, mirror, ticket, ticket_base);
+    return grid;
+}
+
+#endif
 
 void launch_kmeans_close(double* out, int K, int d, int D, double* next, double* mirror, hipStream_t stream)
 {

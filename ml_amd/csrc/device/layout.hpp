@@ -2,8 +2,22 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 
 namespace mlhip {
+
+/// Environment switches that exist only to measure a decision against its alternative (A/B runs; DESIGN.md section 7 lists them with
+/// the profile that settled each): honoured by the `make EXPERIMENTS=1` library, compiled to "not set" in the default one -- the
+/// shipped binary has one code path per decision and no getenv on it.
+inline const char* ab_env(const char* name)
+{
+#ifdef MLHIP_EXPERIMENTS
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 // ---- layout constants shared by host and device code -------------------------------------------
 constexpr int kSampleTile = 256;  // N is padded to a multiple of this in HBM

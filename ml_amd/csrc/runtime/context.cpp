@@ -110,6 +110,14 @@ void destroy_single_context(mlhip_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm) drop_rccl(ctx);
+    {
+        std::lock_guard<std::mutex> lock(ctx->handles_m);
+        for (mlhip_data* h : ctx->handles) {          // (handles that outlive their context: see mlhip_ctx::handles)
+            h->attach_pool(nullptr);
+            h->ctx = nullptr;
+        }
+        ctx->handles.clear();
+    }
     ctx->small_dev.release();
     ctx->small_host.release();
     for (int b = 0; b < 2; ++b) { ctx->up_stage[b].release(); ctx->up_pin[b].release(); }

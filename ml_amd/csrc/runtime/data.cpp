@@ -113,6 +113,7 @@ mlhip_data* upload_common(mlhip_ctx* ctx, const double* x, bool on_device, uint3
         delete dt;
         throw;
     }
+    ctx->adopt(dt);
     return dt;
 }
 
@@ -184,9 +185,11 @@ int mlhip_data_free(mlhip_data* data)
 {
     return guarded([&] {
         if (!data) return;
-        if (!data->parts.empty() || data->ctx->group) { delete data; return; }       // (a group's block: its parts free themselves)
+        if (!data->ctx) { delete data; return; }                                      // (its context is gone: detached, nothing in flight)
+        if (!data->parts.empty() || data->ctx->group) { data->ctx->disown(data); delete data; return; }   // (a group's block: its parts free themselves)
         (void)hipSetDevice(data->ctx->device);
         (void)hipStreamSynchronize(data->ctx->stream);
+        data->ctx->disown(data);
         delete data;
     });
 }

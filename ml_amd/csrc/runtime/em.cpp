@@ -123,6 +123,7 @@ void launch_estep(mlhip_data* dt, int K, bool with_lse, const DevBuf* records, i
     a.ll_partials = dt->ll_partials.as<double>(); a.n_ll_partials = kMaxLlPartials;
     a.shift = dt->shift_dev.as<double>(); a.fold = (fold < 0 ? dt->estep_fold : fold != 0) ? 1 : 0;
     a.with_lse = (with_lse || dt->estep_variant != 2) ? 1 : 0;
+    a.num_cus = ctx->num_cus;
     int grid = 0;
     ctx->timed("em_estep", [&] {
         if (dt->estep_variant == 2) {

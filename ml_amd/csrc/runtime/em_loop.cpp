@@ -89,7 +89,7 @@ struct EmLoop {
         F = diag ? diag_stats_count(d) : stats_count(d);
         n_info = em_close_info_doubles(K);
         n_pack = n_info + K + (size_t)K * d + n_cov;
-        const bool pinned = env_allows("MLHIP_INFO_PINNED");
+        const bool pinned = !(ab_env("MLHIP_INFO_PINNED") && ab_env("MLHIP_INFO_PINNED")[0] == '0');
         info_pinned = pinned && !diag;
         pack_pinned = pinned && diag;
         for (int s = 0; s < 3; ++s) {
@@ -355,7 +355,7 @@ struct EmLoop {
     /// N K d^2 per rank (default 2e9; diagonal: N K d <= 1e9).
     bool lagged_applies(uint32_t max_steps) const
     {
-        static const double work_limit = [] { const char* e = std::getenv("MLHIP_LAGGED_WORK"); return e ? std::atof(e) : 2.0e9; }();
+        static const double work_limit = [] { const char* e = ab_env("MLHIP_LAGGED_WORK"); return e ? std::atof(e) : 2.0e9; }();
         const double pair_work = (double)data->n_global / (double)std::max(1, ctx->world_size) * K * (diag ? d : d * d);
         return env_allows("MLHIP_LAGGED") && (!ctx->reduce_fn || ctx->reduce_on_device) && max_steps >= 2 &&
                pair_work <= (diag ? 1.0e9 : work_limit);

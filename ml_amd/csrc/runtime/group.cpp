@@ -319,6 +319,11 @@ void destroy(mlhip_ctx* ctx)
         }
         delete g;
     }
+    {
+        std::lock_guard<std::mutex> lock(ctx->handles_m);
+        for (mlhip_data* h : ctx->handles) h->ctx = nullptr;   // (group blocks that outlive the group: their parts are detached already)
+        ctx->handles.clear();
+    }
     delete ctx;
 }
 
@@ -401,6 +406,7 @@ mlhip_data* upload(mlhip_ctx* ctx, const double* x, bool on_device, uint32_t d, 
         delete gd;
         throw;
     }
+    ctx->adopt(gd);
     return gd;
 }
 

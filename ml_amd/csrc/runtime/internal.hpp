@@ -242,6 +242,16 @@ struct mlhip_ctx {
     int reduce_on_device = 0, world_size = 1, rank = 0;
     ncclComm_t comm = nullptr;   // library-owned RCCL communicator (mlhip_ctx_init_rccl); its all-reduce is the hook then
     BufferPool pool;         // blocks of released data handles, for the next one
+    // data handles alive on this context: destroying the context DETACHES them (their buffers stop referring to the pool, their context
+    // pointer goes null), so a handle freed after its context releases its memory to the driver instead of touching freed state
+    std::mutex handles_m;
+    std::vector<mlhip_data*> handles;
+    void adopt(mlhip_data* h) { std::lock_guard<std::mutex> lock(handles_m); handles.push_back(h); }
+    void disown(mlhip_data* h)
+    {
+        std::lock_guard<std::mutex> lock(handles_m);
+        handles.erase(std::remove(handles.begin(), handles.end(), h), handles.end());
+    }
     // scratch
     DevBuf small_dev;        // for all-reducing short host vectors through a device hook
     PinnedBuf small_host;
@@ -384,6 +394,8 @@ struct mlhip_data {
     DevBuf km_labels[2], km_cent, km_cent_next, km_partials, km_out, km_mind, km_probe, km_scale, km_cnorm, km_xt_pad;
     PinnedBuf km_host;
     DevBuf kpp_w, kpp_scr;               // mlhip_kpp_draw: the running-minimum weights, block sums / offsets / result
+    DevBuf km_ticket;                    // kmeans_reduce_close_kernel: the arrival counter, never reset ...
+    unsigned km_ticket_base = 0;         // ... and the tickets drawn from it so far (wraps with it)
     int km_cur = 0;
     bool km_have_old = false;
 
@@ -391,7 +403,7 @@ struct mlhip_data {
     void attach_pool(BufferPool* pool)
     {
         for (DevBuf* b : {&xt, &shift_dev, &lw, &lse, &esum, &ll_partials, &params_dev, &partials, &stats_dev, &resp_dev,
-                          &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_cent_next, &km_partials, &km_out, &km_mind, &km_probe, &km_scale, &km_cnorm, &km_xt_pad, &kpp_w, &kpp_scr,
+                          &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_cent_next, &km_partials, &km_out, &km_mind, &km_probe, &km_scale, &km_cnorm, &km_xt_pad, &kpp_w, &kpp_scr, &km_ticket,
                           &refine_shift, &refine_stats, &params_next, &params_prev, &it_pack[0], &it_pack[1], &it_pack[2], &it_sync, &it_xch, &close_work})
             b->pool = pool;
         for (PinnedBuf* b : {&params_host, &stats_host, &km_host, &it_info_slot[0], &it_info_slot[1], &it_info_slot[2], &it_history}) b->pool = pool;
@@ -401,7 +413,7 @@ struct mlhip_data {
     {
         for (mlhip_data* p : parts) mlhip_data_free(p);
         for (DevBuf* b : {&xt, &shift_dev, &lw, &lse, &esum, &ll_partials, &params_dev, &partials, &stats_dev, &resp_dev,
-                          &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_cent_next, &km_partials, &km_out, &km_mind, &km_probe, &km_scale, &km_cnorm, &km_xt_pad, &kpp_w, &kpp_scr,
+                          &labels_dev, &km_labels[0], &km_labels[1], &km_cent, &km_cent_next, &km_partials, &km_out, &km_mind, &km_probe, &km_scale, &km_cnorm, &km_xt_pad, &kpp_w, &kpp_scr, &km_ticket,
                           &refine_shift, &refine_stats, &params_next, &params_prev, &it_pack[0], &it_pack[1], &it_pack[2], &it_sync, &it_xch, &close_work})
             b->release();
         for (auto& sl : it_info_slot) sl.release();
@@ -521,7 +533,10 @@ void km_upload_centroids(mlhip_data* dt, int K, const KmBlock& b, const double* 
 
 /// Assignment (+ optional accumulation) against the table in km_cent, partials reduced into km_out =
 /// [inertia, changed, counts, sums] and summed across ranks there when the all-reduce works on device memory.
-void km_launch(mlhip_data* dt, int K, const KmBlock& b, bool accumulate, double* min_dist_out);
+/// `close_next` (with accumulate, single rank): the closing arithmetic rides in the reduction's launch (kmeans_reduce_close_kernel) --
+/// means into km_out, the next table into close_next, the block into the pinned close_mirror (may be null); returns true when it did.
+bool km_launch(mlhip_data* dt, int K, const KmBlock& b, bool accumulate, double* min_dist_out, double* close_next = nullptr,
+               double* close_mirror = nullptr);
 
 /// km_out -> km_host (`count` doubles), summed across ranks on the host when the all-reduce works on host memory.
 void km_fetch(mlhip_data* dt, size_t count);

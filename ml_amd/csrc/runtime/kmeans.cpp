@@ -92,7 +92,7 @@ void km_upload_centroids(mlhip_data* dt, int K, const KmBlock& b, const double* 
 
 /// Assignment (+ optional accumulation) against the table in km_cent, partials reduced into km_out =
 /// [inertia, changed, counts, sums] and summed across ranks there when the all-reduce works on device memory.
-void km_launch(mlhip_data* dt, int K, const KmBlock& b, bool accumulate, double* min_dist_out)
+bool km_launch(mlhip_data* dt, int K, const KmBlock& b, bool accumulate, double* min_dist_out, double* close_next, double* close_mirror)
 {
     mlhip_ctx* ctx = dt->ctx;
     const int nxt = dt->km_cur ^ 1;
@@ -112,7 +112,24 @@ void km_launch(mlhip_data* dt, int K, const KmBlock& b, bool accumulate, double*
     ctx->timed("kmeans_assign", [&] { rc = launch_kmeans_assign(a, ctx->num_cus, ctx->stream); });
     if (rc == -1) throw Unsupported("K-means kernel not instantiated for this dimension");
     if (rc <= 0) throw std::runtime_error("K-means kernel launch failed");
-    launch_kmeans_reduce(a, rc, ctx->stream);
+    bool fused = false;
+#ifdef MLHIP_EXPERIMENTS
+    // Single rank, the step loop: reduction and closing arithmetic in ONE launch -- measured slower than the two (kmeans.hip
+    // kmeans_reduce_close_kernel); MLHIP_KMEANS_FUSED=1 in a `make EXPERIMENTS=1` library selects it (A/B runs)
+    static const bool fuse_wanted = [] { const char* e = std::getenv("MLHIP_KMEANS_FUSED"); return e && e[0] == '1'; }();
+    fused = close_next && accumulate && !ctx->reduce_fn && fuse_wanted;
+    if (fused) {
+        if (!dt->km_ticket.p) {
+            dt->km_ticket.reserve(64);
+            HIP_CHECK(hipMemsetAsync(dt->km_ticket.p, 0, 64, ctx->stream));
+            dt->km_ticket_base = 0;
+        }
+        dt->km_ticket_base += launch_kmeans_reduce_close(a, rc, b.D, close_next, close_mirror, dt->km_ticket.as<unsigned>(), dt->km_ticket_base, ctx->stream);
+    }
+#else
+    (void)close_next; (void)close_mirror;
+#endif
+    if (!fused) launch_kmeans_reduce(a, rc, ctx->stream);
     HIP_CHECK(hipGetLastError());
     dt->km_cur = nxt;
     dt->km_have_old = true;
@@ -120,6 +137,7 @@ void km_launch(mlhip_data* dt, int K, const KmBlock& b, bool accumulate, double*
         const size_t count = 2 + (accumulate ? (size_t)K * (dt->d + 1) : 0);
         ctx->reduce_device(dt->km_out.as<double>(), count);
     }
+    return fused;
 }
 
 
@@ -166,7 +184,7 @@ void km_iterate(mlhip_data* dt, int K, double* centroids, double* old_centroids,
     mlhip_ctx* ctx = dt->ctx;
     const int d = dt->d;
     const size_t kd = (size_t)K * d;
-    const bool device_route = !(ctx->reduce_fn && !ctx->reduce_on_device) && !std::getenv("MLHIP_KMEANS_HOST_LOOP");
+    const bool device_route = !(ctx->reduce_fn && !ctx->reduce_on_device) && !ab_env("MLHIP_KMEANS_HOST_LOOP");
     const KmBlock b = km_block(dt, K);
     std::vector<double> cur(centroids, centroids + kd), old(kd, 0.0), upd(kd);
     if (device_route) {
@@ -177,11 +195,11 @@ void km_iterate(mlhip_data* dt, int K, double* centroids, double* old_centroids,
     *steps_done = 0;
     for (uint32_t step = 0; step < max_steps; ++step) {
         if (device_route) {
-            km_launch(dt, K, b, true, nullptr);
-            // (the closing kernel writes the block into the pinned km_host as well: no copy-engine transfer in the loop)
-            static const bool mirror = [] { const char* e = std::getenv("MLHIP_KMEANS_MIRROR"); return !(e && e[0] == '0'); }();
-            launch_kmeans_close(dt->km_out.as<double>(), K, d, b.D, dt->km_cent_next.as<double>(), mirror ? dt->km_host.as<double>() : nullptr,
-                                ctx->stream);
+            // (the closing arithmetic writes the block into the pinned km_host as well: no copy-engine transfer in the loop)
+            static const bool mirror = [] { const char* e = ab_env("MLHIP_KMEANS_MIRROR"); return !(e && e[0] == '0'); }();
+            double* const pinned = mirror ? dt->km_host.as<double>() : nullptr;
+            if (!km_launch(dt, K, b, true, nullptr, dt->km_cent_next.as<double>(), pinned))
+                launch_kmeans_close(dt->km_out.as<double>(), K, d, b.D, dt->km_cent_next.as<double>(), pinned, ctx->stream);
             HIP_CHECK(hipGetLastError());
             if (mirror) ctx->sync(); else km_fetch(dt, 2 + (size_t)K * (d + 1));
             const double* r = dt->km_host.as<double>();

@@ -48,3 +48,22 @@ def test_results_do_not_depend_on_reused_blocks(monkeypatch):
             for u, v in zip(a, b):
                 assert np.array_equal(np.asarray(u), np.asarray(v), equal_nan=True)
     pooled.close()
+
+
+def test_a_block_may_outlive_its_context():
+    """mlhip_ctx_destroy detaches the data handles still alive on the context: freeing one afterwards releases its memory to the driver
+    instead of touching the destroyed context's block cache."""
+    from ml_amd import _lib
+    rng = np.random.default_rng(0)
+    ctx = _lib.Context()
+    dt = _lib.Data(ctx, rng.standard_normal((5000, 6)))
+    dt.sample_covariance()
+    ctx._blocks.discard(dt)                 # (the Python wrapper would close the block first)
+    ctx.close()
+    dt.close()
+    again = _lib.Context()                  # the library is still in order
+    d2 = _lib.Data(again, rng.standard_normal((300, 3)))
+    mean, cov = d2.sample_covariance()
+    assert np.all(np.isfinite(cov))
+    d2.close()
+    again.close()
