@@ -357,7 +357,7 @@ struct EmLoop {
     {
         static const double work_limit = [] { const char* e = ab_env("MLHIP_LAGGED_WORK"); return e ? std::atof(e) : 2.0e9; }();
         const double pair_work = (double)data->n_global / (double)std::max(1, ctx->world_size) * K * (diag ? d : d * d);
-        return env_allows("MLHIP_LAGGED") && (!ctx->reduce_fn || ctx->reduce_on_device) && max_steps >= 2 &&
+        return !(ab_env("MLHIP_LAGGED") && ab_env("MLHIP_LAGGED")[0] == '0') && (!ctx->reduce_fn || ctx->reduce_on_device) && max_steps >= 2 &&
                pair_work <= (diag ? 1.0e9 : work_limit);
     }
 
