@@ -365,6 +365,229 @@ __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
     }
 }
 
+#ifdef MLHIP_EXPERIMENTS
+// ---- 64 < d <= 128: half tiles, double-buffered (round 5) ----------------------------------------------------------------------
+// Above d = 64 the kernel above cannot double-buffer its 64-sample tile (x~ rows of 131 doubles + responsibilities: 84 KB, twice that does
+// not fit the CU's 160 KB): a barrier BEFORE staging, the staging of every tile -- normalisation with its exponentials, x - shift, 20 LDS
+// writes per thread -- exposed, the matrix pipe 62 % busy (d = 128, K = 32: 46 TFLOP/s, the dominant kernel of that shape). Here the
+// tile is cut in HALVES of 32 samples, two of which fit; the structure is the d <= 64 kernel's -- stage half h into one buffer, ONE
+// barrier, request half h + 1 from memory, contract half h -- so that a wave staging the next half runs beside the SIMD's other wave
+// still in its matrix phase. Same partial-block layout, same three responsibility forms (EXP), plain dealing of column blocks.
+// MEASURED SLOWER (N = 1M, K = 32: d = 128 12.39 against 11.61 ms, d = 96 6.79 / 6.52, d = 72 4.10 / 4.03): twice the barriers for the
+// same staging work per sample, and a wave still cannot overlap its own staging with its own matrix phase. `make EXPERIMENTS=1`
+// library with MLHIP_MSTATS_HALF=1 only (A/B runs; profiles/r05_big_dim.txt).
+__device__ __forceinline__ double dpp_row_ror(double v, int ctrl_is_12)
+{
+    const int lo = ctrl_is_12 ? __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x12C, 0xf, 0xf, false)
+                              : __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x124, 0xf, 0xf, false);
+    const int hi = ctrl_is_12 ? __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x12C, 0xf, 0xf, false)
+                              : __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x124, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+/// The value of lane ^ 4 (row rotations by 4 and by 12 give lane + 4 and lane - 4 inside a row of 16).
+__device__ __forceinline__ double partner_xor4(double v, int lane)
+{
+    const double up = dpp_row_ror(v, 0), down = dpp_row_ror(v, 1);
+    return (lane & 4) ? down : up;
+}
+[[maybe_unused]] __device__ __forceinline__ double allreduce_max_bits2345(double v, int lane)
+{
+    double a, b;
+    v = fmax(v, partner_xor4(v, lane));
+    v = fmax(v, partner_xor8(v));
+    partners_swap<false>(v, a, b);
+    v = fmax(a, b);
+    partners_swap<true>(v, a, b);
+    return fmax(a, b);
+}
+[[maybe_unused]] __device__ __forceinline__ double allreduce_sum_bits2345(double v, int lane)
+{
+    double a, b;
+    v += partner_xor4(v, lane);                   // (pairwise with the SAME partner on both sides: every lane of a sample ends with the same bits)
+    v += partner_xor8(v);
+    partners_swap<false>(v, a, b);
+    v = a + b;
+    partners_swap<true>(v, a, b);
+    return a + b;
+}
+
+template <int RBW, int CBW, int EXP>
+__global__ __launch_bounds__(512, 2) void em_mstats_half_kernel(
+    const double* __restrict__ xt, size_t ldx, uint32_t n, int d, int D, const double* __restrict__ shift,
+    const double* __restrict__ lw, size_t ldr, const double* __restrict__ lse, int K, int n_rbg, int CB_total,
+    double* __restrict__ partials, int KP, int FP, double* __restrict__ lse_out, double* __restrict__ ll_out)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int DM = kMaxDim, HT = 32;            // half tile: 32 samples
+    constexpr int RS = RBW * 16 + 1;                // odd row stride of the responsibility tile
+    constexpr int XS = tile_stride<DM>();
+    constexpr int NXV = DM / 16;                    // x rows staged per thread (8)
+    constexpr int NRV = RBW;                        // responsibility rows staged per thread
+    const int da = d + 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rbg = blockIdx.y % n_rbg, cbg = blockIdx.y / n_rbg;
+    const int rb0 = rbg * RBW;
+    const int F = da * (da + 1) / 2;
+    int offa[CBW], offb[CBW];
+#pragma unroll
+    for (int c = 0; c < CBW; ++c) {
+        const int cb = (cbg * CBW + c) * NW + wave;
+        int a, b;
+        feature_pair(cb * 16 + (lane & 15), cb < CB_total ? F : 0, da, a, b);
+        offa[c] = a;
+        offb[c] = b;
+    }
+    const bool last_active = (cbg * CBW + CBW - 1) * NW + wave < CB_total;
+    d4 acc[RBW][CBW];
+#pragma unroll
+    for (int r = 0; r < RBW; ++r)
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) acc[r][c] = d4{0.0, 0.0, 0.0, 0.0};
+
+    // staging roles: sample sS of the half tile, rows rowS + 16 it (x~ rows; component rows for EXP < 2). EXP == 2: sample sR = 4 wave +
+    // (lane & 3), components NRV cg + it with cg = lane >> 2 -- one wave holds all K values of its 4 samples.
+    const int sS = lane & 31, rowS = 2 * wave + (lane >> 5);
+    const int sR = EXP == 2 ? 4 * wave + (lane & 3) : sS;
+    const int cg = lane >> 2;
+    double xv[NXV], rv[NRV], lv = 0.0;
+    auto prefetch = [&](uint32_t h) {
+        size_t ldx_ = ldx;
+        asm volatile("" : "+s"(ldx_));              // (row addresses formed per call, not carried through the matrix phase)
+        const uint32_t i = h * HT + sS;             // < n_pad: always inside the allocation
+#pragma unroll
+        for (int it = 0; it < NXV; ++it) xv[it] = xt[(size_t)min(rowS + 16 * it, D - 1) * ldx_ + i];
+        if constexpr (EXP == 2) {
+#pragma unroll
+            for (int it = 0; it < NRV; ++it) rv[it] = lw[(size_t)min(cg * NRV + it, K - 1) * ldr + h * HT + sR];
+        } else {
+#pragma unroll
+            for (int it = 0; it < NRV; ++it) rv[it] = lw[(size_t)min(rb0 * 16 + rowS + 16 * it, K - 1) * ldr + i];
+            if (EXP) lv = lse[i];
+        }
+    };
+    auto stage = [&](double* Xb, double* Rb, uint32_t h) {
+        if constexpr (EXP == 2) {
+            const uint32_t i = h * HT + sR;
+            const bool live = i < n;
+            double m = -__builtin_inf();
+#pragma unroll
+            for (int it = 0; it < NRV; ++it) {
+                if (cg * NRV + it >= K) rv[it] = -__builtin_inf();          // components beyond K: exp(-inf) = 0
+                m = fmax(m, rv[it]);
+            }
+            m = allreduce_max_bits2345(m, lane);
+            double sum = 0.0;
+#pragma unroll
+            for (int it = 0; it < NRV; ++it) {
+                rv[it] = exp_nonpos(rv[it] - m);
+                sum += rv[it];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            sum = allreduce_sum_bits2345(sum, lane);
+            const double inv = live ? 1.0 / sum : 0.0;                      // padding samples contribute nothing
+#pragma unroll
+            for (int it = 0; it < NRV; ++it) Rb[sR * RS + cg * NRV + it] = rv[it] * inv;
+            if (cg == 0 && blockIdx.y == 0) {                               // lse = m + log(sum): em_lse_finish_kernel
+                lse_out[i] = m;
+                ll_out[i] = sum;
+            }
+        } else {
+            const bool live = h * HT + sS < n;
+#pragma unroll
+            for (int it = 0; it < NRV; ++it) {
+                double r = rv[it];
+                if (EXP) r = exp_nonpos(r - lv);
+                const bool valid = live && (rb0 * 16 + rowS + 16 * it < K);
+                Rb[sS * RS + rowS + 16 * it] = valid ? r : 0.0;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NXV; ++it) {
+            const int j = rowS + 16 * it;
+            if (j < d) Xb[sS * XS + j] = xv[it] - shift[j];
+        }
+        if (wave == 0 && lane < HT) {
+            Xb[sS * XS + d] = 1.0;
+            Xb[sS * XS + da] = 0.0;
+        }
+    };
+
+    const uint32_t n_halves = (n + HT - 1) / HT;
+    constexpr int tile_doubles = HT * XS + HT * RS;
+    int buf = 0;
+    if (blockIdx.x < n_halves) prefetch(blockIdx.x);
+    for (uint32_t h = blockIdx.x; h < n_halves; h += gridDim.x, buf ^= 1) {
+        double* Xb = smem + buf * tile_doubles;
+        double* Rb = Xb + HT * XS;
+        stage(Xb, Rb, h);
+        __syncthreads();
+        const uint32_t next = h + gridDim.x;
+        prefetch(next < n_halves ? next : h);        // the last iteration re-reads its own half (discarded)
+        // ---- contraction: 8 groups of 4 samples. Lane group g = lane >> 4 takes sample sg + 8 g.
+        const double* xbase = Xb + 8 * (lane >> 4) * XS;
+        const double* rbase = Rb + 8 * (lane >> 4) * RS + (lane & 15);
+        __builtin_amdgcn_s_setprio(kMatrixPhasePriority);
+#pragma unroll 2
+        for (int sg = 0; sg < HT / 4; ++sg) {
+            const double* xr = xbase + sg * XS;
+            const double* rr = rbase + sg * RS;
+            double av[RBW];
+#pragma unroll
+            for (int r = 0; r < RBW; ++r) av[r] = rr[r * 16];
+#pragma unroll
+            for (int c = 0; c < CBW - 1; ++c) {
+                const double bv = xr[offa[c]] * xr[offb[c]];
+#pragma unroll
+                for (int r = 0; r < RBW; ++r)
+                    acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], bv, acc[r][c], 0, 0, 0);
+            }
+            constexpr int c = CBW - 1;
+            const double bv = xr[offa[c]] * xr[offb[c]];
+            if (last_active) {
+#pragma unroll
+                for (int r = 0; r < RBW; ++r)
+                    acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], bv, acc[r][c], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+
+    double* out = partials + (size_t)blockIdx.x * KP * FP;
+#pragma unroll
+    for (int r = 0; r < RBW; ++r)
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) {
+            const int cb = (cbg * CBW + c) * NW + wave;
+            if (cb < CB_total) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int k = (rb0 + r) * 16 + (lane >> 4) + 4 * g;
+                    out[(size_t)k * FP + cb * 16 + (lane & 15)] = acc[r][c][g];
+                }
+            }
+        }
+}
+
+[[maybe_unused]] inline bool half_tiles() { static const bool on = [] { const char* e = std::getenv("MLHIP_MSTATS_HALF"); return e && e[0] == '1'; }(); return on; }
+
+template <int RBW, int CBW>
+void launch_half(const MstatsArgs& a, const Plan& p, int grid_x, hipStream_t stream)
+{
+    constexpr int XSD = tile_stride<kMaxDim>();
+    const size_t smem = 2 * sizeof(double) * ((size_t)32 * XSD + (size_t)32 * (RBW * 16 + 1));
+    const dim3 grid(grid_x, p.n_rbg * p.n_cbg);
+#define MLHIP_HALF(E, LO, LL) \
+    hipLaunchKernelGGL((em_mstats_half_kernel<RBW, CBW, E>), grid, dim3(512), smem, stream, a.xt, a.ldx, a.n, a.d, padded_dim(a.d), a.shift, \
+                       a.lw, a.ldr, a.lse, a.K, p.n_rbg, p.CB, a.partials, p.KP, p.FP, LO, LL)
+    if (a.mode == kFromLogRespSelfNorm) MLHIP_HALF(2, a.lse_out, a.ll_out);
+    else if (a.mode == kFromLogResp) MLHIP_HALF(1, nullptr, nullptr);
+    else MLHIP_HALF(0, nullptr, nullptr);
+#undef MLHIP_HALF
+}
+
+#endif  // MLHIP_EXPERIMENTS
+
 template <int RBW, int CBW, int DM = kRegDim, int CBT = 0>
 void launch_t(const MstatsArgs& a, const Plan& p, int grid_x, hipStream_t stream)
 {
@@ -396,10 +619,15 @@ int MLHIP_PART_FN(launch_wide)(const MstatsArgs& a, const Plan& p, int grid_x, h
     constexpr int R = (MLHIP_PART - 1) % 4 + 1;
     if (p.RBW != R) return -1;
 #if MLHIP_PART > 4
+#ifdef MLHIP_EXPERIMENTS
+#define MLHIP_TRY_HALF(R_, C_) (half_tiles() ? (launch_half<R_, C_>(a, p, grid_x, stream), true) : false)
+#else
+#define MLHIP_TRY_HALF(R_, C_) false      /* (the half-tile kernel exists in the experiments library only) */
+#endif
     // 32 < d <= 128: 38..525 column blocks in column groups of 8 waves x (3, 4 or 5) blocks
 #define MLHIP_BIG(C) \
     if (p.CBW == C) { \
-        if (a.d <= kMidDim) launch_t<R, C, kMidDim>(a, p, grid_x, stream); else launch_t<R, C, kMaxDim>(a, p, grid_x, stream); \
+        if (a.d <= kMidDim) launch_t<R, C, kMidDim>(a, p, grid_x, stream); else if (!MLHIP_TRY_HALF(R, C)) launch_t<R, C, kMaxDim>(a, p, grid_x, stream); \
     } else
     MLHIP_BIG(3) MLHIP_BIG(4) MLHIP_BIG(5)
     { return -1; }
