@@ -287,11 +287,13 @@ constexpr int XS = 33;        // LDS row stride of a panel: ODD. The compiler pa
 /// what bound the first form of this kernel at 4.4 ms.)
 constexpr int KC = 4;
 
-/// Macro tiles along one edge of S_k. When d is a multiple of 64 the row of the constant 1 (the S1 sums and S0) would open a tile row
-/// of its own -- 15 tile pairs instead of 10 at d = 256, 10 instead of 6 at d = 192, all of it padding but one row: that row is then
-/// formed by em_mstats_big_lastrow_kernel and the tiles cover the d coordinates only (round 5).
-__host__ __device__ inline bool big_ones_row_apart(int d) { return d % MT == 0; }
-__host__ __device__ inline int big_tiles(int d) { return big_ones_row_apart(d) ? d / MT : (d + 1 + MT - 1) / MT; }
+/// Macro tiles along one edge of S_k: over the d COORDINATES only. The row of the constant 1 (the S1 sums and S0) would open a tile row
+/// of its own whenever d is a multiple of 64 -- 15 tile pairs instead of 10 at d = 256, all of it padding but one row; it is formed by
+/// the workgroups of the DIAGONAL tiles instead, on the vector unit, from the panel and the responsibilities they hold in LDS anyway:
+/// thread (row r of the tile, component c of the group) adds r_ic x~_ir over the panel's 32 samples in order -- 32 fused multiply-adds per
+/// chunk next to 8 192 cycles of matrix instructions (round 5; a separate kernel for that row took 0.5 - 0.7 ms: it re-read the
+/// responsibilities per 64 columns with no load in flight during its arithmetic).
+__host__ __device__ inline int big_tiles(int d) { return (d + MT - 1) / MT; }
 
 __global__ __launch_bounds__(256, 2) void em_mstats_big_kernel(const double* __restrict__ xt, size_t ldx, uint32_t n, int d,
                                                              const double* __restrict__ shift, const double* __restrict__ lw,
@@ -321,6 +323,8 @@ __global__ __launch_bounds__(256, 2) void em_mstats_big_kernel(const double* __r
     uint32_t c_end = c_begin + chunks_per_split;
     if (c_end > n_chunks) c_end = n_chunks;
     const int i_r = lane & 15, kq = lane >> 4;
+    const int l_r = tid & (MT - 1), l_c = tid / MT;                     // ones row (diagonal tiles): this thread's coordinate and component
+    double s1 = 0.0, s0 = 0.0;
     // Software pipeline (round 5): the NEXT chunk's panel entries and responsibilities are requested right behind the barrier and are in
     // flight during the matrix phase of this chunk; they go to LDS at the top of the next trip. (Round 4 loaded global -> LDS between
     // the two barriers: every chunk exposed a memory round trip, the matrix pipe was 43 % busy.)
@@ -372,6 +376,15 @@ __global__ __launch_bounds__(256, 2) void em_mstats_big_kernel(const double* __r
         }
         __syncthreads();
         if (ch + 1 < c_end) prefetch(ch + 1);
+        if (ta == tb) {                                                // (workgroup-uniform) the ones row: S1 over this tile's 64 coordinates, S0
+            const double* __restrict__ rc = rr + l_c * SC;
+            const double* __restrict__ xr = pb + l_r * XS;
+#pragma unroll 8
+            for (int sidx = 0; sidx < SC; ++sidx) {
+                s1 = __builtin_fma(rc[sidx], xr[sidx], s1);
+                s0 += rc[sidx];
+            }
+        }
         if (!idle) {
 #pragma unroll
             for (int ks = 0; ks < SC / 4; ++ks) {
@@ -393,6 +406,11 @@ __global__ __launch_bounds__(256, 2) void em_mstats_big_kernel(const double* __r
             }
         }
     }
+    if (ta == tb && k0 + l_c < K) {
+        double* __restrict__ out = partials + ((size_t)blockIdx.z * K + k0 + l_c) * F + (size_t)d * (d + 1) / 2;
+        if (b_base + l_r < d) out[b_base + l_r] = s1;
+        if (ta == 0 && l_r == 0) out[d] = s0;
+    }
     if (idle) return;
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
@@ -407,50 +425,9 @@ __global__ __launch_bounds__(256, 2) void em_mstats_big_kernel(const double* __r
                 for (int g = 0; g < 4; ++g) {
                     const int a = a_base + wa * 32 + u * 16 + kq + 4 * g;   // output row: kq + 4 g of the block; column: lane & 15
                     const int b = b_base + wb * 32 + v * 16 + i_r;
-                    if (a <= d && b <= a && !(big_ones_row_apart(d) && a == d)) out[(size_t)a * (a + 1) / 2 + b] = acc[c][u][v][g];
+                    if (a < d && b <= a) out[(size_t)a * (a + 1) / 2 + b] = acc[c][u][v][g];
                 }
     }
-}
-
-/// The row of the constant 1 when the tiles leave it out (d a multiple of 64): S1_kb = sum_i r_ik x~_ib (b < d) and S0_k = sum_i r_ik,
-/// entries d (d + 1) / 2 + b of the packed block. grid: (64-column block of b, group of KC components, sample range) -- the sample
-/// ranges of em_mstats_big_kernel, so that every partial block is complete. A panel of 64 columns x 32 samples goes through LDS as
-/// there; thread (column, component) walks its 32 samples in order.
-__global__ __launch_bounds__(256) void em_mstats_big_lastrow_kernel(const double* __restrict__ xt, size_t ldx, uint32_t n, int d,
-                                                                     const double* __restrict__ shift, const double* __restrict__ lw,
-                                                                     size_t ldr, const double* __restrict__ lse, int mode,
-                                                                     double* __restrict__ partials, int K, int F, uint32_t chunks_per_split)
-{
-    __shared__ double pa[MT * XS];
-    __shared__ double rr[KC * SC];
-    const int tid = threadIdx.x;
-    const int b_base = blockIdx.x * MT, k0 = blockIdx.y * KC;
-    const uint32_t n_chunks = (n + SC - 1) / SC;
-    const uint32_t c_begin = blockIdx.z * chunks_per_split;
-    uint32_t c_end = c_begin + chunks_per_split;
-    if (c_end > n_chunks) c_end = n_chunks;
-    const int col = tid & (MT - 1), comp = tid / MT;                    // this thread's output: (component k0 + comp, column b_base + col)
-    double acc = 0.0;
-    for (uint32_t ch = c_begin; ch < c_end; ++ch) {
-        const uint32_t i0 = ch * SC;
-        __syncthreads();
-        if (tid < KC * SC) {
-            const int c = tid / SC, sidx = tid - c * SC;
-            const uint32_t i = i0 + sidx;
-            const int k = k0 + c;
-            rr[tid] = (k < K && i < n) ? (mode == kFromResp ? lw[(size_t)k * ldr + i] : exp_nonpos(lw[(size_t)k * ldr + i] - lse[i])) : 0.0;
-        }
-        for (int e = tid; e < MT * SC; e += 256) {
-            const int r = e / SC, sidx = e - r * SC;
-            const int b = b_base + r;
-            pa[r * XS + sidx] = b < d ? xt[(size_t)b * ldx + i0 + sidx] - shift[b] : (b == d ? 1.0 : 0.0);
-        }
-        __syncthreads();
-#pragma unroll 8
-        for (int sidx = 0; sidx < SC; ++sidx) acc = __builtin_fma(rr[comp * SC + sidx], pa[col * XS + sidx], acc);
-    }
-    const int k = k0 + comp, b = b_base + col;
-    if (k < K && b <= d) partials[((size_t)blockIdx.z * K + k) * F + (size_t)d * (d + 1) / 2 + b] = acc;
 }
 
 // ---- K-means assignment -----------------------------------------------------------------------------------------------
@@ -620,9 +597,6 @@ int launch_em_mstats_big(const MstatsArgs& a, int num_cus, hipStream_t stream)
     const int T = big_tiles(a.d);
     hipLaunchKernelGGL(em_mstats_big_kernel, dim3(T * (T + 1) / 2, (a.K + KC - 1) / KC, splits), dim3(256), 0, stream, a.xt, a.ldx, a.n, a.d, a.shift, a.lw,
                        a.ldr, a.lse, a.mode, a.partials, a.K, F, per);
-    if (big_ones_row_apart(a.d))
-        hipLaunchKernelGGL(em_mstats_big_lastrow_kernel, dim3((a.d + 1 + MT - 1) / MT, (a.K + KC - 1) / KC, splits), dim3(256), 0, stream, a.xt, a.ldx,
-                           a.n, a.d, a.shift, a.lw, a.ldr, a.lse, a.mode, a.partials, a.K, F, per);
     return splits;
 }
 

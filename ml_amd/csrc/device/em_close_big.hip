@@ -263,27 +263,29 @@ __global__ __launch_bounds__(64) void whiten_trail_kernel(double* __restrict__ w
 }
 
 /// c = W (mean - shift): row i's sum over col = 0 .. i in ascending order, one product and one addition at a time (the host's loop).
-/// One thread per row; the rows of W are read as 64 x 64 tiles through LDS (a thread walking its own row of Wt directly touches one
+/// One thread per row (64 of the workgroup's 256; all four waves load); the rows of W are read as 64 x 64 tiles through LDS (a thread walking its own row of Wt directly touches one
 /// cache line per load and lane: 1.25 ms at d = 1024).
-__global__ __launch_bounds__(64) void close_big_cvec_kernel(const double* __restrict__ shift, double* __restrict__ work, int d)
+__global__ __launch_bounds__(256) void close_big_cvec_kernel(const double* __restrict__ shift, double* __restrict__ work, int d)
 {
     __shared__ double tile[64][65];
     __shared__ double diff[64];
-    const int k = blockIdx.x, tid = threadIdx.x;
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     BigView v(work, k, d);
     const int r0 = blockIdx.y * 64;
-    const int i = r0 + tid;
+    const int i = r0 + tid;                                                          // (threads 0 .. 63 own a row)
     double acc = 0.0;
     for (int c0 = 0; c0 <= r0; c0 += 64) {
         __syncthreads();
-        const int col = c0 + tid;
-        diff[tid] = col < d ? v.mean[col] - shift[col] : 0.0;
-        for (int r = 0; r < 64; ++r) tile[r][tid] = (r0 + r < d && col < d) ? v.Wt[(size_t)(r0 + r) * d + col] : 0.0;
+        const int col = c0 + lane;
+        if (wave == 0) diff[lane] = col < d ? v.mean[col] - shift[col] : 0.0;
+        for (int r = wave; r < 64; r += 4) tile[r][lane] = (r0 + r < d && col < d) ? v.Wt[(size_t)(r0 + r) * d + col] : 0.0;
         __syncthreads();
-        const int n_cols = i - c0 + 1 < 64 ? i - c0 + 1 : 64;                        // columns c0 .. min(i, c0 + 63)
-        for (int cc = 0; cc < n_cols; ++cc) acc += tile[tid][cc] * diff[cc];
+        if (tid < 64) {
+            const int n_cols = i - c0 + 1 < 64 ? i - c0 + 1 : 64;                    // columns c0 .. min(i, c0 + 63)
+            for (int cc = 0; cc < n_cols; ++cc) acc += tile[tid][cc] * diff[cc];
+        }
     }
-    if (i < d) v.c[i] = acc;
+    if (tid < 64 && i < d) v.c[i] = acc;
 }
 
 /// sum log L_jj, c = W (mean - shift), the refinement flag, the next E-step's record, the info block (em_close_body.hpp's last part,
@@ -296,11 +298,15 @@ __global__ __launch_bounds__(256) void close_big_finish_kernel(const double* __r
 {
     __shared__ double red[256];
     __shared__ double s_coef;
-    const int k = blockIdx.x, tid = threadIdx.x;
+    __shared__ double s_logs[1024], s_codes[1024];                                   // (d <= 1024: thread 0's two ordered scans walk LDS, not
+    const int k = blockIdx.x, tid = threadIdx.x;                                     //  1 024 dependent global loads each: 0.8 ms at d = 1024)
     const int F = (d + 1) * (d + 2) / 2;
     BigView v(work, k, d);
     const double mix = mixing[k];
-    for (int j = tid; j < d; j += 256) v.logs[j] = log(v.L[(size_t)j * d + j]);
+    for (int j = tid; j < d; j += 256) {
+        s_logs[j] = log(v.L[(size_t)j * d + j]);
+        s_codes[j] = v.codes[j];
+    }
     double reach = 0.0;
     for (int i = tid; i < d; i += 256) {
         const double acc = v.c[i];                                                   // (close_big_cvec_kernel)
@@ -313,12 +319,12 @@ __global__ __launch_bounds__(256) void close_big_finish_kernel(const double* __r
         int flag = 0;                                                                // scanned in order, a non-finite entry ends the scan
         if (mix > 0 && isfinite(mix))
             for (int a = 0; a < d; ++a) {
-                if (v.codes[a] == 2.0) break;
-                if (v.codes[a] == 1.0) { flag = 1; break; }
+                if (s_codes[a] == 2.0) break;
+                if (s_codes[a] == 1.0) { flag = 1; break; }
             }
         info[1 + k] = flag;
         double ldh = 0.0;
-        for (int j = 0; j < d; ++j) ldh += v.logs[j];                                // the host's order
+        for (int j = 0; j < d; ++j) ldh += s_logs[j];                                // the host's order
         s_coef = log(mix) - ldh;
         double m = 0.0;
         for (int t = 0; t < 256; ++t) m = red[t] > m ? red[t] : m;
@@ -372,7 +378,7 @@ void factor_and_finish(const double* stats, const double* mixing, const CloseArg
         if (below > 0)
             hipLaunchKernelGGL(whiten_trail_kernel, dim3(K, (cols + 63) / 64, (below + PB - 1) / PB), dim3(64), 0, stream, a.work, a.work, d, i0);
     }
-    hipLaunchKernelGGL(close_big_cvec_kernel, dim3(K, (d + 63) / 64), dim3(64), 0, stream, a.shift, a.work, d);
+    hipLaunchKernelGGL(close_big_cvec_kernel, dim3(K, (d + 63) / 64), dim3(256), 0, stream, a.shift, a.work, d);
     if (a.layout == 2) {
         const int PS = estep_mfma4_param_stride(a.D);
         hipLaunchKernelGGL(close_big_finish_kernel<2>, dim3(K), dim3(256), 0, stream, stats, K, d, a.D, a.shift, mixing, a.work, a.records, PS,
