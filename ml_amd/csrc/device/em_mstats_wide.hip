@@ -262,10 +262,11 @@ __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
             case 6: contract(std::integral_constant<int, 6>{}); break;
             default: contract(std::integral_constant<int, 7>{}); break;
             }
-        } else if constexpr (RBW * CBW < 20 && DM <= kRegDim) {
+        } else if constexpr (RBW * CBW < 20) {
         // Every shape but the headline's 4 x 5 tiles per wave (which sits at 256 registers): the lane's operand addresses (tile base +
         // coordinate offset) are formed ONCE per tile; inside the loop every LDS read is `ds_read base offset:imm` off running
         // pointers that advance by U sample groups per trip -- otherwise one v_add_u32 per read [r3] (d = 24, K = 64: 4.09 -> 3.97 ms).
+        // [r5] also above d = 32, where it had been left out: N = 1M, K = 32, d = 128 11.58 -> 10.54 ms, d = 96 6.50 -> 5.85.
         constexpr int U = 4;
         lds_cdouble* pa[CBW];
         lds_cdouble* pb[CBW];
