@@ -154,8 +154,8 @@ int mlhip_em_step_diag(mlhip_ctx* ctx, mlhip_data* data, uint32_t K,
  * MLHIP_COVARIANCE_DIAGONAL); *log_likelihood is that of the last E-step (i.e. under the parameters before the last M-step, like
  * the reference). Between two tests everything stays on the device -- statistics, all-reduce, the M-step's closing arithmetic
  * and the K Cholesky / inverse factorizations of EM::process_covariances (:274-287), the next E-step's records -- and the
- * host reads back 1 + 2K doubles per iteration (d <= 64; above that, or with MLHIP_DEVICE_CLOSE=0, the loop runs through
- * mlhip_em_step). Same results as calling mlhip_em_step in a loop, to the last bits of log().
+ * host reads back 1 + 2K doubles per iteration (d <= 1024: one wave per component with the matrices in LDS up to d = 64, panelled
+ * factorizations in global memory above; beyond d = 1024, or with MLHIP_DEVICE_CLOSE=0, the loop runs through mlhip_em_step). Same results as calling mlhip_em_step in a loop, to the last bits of log().
  * log_likelihood_history (max_steps doubles) may be NULL. Tolerances 0 run exactly max_steps iterations. */
 #define MLHIP_COVARIANCE_FULL 0
 #define MLHIP_COVARIANCE_DIAGONAL 1

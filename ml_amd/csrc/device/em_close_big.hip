@@ -117,14 +117,16 @@ __global__ __launch_bounds__(64) void chol_diag_kernel(double* __restrict__ work
     double t[PB];
 #pragma unroll
     for (int c = 0; c < PB; ++c) t[c] = (row && c < nb) ? v.L[(size_t)(j0 + c) * d + i] : 0.0;
+    // Column by column, each finished column's term going to every later column at once (the 31 - l updates of a step are independent
+    // of each other: issued back to back; walking an entry's terms only when its column comes up -- the form of em_close_body.hpp -- is
+    // a dependent chain of up to 31 products per step: 13.4 against ... us per launch). An entry still receives its terms in ascending l.
 #pragma unroll
-    for (int jj = 0; jj < PB; ++jj) {
-        if (jj < nb) {                                                               // (uniform)
-            double tt = t[jj];
+    for (int l = 0; l < PB; ++l) {
+        if (l < nb) {                                                                // (uniform)
+            const double ljj = sqrt(lane_value(t[l], l));
+            t[l] = r == l ? ljj : t[l] / ljj;                                        // (rows above the diagonal: unused)
 #pragma unroll
-            for (int l = 0; l < jj; ++l) tt -= t[l] * lane_value(t[l], jj);          // L(i, j0 + l) * L(j0 + jj, j0 + l)
-            const double ljj = sqrt(lane_value(tt, jj));
-            t[jj] = r == jj ? ljj : tt / ljj;                                        // (rows above the diagonal: unused)
+            for (int c = l + 1; c < PB; ++c) t[c] -= t[l] * lane_value(t[l], c);     // L(i, j0 + l) * L(j0 + c, j0 + l)
         }
     }
     if (row) {
