@@ -17,8 +17,10 @@ cases = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 fails = 0
 for case in range(cases):
     d = int(rng.choice([rng.integers(65, 129), rng.integers(129, 300), rng.integers(300, 700), rng.choice([96, 128, 192, 256, 320, 512])]))
-    K = int(rng.integers(1, 10))
-    n = int(rng.integers(max(d + 50, 600), 3000))
+    K = int(rng.integers(1, max(2, min(10, 6000 // (d + 60) + 1))))       # every component gets more samples than dimensions: with fewer
+    n = K * (d + 60) + int(rng.integers(0, 1000))                          # the covariance estimates are singular up to the 1e-15 ridge
+                                                                           # (ML/EM.cpp:252) and the ulp of log() between the two closings is
+                                                                           # amplified by a condition number of 1e15: nothing to compare
     X, mu0 = T._problem(d, K, n, int(rng.integers(1 << 30)))
     dt = _lib.Data(ctx, X)
     _, cov = dt.sample_covariance()
@@ -29,7 +31,8 @@ for case in range(cases):
         assert ll_d == ll_h and np.array_equal(pi_d, pi_h) and np.array_equal(mu_d, mu_h) and np.array_equal(S_d, S_h), "one iteration: bits"
         _, _, _, pi_h, mu_h, S_h, hist_h = T._iterate(dt, pi0, mu0, S0, 3, False)
         _, _, _, pi_d, mu_d, S_d, hist_d = T._iterate(dt, pi0, mu0, S0, 3, True)
-        assert np.max(np.abs(hist_d - hist_h) / np.abs(hist_h)) < 1e-13, "history"
+        herr = np.max(np.abs(hist_d - hist_h) / np.abs(hist_h))
+        assert herr < 1e-13, f"history {herr:.2e} (samples per component {n / K:.0f} at d = {d}; first-iteration ll equal: {hist_d[0] == hist_h[0]}, second: {abs(hist_d[1] - hist_h[1]) / abs(hist_h[1]):.1e})"
         sc = lambda a: max(1e-300, np.max(np.abs(a)))
         assert np.max(np.abs(mu_d - mu_h)) / sc(mu_h) < 1e-12 and np.max(np.abs(S_d - S_h)) / sc(S_h) < 1e-11, "three iterations"
         if d <= 400:
