@@ -29,7 +29,8 @@
 namespace mlhip {
 namespace {
 
-constexpr int PB = 32;             // panel width (columns of L / rows of W handled per step)
+constexpr int PB = 32;             // panel width (columns of L / rows of W handled per step). 64: measured slower (closing 4.49 against 3.56 ms at
+                                   // d = 1024, K = 4; 0.73 / 0.57 at d = 256): the in-panel chains grow faster than the launches shrink
 
 __device__ __forceinline__ int sidx(int a, int b) { return a * (a + 1) / 2 + b; }   // stats_index
 
@@ -148,16 +149,23 @@ __global__ __launch_bounds__(64) void chol_rows_kernel(double* __restrict__ work
     const int i_raw = j0 + PB + blockIdx.y * 64 + threadIdx.x;
     const bool row = i_raw < d;
     const int i = row ? i_raw : d - 1;
+    // the 32 x 32 diagonal block -> LDS, column by column (coalesced); read back as broadcasts. (Scalar loads of the partner values, a
+    // batch per column, were 32 dependent round trips of ~0.4 us: most of this kernel's 19 us.)
+    __shared__ double Ld[PB * PB];
+    for (int e = threadIdx.x; e < PB * PB; e += 64) {
+        const int c = e / PB, c2 = e - c * PB;
+        Ld[e] = (c < nb && c2 < nb) ? Lro[(size_t)(j0 + c) * d + j0 + c2] : 1.0;
+    }
     double t[PB];
 #pragma unroll
     for (int c = 0; c < PB; ++c) t[c] = c < nb ? v.L[(size_t)(j0 + c) * d + i] : 0.0;
+    __syncthreads();
     // (column by column of the diagonal block: entry c is final once the terms of the columns before it are in, and its own term goes
-    // to every later entry at once -- each entry still receives its terms in ascending order, and the partners L(j0 + c2, j0 + c),
-    // c2 > c, are CONTIGUOUS: a few wide scalar loads per column instead of one per term)
+    // to every later entry at once -- each entry still receives its terms in ascending order)
 #pragma unroll
     for (int c = 0; c < PB; ++c) {
         if (c < nb) {                                                                // (uniform)
-            const double* __restrict__ lc = Lro + (size_t)(j0 + c) * d + j0;         // column j0 + c of the diagonal block
+            const double* lc = Ld + c * PB;                                          // column j0 + c of the diagonal block
             t[c] = t[c] / lc[c];
 #pragma unroll
             for (int c2 = c + 1; c2 < PB; ++c2) t[c2] -= t[c] * lc[c2];
@@ -215,14 +223,20 @@ __global__ __launch_bounds__(64) void whiten_solve_kernel(double* __restrict__ w
     const int c_raw = blockIdx.y * 64 + threadIdx.x;
     const bool col = c_raw < i0 + nb;                                                // (columns right of the panel: zeros already)
     const int c = col ? c_raw : 0;
+    __shared__ double Ld[PB * PB];                                                   // the diagonal block of L (as in chol_rows_kernel)
+    for (int e = threadIdx.x; e < PB * PB; e += 64) {
+        const int r = e / PB, r2 = e - r * PB;
+        Ld[e] = (r < nb && r2 < nb) ? Lro[(size_t)(i0 + r) * d + i0 + r2] : 1.0;
+    }
     double acc[PB];
 #pragma unroll
     for (int r = 0; r < PB; ++r) acc[r] = r < nb ? v.Wt[(size_t)(i0 + r) * d + c] : 0.0;
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < PB; ++r) {                                                   // (column by column of the diagonal block, as chol_rows_kernel)
         if (r < nb) {                                                                // (uniform)
             const int i = i0 + r;
-            const double* __restrict__ lc = Lro + (size_t)i * d + i0;                // column i of L, rows i0 ..
+            const double* lc = Ld + r * PB;                                          // column i of L, rows i0 ..
             acc[r] = i < c ? 0.0 : acc[r] / lc[r];
 #pragma unroll
             for (int r2 = r + 1; r2 < PB; ++r2) acc[r2] -= lc[r2] * acc[r];
