@@ -527,7 +527,8 @@ bool big_dim_applies(int d) { return d > kMaxDim && d <= kBigMaxDim && big_dim_e
 /// The K-means assignment kernel of this file has no upper limit on d (no tile in LDS).
 bool big_dim_kmeans_applies(int d) { return d > kMaxDim && big_dim_enabled(); }
 
-/// Sample ranges a statistics tile is cut into (= partial blocks written), at most 32: the count whose workgroups fill whole rounds of
+constexpr int kMaxSplits = 64;      // (32 until late in round 5: 12 units x 32 = 384 workgroups on 512 slots at d = 192, K = 8)
+/// Sample ranges a statistics tile is cut into (= partial blocks written), at most kMaxSplits: the count whose workgroups fill whole rounds of
 /// the chip's 2 x CUs resident slots best (round 4 took ceil(3 CUs / units): 20 units x 32 = 640 workgroups on 512 slots at d = 256,
 /// K = 8 -- a second round a quarter full), the smallest such count within 3 % of the best.
 int big_dim_splits(int d, int K, int num_cus)
@@ -536,16 +537,16 @@ int big_dim_splits(int d, int K, int num_cus)
     const int units = T * (T + 1) / 2 * ((K + KC - 1) / KC);            // (tile pair, component group)
     const int slots = 2 * num_cus;
     double best = 0.0;
-    for (int s = 1; s <= 32; ++s) {
+    for (int s = 1; s <= kMaxSplits; ++s) {
         const int wgs = units * s, rounds = (wgs + slots - 1) / slots;
         const double eff = (double)wgs / ((double)rounds * slots);
         if (eff > best) best = eff;
     }
-    for (int s = 1; s <= 32; ++s) {
+    for (int s = 1; s <= kMaxSplits; ++s) {
         const int wgs = units * s, rounds = (wgs + slots - 1) / slots;
         if ((double)wgs / ((double)rounds * slots) >= best - 0.03 && wgs >= slots) return s;
     }
-    for (int s = 1; s <= 32; ++s) {                                     // (fewer workgroups than slots whatever the count: the fullest)
+    for (int s = 1; s <= kMaxSplits; ++s) {                                     // (fewer workgroups than slots whatever the count: the fullest)
         const int wgs = units * s, rounds = (wgs + slots - 1) / slots;
         if ((double)wgs / ((double)rounds * slots) >= best - 1e-9) return s;
     }

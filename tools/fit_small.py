@@ -4,6 +4,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from ml_amd.cppyml import clustering as cl
 from ml_amd import synth
+"""Whole `EM.fit` / `KMeans.fit` calls through cppyml (upload + initialisation + 50 iterations + labels): the FIRST call of a shape in this
+process against the later ones. The library's process-wide context is created by a throw-away fit of four 1-d points first and timed on
+its own line: it is paid once per process whatever is fitted (device initialisation), and round 4's "first fit 209 ms" mixed it into
+the first shape's number."""
+t0 = time.perf_counter()
+_km = cl.KMeans(1)
+_km.fit(np.array([[0.0], [1.0], [2.0], [3.0]]))
+print(f"context creation (+ a 4-point fit): {(time.perf_counter() - t0) * 1e3:.1f} ms")
 for n, d, K in ((10_000, 4, 3), (100_000, 16, 8), (1_000_000, 16, 16)):
     mix = synth.Mixture(d, K, seed=3)
     X, _ = mix.sample(n)
