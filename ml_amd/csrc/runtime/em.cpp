@@ -70,13 +70,11 @@ void prepare_estep(mlhip_data* dt, int K, const double* mixing, const double* me
         const int d = dt->d;
         const size_t n_par = (size_t)K * ((size_t)d * d + d + 1);
         dt->close_work.reserve(sizeof(double) * em_close_work_doubles(d, K));
-        dt->params_host.reserve(sizeof(double) * n_par);
-        double* stage = dt->params_host.as<double>();
-        std::memcpy(stage, mixing, sizeof(double) * K);
-        std::memcpy(stage + K, means, sizeof(double) * K * d);
-        std::memcpy(stage + K + (size_t)K * d, covs, sizeof(double) * K * d * d);
         double* area = em_close_big_param_area(dt->close_work.as<double>(), d, K);
-        HIP_CHECK(hipMemcpyAsync(area, stage, sizeof(double) * n_par, hipMemcpyHostToDevice, ctx->stream));
+        // (straight from the caller's arrays: the covariances alone are K d^2 doubles -- 0.5 GB at K = 64, d = 1024 --, no pinned copy of that)
+        HIP_CHECK(hipMemcpyAsync(area, mixing, sizeof(double) * K, hipMemcpyHostToDevice, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(area + K, means, sizeof(double) * K * d, hipMemcpyHostToDevice, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(area + K + (size_t)K * d, covs, sizeof(double) * K * d * d, hipMemcpyHostToDevice, ctx->stream));
         CloseArgs ca{};
         ca.K = K; ca.d = d; ca.D = dt->D; ca.shift = dt->shift_dev.as<double>();
         ca.layout = use_mfma4 ? 2 : 0;
@@ -86,7 +84,7 @@ void prepare_estep(mlhip_data* dt, int K, const double* mixing, const double* me
         ca.work = dt->close_work.as<double>();
         launch_em_records_big(ca, ctx->stream);
         HIP_CHECK(hipGetLastError());
-        ctx->sync();                                     // (params_host may be rewritten by the caller's next upload)
+        ctx->sync();                                     // (the caller's arrays may change once this returns)
     } else if (use_mfma4) {
         // FOLD form (no per-component mean subtraction in the kernel) while every |W_k (mu_k - shift)| is small enough for
         // the parity tolerances; the exact form otherwise. Every rank decides from the same parameters. MLHIP_ESTEP_FOLD=0: off.
