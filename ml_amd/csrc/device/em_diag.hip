@@ -753,10 +753,14 @@ __global__ __launch_bounds__(256, 2) void em_diag_mixed_kernel(
 #pragma unroll
                 for (int s = 0; s < S; ++s) x[s][j] -= sh;
             }
+            // (no zeroing of the 32 sums: the first dimension's term is a plain product -- fma(t, t, +0) and t * t are the same bits --,
+            // 32 register moves per 64 samples less [r5]; the timing build zeroes them when the density loop is knocked out)
+            if (MLHIP_KO(1)) {
 #pragma unroll
-            for (int s = 0; s < S; ++s)
+                for (int s = 0; s < S; ++s)
 #pragma unroll
-                for (int k = 0; k < KMAX; ++k) lwv[s][k] = 0.0;
+                    for (int k = 0; k < KMAX; ++k) lwv[s][k] = 0.0;
+            }
             // Software pipeline over the dimensions, in HALVES of 8 components: the operand pairs (a, b) of a half -- eight 16-byte LDS
             // broadcast reads -- are re-loaded for dimension j + 1 as soon as dimension j's arithmetic on that half has been ISSUED,
             // and land while the other half's 16 S instructions run (no second operand buffer; the waits are the compiler's own
@@ -783,7 +787,8 @@ __global__ __launch_bounds__(256, 2) void em_diag_mixed_kernel(
 #pragma unroll
                             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                                for (int s = 0; s < S; ++s) lwv[s][h * KH + g + u] = __builtin_fma(t[u][s], t[u][s], lwv[s][h * KH + g + u]);
+                                for (int s = 0; s < S; ++s)
+                                    lwv[s][h * KH + g + u] = j == 0 ? t[u][s] * t[u][s] : __builtin_fma(t[u][s], t[u][s], lwv[s][h * KH + g + u]);
                         }
                         if (j + 1 < D) {
 #pragma unroll
