@@ -18,6 +18,10 @@
 #include "em_fused_valu_body.hpp"
 #include "parts.hpp"
 
+#ifndef SMALL_STATS_UNROLL
+#define SMALL_STATS_UNROLL 16   // the 16 sample groups of a tile, all of them [r5] (d = 8, K = 32: 1.73 -> 1.69 ms)
+#endif
+
 namespace mlhip {
 namespace mstats {
 namespace {
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(256, (D <= 4 && RBW <= 2) ? 3 : 2) void em_fused_sm
             __builtin_amdgcn_wave_barrier();
             if (rb * 16 < Kt) {                          // wave-uniform: skip all-zero row blocks
                 __builtin_amdgcn_s_setprio(kMatrixPhasePriority);   // see em_estep_mfma4.hip
-#pragma unroll 4
+#pragma unroll SMALL_STATS_UNROLL
                 for (int sg = 0; sg < TS / 4; ++sg) {
                     const double av = rbase[sg * RSS];
                     const double* xr = xbase + sg * XSS;

@@ -24,6 +24,10 @@
 #include "em_mstats_common.hpp"
 #include "exp_nonpos.hpp"
 
+#ifndef MSTATS_UNROLL_GEN
+#define MSTATS_UNROLL_GEN 16   // the 16 sample groups of a tile, all of them (see the contraction loop)
+#endif
+
 namespace mlhip {
 namespace mstats {
 namespace {
@@ -267,7 +271,8 @@ __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
         // coordinate offset) are formed ONCE per tile; inside the loop every LDS read is `ds_read base offset:imm` off running
         // pointers that advance by U sample groups per trip -- otherwise one v_add_u32 per read [r3] (d = 24, K = 64: 4.09 -> 3.97 ms).
         // [r5] also above d = 32, where it had been left out: N = 1M, K = 32, d = 128 11.58 -> 10.54 ms, d = 96 6.50 -> 5.85.
-        constexpr int U = 4;
+        constexpr int U = TS / 4;                    // [r5] the whole tile unrolled: no pointer advances at all (U = 4 until round 5: d = 128, K = 32 10.5 -> 10.1 ms,
+                                                     // d = 32, K = 32 3.11 -> 3.00, d = 28, K = 48 3.53 -> 3.42, d = 12, K = 48 0.574 -> 0.553)
         lds_cdouble* pa[CBW];
         lds_cdouble* pb[CBW];
 #pragma unroll
@@ -306,7 +311,10 @@ __global__ __launch_bounds__(512, 2) void em_mstats_wide_kernel(
             pr += U * RS;
         }
         } else {
-#pragma unroll 2
+        // [r5] unrolled over the WHOLE tile (two sample groups per trip until round 5): the operand addresses become one register per column
+        // block plus immediates -- no address arithmetic between the matrix instructions --, 249 registers and no scratch instead of
+        // 256 + 8 bytes: headline statistics kernel 11.66 -> 11.09 ms (42.7 - 42.8 it/s from 41.6 on the same box), d = 64, K = 64 13.14 -> 12.53.
+#pragma unroll MSTATS_UNROLL_GEN
         for (int sg = 0; sg < TS / 4; ++sg) {
             const double* xr = xbase + sg * XS;
             const double* rr = rbase + sg * RS;
