@@ -112,8 +112,9 @@ __global__ __launch_bounds__(64 * NW, D <= 32 ? 8 / SB : 2) void em_estep_mfma4_
         {
             // (The row pointer is made opaque per tile: left to itself the compiler hoists all Q x SB 64-bit load addresses out of the
             // tile loop and carries them in registers -- 64 to 128 of them at d > 64, spilled to scratch around every tile in round 4.)
-            const double* row = xt + (size_t)g * ldx + base + s;
-            asm volatile("" : "+v"(row));
+            size_t first = (size_t)g * ldx + base + s;      // (the OFFSET is made opaque, not the pointer: loads through a laundered pointer
+            asm volatile("" : "+v"(first));                  //  become flat loads, which also count on the LDS counter)
+            const double* row = xt + first;
 #pragma unroll
             for (int C = 0; C < Q; ++C)
 #pragma unroll
