@@ -315,9 +315,23 @@ __global__ __launch_bounds__(256) void close_big_finish_kernel(const double* __r
     __shared__ double red[256];
     __shared__ double s_coef;
     __shared__ double s_logs[1024], s_codes[1024];                                   // (d <= 1024: thread 0's two ordered scans walk LDS, not
-    const int k = blockIdx.x, tid = threadIdx.x;                                     //  1 024 dependent global loads each: 0.8 ms at d = 1024)
+    const int k = blockIdx.x, tid = threadIdx.x;                                     //  1 024 dependent global loads each)
     const int F = (d + 1) * (d + 2) / 2;
     BigView v(work, k, d);
+    if constexpr (LAYOUT == 0) {
+        // The packed triangle of W -- D (D + 1) / 2 doubles, 4 MB at d = 1024 -- is copied by the workgroups blockIdx.y >= 1, rows dealt
+        // round-robin (one workgroup moving all of it took 0.7 ms of the 0.8 this kernel ran at d = 1024); workgroup 0 does the rest.
+        if (blockIdx.y > 0) {
+            double* __restrict__ rec = records + (size_t)k * PS;
+            const int wave = tid >> 6, lane = tid & 63;
+            const int stride = 4 * ((int)gridDim.y - 1);
+            for (int j = ((int)blockIdx.y - 1) * 4 + wave; j < D; j += stride) {
+                double* __restrict__ out = rec + D + (size_t)j * (j + 1) / 2;
+                for (int l = lane; l <= j; l += 64) out[l] = j < d ? v.Wt[(size_t)j * d + l] : 0.0;
+            }
+            return;
+        }
+    }
     const double mix = mixing[k];
     for (int j = tid; j < d; j += 256) {
         s_logs[j] = log(v.L[(size_t)j * d + j]);
@@ -366,12 +380,7 @@ __global__ __launch_bounds__(256) void close_big_finish_kernel(const double* __r
         if (tid == 0) rec[NB * 16 + 2 * D] = s_coef;
     } else {
         for (int j = tid; j < D; j += 256) rec[j] = j < d ? v.mean[j] : 0.0;
-        const int wave = tid >> 6, lane = tid & 63;
-        for (int j = wave; j < D; j += 4) {                                          // packed lower triangle, row by row
-            double* __restrict__ out = rec + D + (size_t)j * (j + 1) / 2;
-            for (int l = lane; l <= j; l += 64) out[l] = j < d ? v.Wt[(size_t)j * d + l] : 0.0;
-        }
-        if (tid == 0) rec[PS - 1] = s_coef;
+        if (tid == 0) rec[PS - 1] = s_coef;                                          // (the packed triangle: the workgroups blockIdx.y >= 1)
     }
 }
 
@@ -401,8 +410,8 @@ void factor_and_finish(const double* stats, const double* mixing, const CloseArg
                            a.info);
     } else {
         const int PS = estep_param_stride(a.D);
-        hipLaunchKernelGGL(close_big_finish_kernel<0>, dim3(K), dim3(256), 0, stream, stats, K, d, a.D, a.shift, mixing, a.work, a.records, PS,
-                           a.info);
+        hipLaunchKernelGGL(close_big_finish_kernel<0>, dim3(K, 1 + (a.D + 63) / 64), dim3(256), 0, stream, stats, K, d, a.D, a.shift, mixing, a.work,
+                           a.records, PS, a.info);
     }
 }
 
