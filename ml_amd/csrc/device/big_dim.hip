@@ -145,7 +145,10 @@ __global__ __launch_bounds__(256) void em_estep_big_kernel(const double* __restr
 // into the samples' q on the spot; log-sum-exp over the components is a separate pass over lw (em_lse_rows_kernel), so a unit of work
 // is (sample tile, component) and the units are dealt to persistent workgroups round-robin.
 constexpr int GR = 128, GS = 128, GC = 16;      // rows, samples, columns per chunk
-constexpr int GWS = GC + 1, GZS = GS + 1;       // LDS row strides (odd)
+constexpr int GWS = GC + 1;                     // LDS row stride of the W chunk (odd)
+constexpr int GZS = GS + 16;                    // ... of the centred-sample chunk: 16 mod 32 doubles -- the B operand's two rows of a 32-lane
+                                                // half (kq = 0, 1) land 32 banks apart; with GS + 1 they were ONE bank pair apart and 15 of 16
+                                                // lanes collided (SQ_LDS_BANK_CONFLICT 4.6e8 of SQ_LDS_IDX_ACTIVE 7.4e8 at d = 1024)
 
 __global__ __launch_bounds__(256, 2) void em_estep_gemm_kernel(const double* __restrict__ xt, size_t ldx, uint32_t n_pad, int D,
                                                                 const double* __restrict__ params, int K, double* __restrict__ lw_out,
@@ -160,7 +163,9 @@ __global__ __launch_bounds__(256, 2) void em_estep_gemm_kernel(const double* __r
     const size_t PS = (size_t)D + (size_t)D * (D + 1) / 2 + 1;
     const int n_rb = (D + GR - 1) / GR;
     const uint32_t n_tiles = n_pad / GS, n_units = n_tiles * (uint32_t)K;
-    // staging roles: W chunk -- row w_r, columns 8 w_h .. + 7; Z chunk -- column (of W) z_j, samples 8 z_g .. + 7
+    // staging roles: W chunk -- row w_r, columns 8 w_h .. + 7; Z chunk -- column (of W) z_j, samples z_g + 16 j (a thread's eight samples
+    // interleaved with its neighbours': 16 lanes load and store 16 consecutive doubles -- eight consecutive ones per thread put the lanes
+    // of a store 64 bytes apart, an 8-way bank conflict)
     const int w_r = tid >> 1, w_h = tid & 1, z_j = tid >> 4, z_g = tid & 15;
     for (uint32_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
         const uint32_t tile = unit / (uint32_t)K;
@@ -180,9 +185,9 @@ __global__ __launch_bounds__(256, 2) void em_estep_gemm_kernel(const double* __r
 #pragma unroll
             for (int j = 0; j < 8; ++j) wv[j] = wr[l0 + j <= rowc ? l0 + j : rowc];
             const int l = c * GC + z_j, lc = l < D ? l : D - 1;
-            const double* __restrict__ xr = xt + (size_t)lc * ldx_ + i0 + 8 * z_g;
+            const double* __restrict__ xr = xt + (size_t)lc * ldx_ + i0 + z_g;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) zv[j] = xr[j];
+            for (int j = 0; j < 8; ++j) zv[j] = xr[16 * j];
             mu = p[lc];
         };
         auto stage = [&](int rb, int c, int buf) {
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void em_estep_gemm_kernel(const double* __r
 #pragma unroll
             for (int j = 0; j < 8; ++j) Wc[buf][w_r * GWS + 8 * w_h + j] = (row < D && l0 + j <= row) ? wv[j] : 0.0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) Zc[buf][z_j * GZS + 8 * z_g + j] = zv[j] - mu;
+            for (int j = 0; j < 8; ++j) Zc[buf][z_j * GZS + z_g + 16 * j] = zv[j] - mu;
         };
         int buf = 0;
         prefetch(0, 0);
