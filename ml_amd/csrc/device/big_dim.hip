@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void em_estep_big_kernel(const double* __restr
 // The kernel above keeps ONE centred tile of 16 samples per workgroup (all D rows of it: 128 KB at D = 1024) and streams the whole of W
 // past it: every element of W is fetched again for every 16 samples -- 4 flop per byte from L2, which is what it ran at (15.8 TFLOP/s
 // at d = 1024: 52 GB through L2 per launch). Here a workgroup owns a tile of 128 rows of Y = W (X - mu) x 128 samples in registers (each
-// of four waves 64 x 64: 16 accumulator blocks) and walks the columns l of W in chunks of 16: 128 x 16 of W and 16 x 128 of the centred
+// of four waves 64 x 64: 16 accumulator blocks -- its rows are every other 16-row block of the tile) and walks the columns l of W in chunks of 16: 128 x 16 of W and 16 x 128 of the centred
 // samples go through LDS, double-buffered, the next chunk in flight during the matrix phase: 16 flop per byte. Only chunks on or left
 // of the tile's diagonal exist; a wave skips the 16-row blocks that lie wholly right of it. The squares of a finished tile are folded
 // into the samples' q on the spot; log-sum-exp over the components is a separate pass over lw (em_lse_rows_kernel), so a unit of work
@@ -213,9 +213,13 @@ __global__ __launch_bounds__(256, 2) void em_estep_gemm_kernel(const double* __r
                 __syncthreads();
                 if (c + 1 < n_c) prefetch(rb, c + 1);
                 else if (rb + 1 < n_rb) prefetch(rb + 1, 0);
-                const double* Wb = Wc[buf] + (wa * 64 + i_r) * GWS + kq;
+                const double* Wb = Wc[buf] + (wa * 16 + i_r) * GWS + kq;
                 const double* Zb = Zc[buf] + kq * GZS + wb * 64 + i_r;
-                const int first_row = row0 + wa * 64;                   // block u of this wave: rows first_row + 16 u .. + 15
+                // block u of this wave: rows first_row + 32 u .. + 15 -- the tile's eight 16-row blocks dealt ALTERNATELY to the two
+                // waves of a sample half. With 64 consecutive rows per wave the lower wave carried the whole triangle of a diagonal tile
+                // and the upper one all of a ragged last tile (d = 192: rows 128 .. 191 on one wave, the other idle), and the waves of
+                // a kind sit on the same SIMDs in every workgroup of the CU.
+                const int first_row = row0 + wa * 16;
 #pragma unroll
                 for (int ks = 0; ks < GC / 4; ++ks) {
                     const int l_lo = c * GC + 4 * ks;                   // columns l_lo .. l_lo + 3
@@ -224,15 +228,15 @@ __global__ __launch_bounds__(256, 2) void em_estep_gemm_kernel(const double* __r
                     for (int v = 0; v < 4; ++v) bv[v] = Zb[4 * ks * GZS + 16 * v];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        if (l_lo <= first_row + 16 * u + 15 && first_row + 16 * u < D) {   // (wave-uniform: blocks wholly right of the diagonal or below row D - 1 hold zeros)
-                            const double av = Wb[16 * u * GWS + 4 * ks];
+                        if (l_lo <= first_row + 32 * u + 15 && first_row + 32 * u < D) {   // (wave-uniform: blocks wholly right of the diagonal or below row D - 1 hold zeros)
+                            const double av = Wb[32 * u * GWS + 4 * ks];
 #pragma unroll
                             for (int v = 0; v < 4; ++v) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[v], acc[u][v], 0, 0, 0);
                         }
                     }
                 }
             }
-            // the finished tile's squares: lane (i_r, kq) holds rows kq + 4 g + 16 u of sample 16 v + i_r
+            // the finished tile's squares: lane (i_r, kq) holds rows 16 wa + kq + 4 g + 32 u of sample 16 v + i_r
 #pragma unroll
             for (int v = 0; v < 4; ++v)
 #pragma unroll
