@@ -10,6 +10,8 @@
 //                             row and 32 columns, the partner rows' values by scalar loads): all the parallelism of the factorization
 //   per panel    whiten_solve : the panel's 32 rows of W = L^-1 against the diagonal block, one thread per column of W
 //   (of W)       whiten_trail : their terms to every later row at once
+//                (the same panel of L and of W in the same launches: panel_solve_kernel = chol_rows + whiten_solve,
+//                 panel_trail_kernel = chol_trail + whiten_trail -- 3 launches per panel)
 //   finish       sum log L_jj, c = W (mean - shift), flags, the record in the E-step's layout, the info block
 // A first form walked the earlier columns per panel (left-looking: one launch per panel and long chains per thread: 25 ms at d = 1024,
 // K = 4); with the trailing updates every launch is short and wide (3 + 2 launches per panel).
@@ -140,18 +142,17 @@ __global__ __launch_bounds__(64) void chol_diag_kernel(double* __restrict__ work
 /// Rows below the panel's diagonal block, one thread per row: the panel's own columns against the diagonal block (final:
 /// chol_diag_kernel ran before). `work_ro` is the same workspace, read-only here for everything this kernel reads through it (the
 /// diagonal rows: other rows than the ones it writes) -- uniform addresses, scalar loads.
-__global__ __launch_bounds__(64) void chol_rows_kernel(double* __restrict__ work, const double* __restrict__ work_ro, int d, int j0)
+__device__ __forceinline__ void chol_rows_body(double* __restrict__ work, const double* __restrict__ work_ro, int d, int j0, int k, int by,
+                                               double* __restrict__ Ld)
 {
-    const int k = blockIdx.x;
     BigView v(work, k, d);
     const double* __restrict__ Lro = work_ro + (size_t)k * big_stride(d);
     const int nb = d - j0 < PB ? d - j0 : PB;
-    const int i_raw = j0 + PB + blockIdx.y * 64 + threadIdx.x;
+    const int i_raw = j0 + PB + by * 64 + threadIdx.x;
     const bool row = i_raw < d;
     const int i = row ? i_raw : d - 1;
     // the 32 x 32 diagonal block -> LDS, column by column (coalesced); read back as broadcasts. (Scalar loads of the partner values, a
     // batch per column, were 32 dependent round trips of ~0.4 us: most of this kernel's 19 us.)
-    __shared__ double Ld[PB * PB];
     for (int e = threadIdx.x; e < PB * PB; e += 64) {
         const int c = e / PB, c2 = e - c * PB;
         Ld[e] = (c < nb && c2 < nb) ? Lro[(size_t)(j0 + c) * d + j0 + c2] : 1.0;
@@ -181,15 +182,14 @@ __global__ __launch_bounds__(64) void chol_rows_kernel(double* __restrict__ work
 /// Right-looking step of the factorization: the terms l = j0 .. j0 + 31 of the panel just finished go to the entries (i, jb + c),
 /// c = 0 .. 31, of one later column block -- one thread per row i >= jb, 32 accumulators, the partner values L(jb + c, l) by scalar
 /// loads. Every entry receives its terms in ascending l: panels in order, l in order inside a panel.
-__global__ __launch_bounds__(64) void chol_trail_kernel(double* __restrict__ work, const double* __restrict__ work_ro, int d, int j0)
+__device__ __forceinline__ void chol_trail_body(double* __restrict__ work, const double* __restrict__ work_ro, int d, int j0, int k, int by, int bz)
 {
-    const int k = blockIdx.x;
     BigView v(work, k, d);
     const double* __restrict__ Lro = work_ro + (size_t)k * big_stride(d);
-    const int jb = j0 + PB + (int)blockIdx.z * PB;                                   // first column of the block
+    const int jb = j0 + PB + bz * PB;                                   // first column of the block
     const int nbc = d - jb < PB ? d - jb : PB;
-    const int i_raw = jb + blockIdx.y * 64 + threadIdx.x;
-    if (jb + (int)blockIdx.y * 64 >= d) return;                                       // (uniform: no row of this block exists)
+    const int i_raw = jb + by * 64 + threadIdx.x;
+    if (jb + by * 64 >= d) return;                                       // (uniform: no row of this block exists)
     const bool row = i_raw < d;
     const int i = row ? i_raw : d - 1;
     double t[PB];
@@ -214,16 +214,16 @@ __global__ __launch_bounds__(64) void chol_trail_kernel(double* __restrict__ wor
 /// entries above the diagonal are set to zero as the host sets them. Stored transposed (Wt[i * d + c]: the threads of a wave -- one
 /// per column c -- touch neighbouring words). This kernel: the 32 rows i0 .. of one panel against the diagonal block of L, the terms of
 /// all rows l < i0 being in (whiten_trail_kernel).
-__global__ __launch_bounds__(64) void whiten_solve_kernel(double* __restrict__ work, const double* __restrict__ work_ro, int d, int i0)
+__device__ __forceinline__ void whiten_solve_body(double* __restrict__ work, const double* __restrict__ work_ro, int d, int i0, int k, int by,
+                                                  double* __restrict__ Ld)
 {
-    const int k = blockIdx.x;
     BigView v(work, k, d);
     const double* __restrict__ Lro = work_ro + (size_t)k * big_stride(d);
     const int nb = d - i0 < PB ? d - i0 : PB;
-    const int c_raw = blockIdx.y * 64 + threadIdx.x;
+    const int c_raw = by * 64 + threadIdx.x;
     const bool col = c_raw < i0 + nb;                                                // (columns right of the panel: zeros already)
     const int c = col ? c_raw : 0;
-    __shared__ double Ld[PB * PB];                                                   // the diagonal block of L (as in chol_rows_kernel)
+    // Ld: the diagonal block of L (as in chol_rows_body)
     for (int e = threadIdx.x; e < PB * PB; e += 64) {
         const int r = e / PB, r2 = e - r * PB;
         Ld[e] = (r < nb && r2 < nb) ? Lro[(size_t)(i0 + r) * d + i0 + r2] : 1.0;
@@ -251,14 +251,13 @@ __global__ __launch_bounds__(64) void whiten_solve_kernel(double* __restrict__ w
 
 /// The finished rows l = i0 .. i0 + 31 of W go to the 32 later rows ib .. of one row block: (i, c) -= L(i, l) W(l, c), ascending l.
 /// Only the columns c < i0 + 32 can hold anything but zero.
-__global__ __launch_bounds__(64) void whiten_trail_kernel(double* __restrict__ work, const double* __restrict__ work_ro, int d, int i0)
+__device__ __forceinline__ void whiten_trail_body(double* __restrict__ work, const double* __restrict__ work_ro, int d, int i0, int k, int by, int bz)
 {
-    const int k = blockIdx.x;
     BigView v(work, k, d);
     const double* __restrict__ Lro = work_ro + (size_t)k * big_stride(d);
-    const int ib = i0 + PB + (int)blockIdx.z * PB;                                   // first row of the block
+    const int ib = i0 + PB + bz * PB;                                   // first row of the block
     const int nbr = d - ib < PB ? d - ib : PB;
-    const int c_raw = blockIdx.y * 64 + threadIdx.x;
+    const int c_raw = by * 64 + threadIdx.x;
     const bool col = c_raw < i0 + PB;
     const int c = col ? c_raw : 0;
     double acc[PB];
@@ -276,6 +275,27 @@ __global__ __launch_bounds__(64) void whiten_trail_kernel(double* __restrict__ w
         for (int r = 0; r < PB; ++r)
             if (r < nbr) v.Wt[(size_t)(ib + r) * d + c] = acc[r];
     }
+}
+
+/// Panel p of L and panel p of W = L^-1 advance TOGETHER (late round 5; before: all panels of L, then all panels of W -- 3 + 2 launches
+/// of 14 - 18 us per panel, each a short chain of dependent steps in every thread, 160 of them in a row at d = 1024). The rows of W in
+/// panel p need the diagonal block of L (chol_diag of the panel) and the terms of W's earlier panels; their terms for the later rows
+/// need L's rows below the block in the panel's columns (chol_rows of the panel) -- nothing of L's LATER panels. So one launch carries
+/// chol_rows and whiten_solve of a panel (workgroups blockIdx.y < ny_chol: rows of L; the others: columns of W), the next one
+/// chol_trail and whiten_trail: 3 launches per panel, the same values by the same operations.
+__global__ __launch_bounds__(64) void panel_solve_kernel(double* __restrict__ work, const double* __restrict__ work_ro, int d, int j0, int ny_chol)
+{
+    __shared__ double Ld[PB * PB];
+    const int by = (int)blockIdx.y;
+    if (by < ny_chol) chol_rows_body(work, work_ro, d, j0, (int)blockIdx.x, by, Ld);
+    else whiten_solve_body(work, work_ro, d, j0, (int)blockIdx.x, by - ny_chol, Ld);
+}
+
+__global__ __launch_bounds__(64) void panel_trail_kernel(double* __restrict__ work, const double* __restrict__ work_ro, int d, int j0, int ny_chol)
+{
+    const int by = (int)blockIdx.y;
+    if (by < ny_chol) chol_trail_body(work, work_ro, d, j0, (int)blockIdx.x, by, (int)blockIdx.z);
+    else whiten_trail_body(work, work_ro, d, j0, (int)blockIdx.x, by - ny_chol, (int)blockIdx.z);
 }
 
 /// c = W (mean - shift): row i's sum over col = 0 .. i in ascending order, one product and one addition at a time (the host's loop).
@@ -391,17 +411,11 @@ void factor_and_finish(const double* stats, const double* mixing, const CloseArg
     for (int j0 = 0; j0 < d; j0 += PB) {
         hipLaunchKernelGGL(chol_diag_kernel, dim3(K), dim3(64), 0, stream, a.work, d, j0);
         const int below = d - (j0 + PB);                                             // rows / columns behind the panel
-        if (below > 0) {
-            hipLaunchKernelGGL(chol_rows_kernel, dim3(K, (below + 63) / 64), dim3(64), 0, stream, a.work, a.work, d, j0);
-            hipLaunchKernelGGL(chol_trail_kernel, dim3(K, (below + 63) / 64, (below + PB - 1) / PB), dim3(64), 0, stream, a.work, a.work, d, j0);
-        }
-    }
-    for (int i0 = 0; i0 < d; i0 += PB) {
-        const int cols = i0 + PB < d ? i0 + PB : d;                                  // columns that hold anything but zero so far
-        hipLaunchKernelGGL(whiten_solve_kernel, dim3(K, (cols + 63) / 64), dim3(64), 0, stream, a.work, a.work, d, i0);
-        const int below = d - (i0 + PB);
+        const int cols = j0 + PB < d ? j0 + PB : d;                                  // columns of W that hold anything but zero so far
+        const int ny_chol = below > 0 ? (below + 63) / 64 : 0, ny_w = (cols + 63) / 64;
+        hipLaunchKernelGGL(panel_solve_kernel, dim3(K, ny_chol + ny_w), dim3(64), 0, stream, a.work, a.work, d, j0, ny_chol);
         if (below > 0)
-            hipLaunchKernelGGL(whiten_trail_kernel, dim3(K, (cols + 63) / 64, (below + PB - 1) / PB), dim3(64), 0, stream, a.work, a.work, d, i0);
+            hipLaunchKernelGGL(panel_trail_kernel, dim3(K, ny_chol + ny_w, (below + PB - 1) / PB), dim3(64), 0, stream, a.work, a.work, d, j0, ny_chol);
     }
     hipLaunchKernelGGL(close_big_cvec_kernel, dim3(K, (d + 63) / 64), dim3(256), 0, stream, a.shift, a.work, d);
     if (a.layout == 2) {
