@@ -337,25 +337,34 @@ __global__ __launch_bounds__(256, 2) void em_mstats_big_kernel(const double* __r
     // Software pipeline (round 5): the NEXT chunk's panel entries and responsibilities are requested right behind the barrier and are in
     // flight during the matrix phase of this chunk; they go to LDS at the top of the next trip. (Round 4 loaded global -> LDS between
     // the two barriers: every chunk exposed a memory round trip, the matrix pipe was 43 % busy.)
-    // thread -> (row = e / 32, sample = e % 32), e = tid + 256 t: 256-byte runs along a row of X
-    constexpr int NP = MT * SC / 256;
-    double va[NP], vb[NP], vr = 0.0, vl = 0.0;
-    const int p_s = tid & (SC - 1), p_r = tid / SC;                     // sample column, first row (rows p_r + 8 t)
-    const int r_c = tid / SC;                                           // (tid < KC * SC) component of the group
+    // Staging roles (late round 5): a thread owns ONE row of each panel (p_r = tid / 4) and eight consecutive samples of it (p_q = tid % 4):
+    // the row's address, its shift and what a row at or beyond d holds (the constant 1 / zero) are formed ONCE -- 12 registers carried
+    // through the loop -- and a chunk costs the thread 2 x 4 16-byte loads, 16 subtractions and 16 LDS writes. (Before: 16 rows per thread,
+    // e = tid + 256 t -> (row e / 32, sample e % 32): 16 row clamps, 16 64-bit address products, 16 shift loads, 32 selects and 16 8-byte
+    // loads per chunk -- ~250 vector instructions per thread and chunk beside the 128 matrix instructions of its wave, SQ_INSTS_VALU 2.7
+    // per matrix instruction; hoisting THEM out of the loop costs 40 registers and spills.)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    constexpr int NP = SC / 4 / 2;                                       // 16-byte loads per thread, panel and chunk
+    d2 va[NP], vb[NP];
+    double vr = 0.0, vl = 0.0;
+    const int p_r = tid >> 2, p_q = tid & 3;
+    const int p_s = tid & (SC - 1), r_c = tid / SC;                     // responsibilities (tid < KC * SC): sample column, component of the group
+    const int ar = a_base + p_r, br = b_base + p_r;
+    const bool la = ar < d, lb = br < d;                                // a row of X (rows beyond d - 1 re-read row d - 1: discarded below)
+    const double ca = ar == d ? 1.0 : 0.0, cb = br == d ? 1.0 : 0.0;    // the row of the constant 1, padding rows
+    const double sa = shift[la ? ar : d - 1], sb = shift[lb ? br : d - 1];
+    const d2* __restrict__ pa_src = reinterpret_cast<const d2*>(xt + (size_t)(la ? ar : d - 1) * ldx + 8 * p_q);
+    const d2* __restrict__ pb_src = reinterpret_cast<const d2*>(xt + (size_t)(lb ? br : d - 1) * ldx + 8 * p_q);
     auto prefetch = [&](uint32_t ch) {
-        const uint32_t i = ch * SC + p_s;                               // < n_pad (the allocation is padded to the tile)
-        // (the row stride is made opaque per call: the compiler would otherwise form the 16 row offsets once, outside the chunk loop, and
-        // carry them through the matrix phase -- 32 registers, which it then spills together with the values in flight)
-        size_t ldx_ = ldx;
-        asm volatile("" : "+s"(ldx_));
-        const int ar = a_base + p_r, br = b_base + p_r;                 // rows beyond d - 1 re-read row d - 1 (discarded at the LDS write)
+        const size_t o = (size_t)ch * (SC / 2);                         // (samples ch * 32 .. + 31 < n_pad: the allocation is padded to the tile)
 #pragma unroll
         for (int t = 0; t < NP; ++t) {
-            va[t] = xt[(size_t)(ar + 8 * t < d ? ar + 8 * t : d - 1) * ldx_ + i];
-            vb[t] = xt[(size_t)(br + 8 * t < d ? br + 8 * t : d - 1) * ldx_ + i];
+            va[t] = pa_src[o + t];
+            vb[t] = pb_src[o + t];
         }
         if (tid < KC * SC) {
             const int k = k0 + r_c;
+            const uint32_t i = ch * SC + p_s;
             vr = lw[(size_t)(k < K ? k : 0) * ldr + i];
             if (mode != kFromResp) vl = lse[i];
         }
@@ -369,18 +378,14 @@ __global__ __launch_bounds__(256, 2) void em_mstats_big_kernel(const double* __r
             rr[tid] = (k < K && i0 + p_s < n) ? (mode == kFromResp ? vr : exp_nonpos(vr - vl)) : 0.0;
         }
         {
-            // (an opaque zero in the row index: the 16 shift entries and the row tests are otherwise formed once, outside the chunk loop,
-            // and held in 40 registers next to 128 of accumulators)
-            int zero = 0;
-            asm volatile("" : "+v"(zero));
+            double* __restrict__ wa_ = pa + p_r * XS + 8 * p_q;
+            double* __restrict__ wb_ = pb + p_r * XS + 8 * p_q;
 #pragma unroll
             for (int t = 0; t < NP; ++t) {
-                const int r = p_r + 8 * t;
-                const int a = a_base + r + zero, b = b_base + r + zero;
-                const double sa = shift[a < d ? a : d - 1], sb = shift[b < d ? b : d - 1];
-                const double xa = va[t] - sa, xb = vb[t] - sb;
-                pa[r * XS + p_s] = a < d ? xa : (a == d ? 1.0 : 0.0);
-                pb[r * XS + p_s] = b < d ? xb : (b == d ? 1.0 : 0.0);
+                wa_[2 * t] = la ? va[t][0] - sa : ca;
+                wa_[2 * t + 1] = la ? va[t][1] - sa : ca;
+                wb_[2 * t] = lb ? vb[t][0] - sb : cb;
+                wb_[2 * t + 1] = lb ? vb[t][1] - sb : cb;
             }
         }
         __syncthreads();

@@ -11,7 +11,7 @@
 //   per panel    whiten_solve : the panel's 32 rows of W = L^-1 against the diagonal block, one thread per column of W
 //   (of W)       whiten_trail : their terms to every later row at once
 //                (the same panel of L and of W in the same launches: panel_solve_kernel = chol_rows + whiten_solve,
-//                 panel_trail_kernel = chol_trail + whiten_trail -- 3 launches per panel)
+//                 panel_trail_kernel = chol_trail + whiten_trail + the next panel's chol_diag -- 2 launches per panel)
 //   finish       sum log L_jj, c = W (mean - shift), flags, the record in the E-step's layout, the info block
 // A first form walked the earlier columns per panel (left-looking: one launch per panel and long chains per thread: 25 ms at d = 1024,
 // K = 4); with the trailing updates every launch is short and wide (3 + 2 launches per panel).
@@ -108,8 +108,26 @@ __global__ __launch_bounds__(256) void close_big_from_params_kernel(const double
     }
 }
 
-/// The panel's 32 x 32 diagonal block (rows j0 .. j0 + 31, lane = row; the terms of all columns l < j0 are in: chol_trail_kernel),
-/// factored in registers as em_close_body.hpp factors a whole d <= 32 matrix. One wave per component.
+/// A 32 x 32 diagonal block held one row per lane (lanes 0 .. 31: t[c] = entry (row, column c) with the terms of all earlier panels in),
+/// factored in registers as em_close_body.hpp factors a whole d <= 32 matrix.
+/// Column by column, each finished column's term going to every later column at once (the 31 - l updates of a step are independent
+/// of each other: issued back to back; walking an entry's terms only when its column comes up -- the form of em_close_body.hpp -- is
+/// a dependent chain of up to 31 products per step). An entry still receives its terms in ascending l.
+__device__ __forceinline__ void factor_diag_block(double (&t)[PB], int r, int nb)
+{
+#pragma unroll
+    for (int l = 0; l < PB; ++l) {
+        if (l < nb) {                                                                // (uniform)
+            const double ljj = sqrt(lane_value(t[l], l));
+            t[l] = r == l ? ljj : t[l] / ljj;                                        // (rows above the diagonal: unused)
+#pragma unroll
+            for (int c = l + 1; c < PB; ++c) t[c] -= t[l] * lane_value(t[l], c);     // L(i, j0 + l) * L(j0 + c, j0 + l)
+        }
+    }
+}
+
+/// The FIRST panel's diagonal block (rows 0 .. 31, lane = row), one wave per component. The later panels' blocks are factored by the
+/// workgroup of the trailing update that has just put the last terms into them (chol_trail_body).
 __global__ __launch_bounds__(64) void chol_diag_kernel(double* __restrict__ work, int d, int j0)
 {
     const int k = blockIdx.x, r = threadIdx.x;
@@ -120,18 +138,7 @@ __global__ __launch_bounds__(64) void chol_diag_kernel(double* __restrict__ work
     double t[PB];
 #pragma unroll
     for (int c = 0; c < PB; ++c) t[c] = (row && c < nb) ? v.L[(size_t)(j0 + c) * d + i] : 0.0;
-    // Column by column, each finished column's term going to every later column at once (the 31 - l updates of a step are independent
-    // of each other: issued back to back; walking an entry's terms only when its column comes up -- the form of em_close_body.hpp -- is
-    // a dependent chain of up to 31 products per step: 13.4 against ... us per launch). An entry still receives its terms in ascending l.
-#pragma unroll
-    for (int l = 0; l < PB; ++l) {
-        if (l < nb) {                                                                // (uniform)
-            const double ljj = sqrt(lane_value(t[l], l));
-            t[l] = r == l ? ljj : t[l] / ljj;                                        // (rows above the diagonal: unused)
-#pragma unroll
-            for (int c = l + 1; c < PB; ++c) t[c] -= t[l] * lane_value(t[l], c);     // L(i, j0 + l) * L(j0 + c, j0 + l)
-        }
-    }
+    factor_diag_block(t, r, nb);
     if (row) {
 #pragma unroll
         for (int c = 0; c < PB; ++c)
@@ -202,7 +209,23 @@ __device__ __forceinline__ void chol_trail_body(double* __restrict__ work, const
 #pragma unroll
         for (int c = 0; c < PB; ++c) t[c] -= xl * cl[c];
     }
-    if (row) {
+    if (by == 0 && bz == 0) {
+        // (uniform) this wave's lanes 0 .. 31 hold the NEXT panel's diagonal block, complete: factored here, behind the update, instead of
+        // in a launch of its own between this one and the next panel's rows (the entries above the diagonal keep the update's values,
+        // as that launch left them; lanes 32 .. 63 -- rows below the block -- are not touched: EXEC)
+        const int r = threadIdx.x;
+        if (row && r < PB) {
+#pragma unroll
+            for (int c = 0; c < PB; ++c)
+                if (c < nbc && c > r) v.L[(size_t)(jb + c) * d + i] = t[c];
+        }
+        if (r < PB) factor_diag_block(t, r, nbc);
+        if (row) {
+#pragma unroll
+            for (int c = 0; c < PB; ++c)
+                if (c < nbc && (r >= PB || c <= r)) v.L[(size_t)(jb + c) * d + i] = t[c];
+        }
+    } else if (row) {
 #pragma unroll
         for (int c = 0; c < PB; ++c)
             if (c < nbc) v.L[(size_t)(jb + c) * d + i] = t[c];
@@ -408,8 +431,8 @@ __global__ __launch_bounds__(256) void close_big_finish_kernel(const double* __r
 void factor_and_finish(const double* stats, const double* mixing, const CloseArgs& a, hipStream_t stream)
 {
     const int d = a.d, K = a.K;
+    hipLaunchKernelGGL(chol_diag_kernel, dim3(K), dim3(64), 0, stream, a.work, d, 0);
     for (int j0 = 0; j0 < d; j0 += PB) {
-        hipLaunchKernelGGL(chol_diag_kernel, dim3(K), dim3(64), 0, stream, a.work, d, j0);
         const int below = d - (j0 + PB);                                             // rows / columns behind the panel
         const int cols = j0 + PB < d ? j0 + PB : d;                                  // columns of W that hold anything but zero so far
         const int ny_chol = below > 0 ? (below + 63) / 64 : 0, ny_w = (cols + 63) / 64;
