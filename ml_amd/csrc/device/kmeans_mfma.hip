@@ -115,7 +115,7 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
     // chains run over the row, beyond that it spills); above, rolled loops that re-read the sample (unrolling would let
     // the compiler hoist all D loads back into registers)
     constexpr bool kRowInRegs = D <= (QUAD ? kRegDim : kMidDim);
-    constexpr int kExactUnroll = kRowInRegs ? D : 8;   // 8 loads in flight per trip: a trip per load is latency-bound
+    constexpr int kExactUnroll = kRowInRegs ? D : 8;   // 8 loads in flight per trip: a trip per load is latency-bound. (Late round 5: 16 per trip -- d = 128, K = 64 2.23 -> 2.12 ms but d = 96, K = 256 5.38 -> 6.51, d = 72, K = 1024 13.85 -> 14.37; with 32 the compiler issues the loads ONE at a time, each behind its own s_waitcnt vmcnt(0): 2.23 -> 4.65 ms. 8 kept.)
     constexpr int DS = D + 1;         // odd row stride of the centroid table: conflict-free A-operand reads
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int Kp = (K + 15) & ~15;
@@ -214,19 +214,22 @@ __global__ __launch_bounds__(BSM, (D <= 16) ? 4 : 2) void kmeans_mfma_kernel(
         const int rows = min(KT, Kp - k0);      // a multiple of 16
         if constexpr (CHUNKED) {
             __syncthreads();                    // every wave is done with the previous chunk
-            // the chunk is one contiguous range of the centroid array: 4 independent loads per thread in flight, then the
-            // LDS writes with the row padding (column D of a row is never read)
+            // the chunk is one contiguous range of the centroid array: LU independent loads per thread in flight, then the
+            // LDS writes with the row padding (column D of a row is never read). LU = 12 covers a 60 KB chunk in ONE round trip
+            // (4 until late round 5: three dependent round trips of ~1.5 us per chunk, longer than the chunk's 6 144 cycles of
+            // matrix instructions at d = 128 -- the accumulators are dead here, so the registers are there)
+            constexpr int LU = 12;
             const int total = rows * D;
             const double* __restrict__ src = cent + (size_t)k0 * D;
-            for (int g0 = tid; g0 < total; g0 += 4 * BSM) {
-                double v[4];
+            for (int g0 = tid; g0 < total; g0 += LU * BSM) {
+                double v[LU];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < LU; ++u) {
                     const int gi = g0 + u * BSM;
                     v[u] = (gi < total && k0 + gi / D < K) ? src[gi] : 0.0;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < LU; ++u) {
                     const int gi = g0 + u * BSM;
                     if (gi < total) Cs[(gi / D) * DS + gi % D] = v[u];
                 }

@@ -7,10 +7,11 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out; mkdir -p "$O"
 N=$1; D=$2; K=$3; shift 3
 for kv in "$@"; do export "$kv"; done
+W=${WORKLOAD:+--workload $WORKLOAD}      # WORKLOAD=kmeans: the K-means step of the shape instead of the EM iteration
 cd /tmp && export TMPDIR=/tmp
 echo "== N=$N d=$D K=$K $*"
 rm -rf "$O/spmc_trace"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/spmc_trace" -- python3 "$R/bench.py" --samples $N --dim $D --components $K --no-cpu-baseline --steps 20 --warmup 5 > "$O/spmc_trace.txt" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/spmc_trace" -- python3 "$R/bench.py" $W --samples $N --dim $D --components $K --no-cpu-baseline --steps 20 --warmup 5 > "$O/spmc_trace.txt" 2>&1
 python3 - "$O/spmc_trace" <<'PY'
 import csv, glob, sys
 for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):
@@ -20,7 +21,7 @@ PY
 for pass in "sq:SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU" "stall:SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" "mem:SQ_WAVES SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_WR"; do
     name=${pass%%:*}; counters=${pass#*:}
     rm -rf "$O/spmc_$name"
-    rocprofv3 --kernel-trace --pmc $counters --output-format csv -d "$O/spmc_$name" -- python3 "$R/bench.py" --samples $N --dim $D --components $K --no-cpu-baseline --steps 3 --warmup 1 > "$O/spmc_$name.txt" 2>&1
+    rocprofv3 --kernel-trace --pmc $counters --output-format csv -d "$O/spmc_$name" -- python3 "$R/bench.py" $W --samples $N --dim $D --components $K --no-cpu-baseline --steps 3 --warmup 1 > "$O/spmc_$name.txt" 2>&1
     python3 - "$O/spmc_$name" <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
