@@ -150,9 +150,15 @@ constexpr int GZS = GS + 16;                    // ... of the centred-sample chu
                                                 // half (kq = 0, 1) land 32 banks apart; with GS + 1 they were ONE bank pair apart and 15 of 16
                                                 // lanes collided (SQ_LDS_BANK_CONFLICT 4.6e8 of SQ_LDS_IDX_ACTIVE 7.4e8 at d = 1024)
 
+///
+/// P > 1 (late round 5): with FEW units -- a small N K against the chip's 2 x CUs workgroup slots: 1 564 units are 3.05 rounds run as 4 at
+/// N = 50k, d = 1024, K = 4, and a test-sized fit leaves most of the chip idle -- a unit's row blocks are dealt to P parts (part p takes the
+/// blocks p, 2P - 1 - p, 2P + p, 4P - 1 - p, ...: the triangle's cost in equal shares when the count is a multiple of 2P), a part being a
+/// unit of its own that leaves its share of q in q_parts[part][k][i]; em_lse_rows_kernel adds the shares in ascending part order and
+/// forms lw. P = 1 is the form above, bit for bit.
 __global__ __launch_bounds__(256, 2) void em_estep_gemm_kernel(const double* __restrict__ xt, size_t ldx, uint32_t n_pad, int D,
                                                                 const double* __restrict__ params, int K, double* __restrict__ lw_out,
-                                                                size_t ldr)
+                                                                size_t ldr, int P, double* __restrict__ q_parts)
 {
     __shared__ double Wc[2][GR * GWS];
     __shared__ double Zc[2][GC * GZS];
@@ -162,15 +168,19 @@ __global__ __launch_bounds__(256, 2) void em_estep_gemm_kernel(const double* __r
     const int wa = wave >> 1, wb = wave & 1;                           // the wave's 64 rows x 64 samples of the tile
     const size_t PS = (size_t)D + (size_t)D * (D + 1) / 2 + 1;
     const int n_rb = (D + GR - 1) / GR;
-    const uint32_t n_tiles = n_pad / GS, n_units = n_tiles * (uint32_t)K;
+    const uint32_t n_tiles = n_pad / GS, per_part = n_tiles * (uint32_t)K, n_units = per_part * (uint32_t)P;
     // staging roles: W chunk -- row w_r, columns 8 w_h .. + 7; Z chunk -- column (of W) z_j, samples z_g + 16 j (a thread's eight samples
     // interleaved with its neighbours': 16 lanes load and store 16 consecutive doubles -- eight consecutive ones per thread put the lanes
     // of a store 64 bytes apart, an 8-way bank conflict)
     const int w_r = tid >> 1, w_h = tid & 1, z_j = tid >> 4, z_g = tid & 15;
     for (uint32_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
-        const uint32_t tile = unit / (uint32_t)K;
-        const int k = (int)(unit - tile * (uint32_t)K);
+        const int part = (int)(unit / per_part);                       // (part-major: the parts of a tile are spread over the grid)
+        const uint32_t tk = unit - (uint32_t)part * per_part;
+        const uint32_t tile = tk / (uint32_t)K;
+        const int k = (int)(tk - tile * (uint32_t)K);
         const uint32_t i0 = tile * GS;
+        // the part's row blocks in ascending order: m-th is m P + part (m even), (m + 1) P - 1 - part (m odd)
+        auto rb_at = [&](int m) { return (m & 1) ? (m + 1) * P - 1 - part : m * P + part; };
         const double* __restrict__ p = params + (size_t)k * PS;
         const double* __restrict__ w = p + D;
         double qacc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -198,9 +208,10 @@ __global__ __launch_bounds__(256, 2) void em_estep_gemm_kernel(const double* __r
             for (int j = 0; j < 8; ++j) Zc[buf][z_j * GZS + z_g + 16 * j] = zv[j] - mu;
         };
         int buf = 0;
-        prefetch(0, 0);
-        for (int rb = 0; rb < n_rb; ++rb) {
+        prefetch(rb_at(0), 0);                                          // (part < P <= n_rb: the part's first block exists)
+        for (int m = 0, rb = rb_at(0); rb < n_rb; ++m, rb = rb_at(m)) {
             const int row0 = rb * GR;
+            const int rb_next = rb_at(m + 1);
             const int l_end = row0 + GR < D ? row0 + GR : D;             // columns 0 .. l_end - 1
             const int n_c = (l_end + GC - 1) / GC;
             d4 acc[4][4];
@@ -212,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void em_estep_gemm_kernel(const double* __r
                 stage(rb, c, buf);
                 __syncthreads();
                 if (c + 1 < n_c) prefetch(rb, c + 1);
-                else if (rb + 1 < n_rb) prefetch(rb + 1, 0);
+                else if (rb_next < n_rb) prefetch(rb_next, 0);
                 const double* Wb = Wc[buf] + (wa * 16 + i_r) * GWS + kq;
                 const double* Zb = Zc[buf] + kq * GZS + wb * 64 + i_r;
                 // block u of this wave: rows first_row + 32 u .. + 15 -- the tile's eight 16-row blocks dealt ALTERNATELY to the two
@@ -250,21 +261,33 @@ __global__ __launch_bounds__(256, 2) void em_estep_gemm_kernel(const double* __r
             if (kq == 0) qs[wa][wb * 64 + 16 * v + i_r] = q;
         }
         __syncthreads();
-        if (tid < GS) lw_out[(size_t)k * ldr + i0 + tid] = __builtin_fma(-0.5, qs[0][tid] + qs[1][tid], p[PS - 1]);
+        if (tid < GS) {
+            if (P == 1) lw_out[(size_t)k * ldr + i0 + tid] = __builtin_fma(-0.5, qs[0][tid] + qs[1][tid], p[PS - 1]);
+            else q_parts[((size_t)part * K + k) * ldr + i0 + tid] = qs[0][tid] + qs[1][tid];
+        }
         __syncthreads();                                               // (qs and the LDS buffers are reused by the next unit)
     }
 }
 
 /// lse_i = log sum_k exp(lw_ki) (the online form of em_estep.hip, k ascending) and the per-workgroup sums of lse over the live samples.
-__global__ __launch_bounds__(256) void em_lse_rows_kernel(const double* __restrict__ lw, size_t ldr, uint32_t n, uint32_t n_pad, int K,
-                                                           double* __restrict__ lse_out, double* __restrict__ ll_partials)
+/// P > 1: lw is formed here from the parts' shares of q (ascending part order) and the records' constants, and written.
+__global__ __launch_bounds__(256) void em_lse_rows_kernel(double* __restrict__ lw, size_t ldr, uint32_t n, uint32_t n_pad, int K,
+                                                           double* __restrict__ lse_out, double* __restrict__ ll_partials, int P,
+                                                           const double* __restrict__ q_parts, const double* __restrict__ params, size_t PS)
 {
     __shared__ double red[4];
     double ll_acc = 0.0;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_pad; i += gridDim.x * 256u) {
         double m = -__builtin_inf(), s = 0.0;
         for (int k = 0; k < K; ++k) {
-            const double v = lw[(size_t)k * ldr + i];
+            double v;
+            if (P == 1) v = lw[(size_t)k * ldr + i];
+            else {
+                double q = q_parts[(size_t)k * ldr + i];
+                for (int part = 1; part < P; ++part) q += q_parts[((size_t)part * K + k) * ldr + i];
+                v = __builtin_fma(-0.5, q, params[(size_t)k * PS + PS - 1]);
+                lw[(size_t)k * ldr + i] = v;
+            }
             const double e = exp_nonpos(v == -HUGE_VAL ? -HUGE_VAL : -fabs(v - m));
             const bool up = v > m;
             s = up ? __builtin_fma(s, e, 1.0) : s + e;
@@ -567,20 +590,62 @@ int big_dim_splits(int d, int K, int num_cus)
     return 1;
 }
 
+/// Parts a unit of the tiled E-step is cut into (1, 2, 4 or 8; at most the number of row blocks and what the scratch block holds): the
+/// count with the shortest schedule when the units are dealt round-robin to `slots` workgroups, a part costing the chunks of its row
+/// blocks (block rb: the chunks left of and on its diagonal, its rows inside W) plus a fixed share per unit (prologue, the q write).
+int estep_parts(uint32_t units1, int D, int slots, size_t max_parts)
+{
+    const int n_rb = (D + GR - 1) / GR;
+    if (const char* e = ab_env("MLHIP_ESTEP_PARTS")) {                          // (A/B runs: a given count where it is allowed)
+        const int want = std::atoi(e);
+        if (want >= 1 && want <= 8 && want <= n_rb && (want == 1 || (size_t)want <= max_parts)) return want;
+    }
+    if (units1 == 0 || units1 >= 16u * (uint32_t)slots) return 1;              // many rounds: the tail is a few per cent at most
+    int best_p = 1;
+    double best_t = 0.0;
+    for (int P = 1; P <= 8 && P <= n_rb && (P == 1 || (size_t)P <= max_parts); P *= 2) {
+        double cost[8];
+        for (int part = 0; part < P; ++part) {
+            double c = 4.0;                                                     // (fixed share, in chunks)
+            for (int m = 0;; ++m) {
+                const int rb = (m & 1) ? (m + 1) * P - 1 - part : m * P + part;
+                if (rb >= n_rb) break;
+                const int l_end = rb * GR + GR < D ? rb * GR + GR : D;
+                const int rows = l_end - rb * GR;
+                c += (double)((l_end + GC - 1) / GC) * (rows > 64 ? 1.0 : 0.6);
+            }
+            cost[part] = c;
+        }
+        // round-robin: workgroup w takes the units w, w + slots, ...; unit u belongs to part u / units1
+        const uint64_t total = (uint64_t)units1 * P;
+        double t = 0.0;
+        const uint32_t probe = total < (uint64_t)slots ? (uint32_t)total : (uint32_t)slots;
+        for (uint32_t w = 0; w < probe; w += (probe > 64 ? probe / 64 : 1)) {   // (a sample of the workgroups; the first ones carry the longest lists)
+            double tw = 0.0;
+            for (uint64_t u = w; u < total; u += (uint64_t)slots) tw += cost[u / units1];
+            if (tw > t) t = tw;
+        }
+        if (best_t == 0.0 || t < 0.97 * best_t) { best_t = t; best_p = P; }
+    }
+    return best_p;
+}
+
 int launch_em_estep_big(const EstepArgs& a, int num_cus, hipStream_t stream)
 {
     const uint32_t n_pad = padded_samples(a.n);
     static const bool tiled = [] { const char* e = ab_env("MLHIP_ESTEP_BIG"); return !(e && e[0] == 't'); }();   // "tile": round 4's kernel (A/B)
     if (tiled) {
         static_assert(kSampleTile % GS == 0, "a sample tile of the product must divide the padding granule of N");
-        const uint32_t units = n_pad / GS * (uint32_t)a.K;
+        const int P = estep_parts(n_pad / GS * (uint32_t)a.K, a.D, 2 * num_cus, a.scratch ? a.scratch_doubles / ((size_t)a.K * a.ldr) : 0);
+        const uint32_t units = n_pad / GS * (uint32_t)a.K * (uint32_t)P;
         uint32_t grid = 2u * (uint32_t)num_cus;
         if (grid > units) grid = units;
-        hipLaunchKernelGGL(em_estep_gemm_kernel, dim3(grid), dim3(256), 0, stream, a.xt, a.ldx, n_pad, a.D, a.params, a.K, a.lw, a.ldr);
+        hipLaunchKernelGGL(em_estep_gemm_kernel, dim3(grid), dim3(256), 0, stream, a.xt, a.ldx, n_pad, a.D, a.params, a.K, a.lw, a.ldr, P, a.scratch);
         uint32_t lgrid = (n_pad + 255) / 256;
         if (lgrid > (uint32_t)a.n_ll_partials) lgrid = (uint32_t)a.n_ll_partials;
         if (lgrid > 4u * (uint32_t)num_cus) lgrid = 4u * (uint32_t)num_cus;
-        hipLaunchKernelGGL(em_lse_rows_kernel, dim3(lgrid), dim3(256), 0, stream, a.lw, a.ldr, a.n, n_pad, a.K, a.lse, a.ll_partials);
+        hipLaunchKernelGGL(em_lse_rows_kernel, dim3(lgrid), dim3(256), 0, stream, a.lw, a.ldr, a.n, n_pad, a.K, a.lse, a.ll_partials, P,
+                           (const double*)a.scratch, a.params, (size_t)a.D + (size_t)a.D * (a.D + 1) / 2 + 1);
         return (int)lgrid;
     }
     const size_t smem = sizeof(double) * ((size_t)a.D * 16 + 64);     // 64.5 KB at D = 512, 128.5 KB at D = 1024

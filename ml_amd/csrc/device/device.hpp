@@ -54,6 +54,7 @@ struct EstepArgs {
     int fold;                                               // records carry -W (mu - shift) instead of the mean (d <= 32)
     int with_lse;                                           // 0: write lw only (the statistics kernel normalises)
     int num_cus;                                            // compute units of the context's device (0: ask the current device)
+    double* scratch; size_t scratch_doubles;                // a block free for the launch (the statistics partials): the big tier's q parts
 };
 /// Returns the grid size used (= number of ll partials written), or <0 if D is not instantiated.
 int launch_em_estep(const EstepArgs& a, hipStream_t stream);

@@ -122,6 +122,7 @@ void launch_estep(mlhip_data* dt, int K, bool with_lse, const DevBuf* records, i
     a.shift = dt->shift_dev.as<double>(); a.fold = (fold < 0 ? dt->estep_fold : fold != 0) ? 1 : 0;
     a.with_lse = (with_lse || dt->estep_variant != 2) ? 1 : 0;
     a.num_cus = ctx->num_cus;
+    a.scratch = dt->partials.as<double>(); a.scratch_doubles = dt->partials.bytes / sizeof(double);   // (written by the statistics kernel AFTER the E-step, on the same stream)
     int grid = 0;
     ctx->timed("em_estep", [&] {
         if (dt->estep_variant == 2) {
