@@ -220,6 +220,22 @@ struct KmeansArgs {
     double* out;                               // device: [inertia, n_changed, counts(K), sums(K*d)]
 };
 size_t kmeans_scratch_doubles(int d, int K, int num_cus);
+/// The whole step loop of KMeans::fit_once in one launch of one workgroup (kmeans_resident.hip): small blocks, few clusters, the
+/// dimensions whose step runs on the direct-form kernel. `out` is host-visible pinned memory:
+/// [steps, converged, inertia, label buffer, counts(K), centroids(K d), old centroids(K d)].
+constexpr int kKmResidentMaxN = 4096, kKmResidentMaxK = 32;
+struct KmResidentArgs {
+    const double* xt; size_t ldx; uint32_t n; int D, d, K;
+    double* cent;                              // device, [K][D]: the starting table in, the final one out
+    const double* scale;                       // device, d doubles (as KmeansArgs)
+    uint32_t* labels[2]; int label_buf, have_old;   // the two label buffers, which one holds the assignment before, whether it does
+    double* min_dist;
+    uint32_t max_steps; double atol;
+    double* out;
+    int copies;                                // (set by the launcher)
+};
+bool kmeans_resident_supported(int D, int d, int K, uint64_t n);
+bool launch_kmeans_resident(const KmResidentArgs& a, hipStream_t stream);
 /// Assignment kernel; returns the number of per-workgroup partials (>0) or <0 on error.
 int launch_kmeans_assign(const KmeansArgs& a, int num_cus, hipStream_t stream);
 void launch_kmeans_assign_generic(const KmeansArgs& a, int grid, size_t pstride, hipStream_t stream);   // d > kMaxDim (generic_dim.hip)

@@ -187,6 +187,39 @@ void km_iterate(mlhip_data* dt, int K, double* centroids, double* old_centroids,
     const bool device_route = !(ctx->reduce_fn && !ctx->reduce_on_device) && !ab_env("MLHIP_KMEANS_HOST_LOOP");
     const KmBlock b = km_block(dt, K);
     std::vector<double> cur(centroids, centroids + kd), old(kd, 0.0), upd(kd);
+    // Small blocks with few clusters in the dimensions of the direct-form kernel: the whole loop in ONE launch of one workgroup
+    // (device/kmeans_resident.hip; bit-identical to the launches below; MLHIP_RESIDENT=0: off).
+    const char* const res_env = std::getenv("MLHIP_RESIDENT");                 // (per call, as the EM loop reads it: the tests flip it)
+    const bool resident_allowed = !(res_env && res_env[0] == '0');
+    if (device_route && !ctx->reduce_fn && ctx->world_size <= 1 && b.xt == dt->xt.as<double>() && resident_allowed &&
+        kmeans_resident_supported(b.D, d, K, dt->n)) {
+        const size_t n_out = 4 + (size_t)K + 2 * kd;
+        dt->km_host.reserve(sizeof(double) * (n_out > (size_t)K * b.D ? n_out : (size_t)K * b.D));
+        km_upload_centroids(dt, K, b, cur.data());
+        KmResidentArgs a{};
+        a.xt = b.xt; a.ldx = dt->ldx; a.n = dt->n; a.D = b.D; a.d = d; a.K = K;
+        a.cent = dt->km_cent.as<double>(); a.scale = dt->km_scale.as<double>();
+        a.labels[0] = dt->km_labels[0].as<uint32_t>(); a.labels[1] = dt->km_labels[1].as<uint32_t>();
+        a.label_buf = dt->km_cur; a.have_old = dt->km_have_old ? 1 : 0;
+        a.min_dist = dt->km_mind.as<double>();
+        a.max_steps = max_steps; a.atol = atol;
+        a.out = dt->km_host.as<double>();
+        bool ok = false;
+        ctx->timed("kmeans_resident", [&] { ok = launch_kmeans_resident(a, ctx->stream); });
+        if (!ok) throw std::runtime_error("resident K-means kernel not instantiated for this dimension");
+        HIP_CHECK(hipGetLastError());
+        ctx->sync();
+        const double* r = dt->km_host.as<double>();
+        *steps_done = (uint32_t)std::llround(r[0]);
+        *converged = r[1] != 0.0 ? 1 : 0;
+        *inertia = r[2];
+        dt->km_cur = (int)std::llround(r[3]);
+        dt->km_have_old = true;
+        if (counts) std::copy(r + 4, r + 4 + K, counts);
+        std::copy(r + 4 + K, r + 4 + K + kd, centroids);
+        if (old_centroids) std::copy(r + 4 + K + kd, r + 4 + K + 2 * kd, old_centroids);
+        return;
+    }
     if (device_route) {
         dt->km_cent_next.reserve(sizeof(double) * (size_t)K * b.D);
         km_upload_centroids(dt, K, b, cur.data());
