@@ -1,6 +1,7 @@
 #include "DeviceInit.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <iterator>
 #include <limits>
@@ -287,6 +288,7 @@ void init_centroids(const CentroidsInitialiser& initialiser, ConstMatrixRef data
     // than that bound (about 8 N^2 2^-53 of them) comes back for the sequential evaluation below. The N-long host passes per
     // centroid were 50x the K-means iterations they prepare at N = 1M, K = 64.
     const bool device_draw = count >= 32768;
+    constexpr std::size_t kHostDistanceRows = 4096;
     std::vector<double> weights(device_draw ? 0 : count, 1.0), latest;
     for (unsigned int chosen = 0; chosen < number_components; ++chosen) {
         if (device_draw) {
@@ -329,7 +331,23 @@ void init_centroids(const CentroidsInitialiser& initialiser, ConstMatrixRef data
             // squared distance of every sample to the centroid chosen last; weights = running minimum
             std::vector<double>& target = chosen == 1 ? weights : latest;
             target.resize(count);
-            device::check(mlhip_min_squared_distances(ctx, device_data, 1, centroids.col(chosen - 1), target.data()));
+            if (count <= kHostDistanceRows) {
+                // a few thousand rows: the distances here, from the caller's own array, with the kernels' arithmetic (ascending-j chain
+                // s = fma(x_j - c_j, x_j - c_j, s): the same bits, so the same draws) -- a launch, an N-long download and a wait per
+                // centroid cost ~50 us, more than the whole step loop of such a fit
+                const double* c = centroids.col(chosen - 1);
+                for (std::size_t i = 0; i < count; ++i) {
+                    const double* x = data.col(static_cast<Index>(i));
+                    double s = 0.0;
+                    for (Index j = 0; j < d; ++j) {
+                        const double t = x[j] - c[j];
+                        s = std::fma(t, t, s);
+                    }
+                    target[i] = s;
+                }
+            } else {
+                device::check(mlhip_min_squared_distances(ctx, device_data, 1, centroids.col(chosen - 1), target.data()));
+            }
             if (chosen == 1) {
                 for (std::size_t i = 0; i < count; ++i) sum += weights[i];
             } else {
