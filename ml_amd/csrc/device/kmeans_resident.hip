@@ -1,8 +1,8 @@
 // The WHOLE step loop of KMeans::fit_once (reference ML/KMeans.cpp:80-110: assignment_step, update_step, the "same labels twice" and
 // "centroids moved less than the tolerance" tests) in ONE launch of ONE workgroup, for the reference's own benchmark regime
 // (Benchmarks/bm_KMeans.cpp: d = 2, K = 3, N = 100 ... 100 000, three initialisations per fit). As three dependent launches and a
-// read-back per step (assignment kernel, reduction, closing: runtime/kmeans.cpp km_iterate) such a step costs 33 us whatever N is, and a
-// fit of 3 x 15 steps on 10 000 points takes 1.7 ms against 3.1 ms on one CPU core.
+// read-back per step (assignment kernel, reduction, closing: runtime/kmeans.cpp km_iterate) such a step costs 21 us whatever N is; here a
+// step of a block that one workgroup holds costs 7 - 10 us (tools/kmeans_resident_time.py).
 //
 // With at most 4 096 samples (2-d; 1 024 in 6 dimensions) one workgroup of 1024 threads holds the whole problem IN REGISTERS: the centroid table, the exact accumulator words and
 // the stopping tests live in LDS, the steps are separated by workgroup barriers -- no exchange between workgroups, nothing to wait for
